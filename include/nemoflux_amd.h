@@ -1,0 +1,189 @@
+/*
+ * nemoflux_amd.h -- C ABI of libnemoflux_amd.so, the MI355X (gfx950) transect-flux engine.
+ *
+ * This is the drop-in boundary for nemoflux's hot path.  Two levels:
+ *
+ *   Level 1  mnt_grid_* / mnt_polylineintegral_*  -- the entry points nemoflux reaches in the
+ *            un-vendored `mint` C library through its ctypes wrapper (python-mint >= 1.24.4,
+ *            /root/reference/README.md:12).  Same names, argument order, handle convention
+ *            (opaque object passed as T**) and error convention (int return, 0 = OK) as mint's
+ *            C API, so nemoflux/horizgrid.py:23-24,30,43 and nemoflux/field.py:45-48,102 run
+ *            unchanged on top of nemoflux_amd/mint.py.
+ *   Level 2  nf_field_*  -- the Field-shaped engine (nemoflux/field.py:15-234): geometry set-up,
+ *            per-time-step vertical integration + edge flux (the bandwidth-bound kernel), batched
+ *            transect weights and the per-segment / per-transect reduction, with U/V resident in HBM
+ *            and (t,z) slab ownership for multi-GPU runs.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in any signature (streams travel as void*).
+ *   - every function returns 0 on success, non-zero on error; nf_last_error() gives the message.
+ *   - "host" pointers are ordinary CPU memory owned by the caller; "dev" pointers are HBM addresses
+ *     of the current device (e.g. torch.Tensor.data_ptr() or nf_malloc()).
+ *   - all entry points are synchronous at return unless the name ends in _async.
+ *   - there is NO CPU fallback: every compute entry point fails with NF_ERR_NO_DEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef NEMOFLUX_AMD_H
+#define NEMOFLUX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NF_OK 0
+#define NF_ERR_ARG 1        /* bad argument / shape (the reference raises RuntimeError: field.py:135,154) */
+#define NF_ERR_STATE 2      /* call order violated (e.g. computeWeights before setGrid) */
+#define NF_ERR_HIP 3        /* a HIP runtime call failed */
+#define NF_ERR_NO_DEVICE 4  /* no usable GPU: the engine never falls back to the CPU */
+
+#define NF_F64 0
+#define NF_F32 1
+
+/* mint.CELL_BY_CELL_DATA / mint.UNIQUE_EDGE_DATA (field.py:102 uses the former) */
+#define MNT_CELL_BY_CELL_DATA 0
+#define MNT_UNIQUE_EDGE_DATA 1
+
+/* ------------------------------------------------------------------ library / device plumbing */
+const char *nf_last_error(void);
+int nf_version(void);
+int nf_device_count(int *count);
+int nf_set_device(int device);
+int nf_device_name(char *buf, int buflen); /* e.g. "gfx950:..." */
+int nf_malloc(void **dev, size_t bytes);
+int nf_free(void *dev);
+int nf_host_alloc(void **host, size_t bytes); /* pinned host memory (fast D2H into numpy views) */
+int nf_host_free(void *host);
+int nf_memcpy_h2d(void *dev, const void *host, size_t bytes);
+int nf_memcpy_d2h(void *host, const void *dev, size_t bytes);
+int nf_memset(void *dev, int value, size_t bytes);
+int nf_synchronize(void);
+
+/* ------------------------------------------------------------------ Level 1: mint-shaped API */
+typedef struct Grid_t Grid_t;
+typedef struct PolylineIntegral_t PolylineIntegral_t;
+
+/* mint.Grid()                                   horizgrid.py:23 */
+int mnt_grid_new(Grid_t **self);
+int mnt_grid_del(Grid_t **self);
+/* mint.Grid.setPoints(points (ncell,4,3) float64)  horizgrid.py:24.  `points` is BORROWED (host) and
+ * must outlive the grid, as in mint; the corner (lon,lat) pairs are uploaded to HBM by mnt_grid_build. */
+int mnt_grid_setPointsPtr(Grid_t **self, double *points);
+int mnt_grid_build(Grid_t **self, int nVertsPerCell, long long ncells);
+/* mint.Grid.getNumberOfCells()                  horizgrid.py:30 */
+int mnt_grid_getNumberOfCells(Grid_t **self, size_t *numCells);
+/* mint.Grid.dump(fileName): legacy-VTK unstructured grid  horizgrid.py:43 */
+int mnt_grid_dump(Grid_t **self, const char *fileName);
+
+/* mint.PolylineIntegral()                       field.py:45 */
+int mnt_polylineintegral_new(PolylineIntegral_t **self);
+int mnt_polylineintegral_del(PolylineIntegral_t **self);
+/* .setGrid(grid)                                field.py:46 */
+int mnt_polylineintegral_setGrid(PolylineIntegral_t **self, Grid_t *grid);
+/* .buildLocator(numCellsPerBucket=128, periodX=360., enableFolding=False)   field.py:47
+ * numCellsPerBucket sets the cull-tile size (rounded to the 64-cell wavefront tile); enableFolding != 0
+ * is rejected (nemoflux never enables it). */
+int mnt_polylineintegral_buildLocator(PolylineIntegral_t **self, int numCellsPerBucket, double periodX,
+                                      int enableFolding);
+/* .computeWeights(xyz (npoints,3), counterclock=False)   field.py:48 */
+int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, const double xyz[],
+                                        int counterclock);
+/* .getIntegral(data (ncell,4) float64 HOST, placement) -> *result   field.py:102, fluxplot.py:56
+ * Host data is staged to HBM (PCIe-inclusive path); see ...getIntegralDev for resident data. */
+int mnt_polylineintegral_getIntegral(PolylineIntegral_t **self, const double data[], int placement,
+                                     double *result);
+/* extensions (not in mint): device-resident data, per-target-segment sums, weight read-back */
+int mnt_polylineintegral_getIntegralDev(PolylineIntegral_t **self, const double *data_dev, int placement,
+                                        double *result, double *seg_totals_host /* nseg or NULL */);
+int mnt_polylineintegral_getNumberOfWeights(PolylineIntegral_t **self, size_t *n);
+int mnt_polylineintegral_getWeights(PolylineIntegral_t **self, int64_t *cell_edge, double *weight, int *seg);
+
+/* ------------------------------------------------------------------ Level 2: Field-shaped engine */
+typedef struct nf_field nf_field;
+
+int nf_field_new(nf_field **self);
+int nf_field_del(nf_field **self);
+/* HIP stream all of this field's kernels and copies are issued on (NULL = the null stream, which is
+ * also torch's default current stream). */
+int nf_field_set_stream(nf_field **self, void *hip_stream);
+/* Cell bounds (field.py:22-24, horizgrid.py:12-24): bounds_lon/lat (ny,nx,4), dtype NF_F64 (datagen) or
+ * NF_F32 (real NEMO), host (on_device=0) or HBM (1).  Runs the geometry kernel: corner table, great-circle
+ * edge lengths (field.py:170-181), lon/lat box (field.py:27-30). */
+int nf_field_set_bounds(nf_field **self, const void *bounds_lon, const void *bounds_lat, long ny, long nx,
+                        int dtype, int on_device);
+/* Layer thickness = deptht_bounds[:,1]-deptht_bounds[:,0] (field.py:51), host, nz values. */
+int nf_field_set_thickness(nf_field **self, const double *thickness, long nz);
+/* uo/vo (nt,nz,ny,nx) x-fastest (field.py:34-35,122-136).  on_device=1: HBM pointers, used in place (no
+ * copy).  on_device=0: host arrays, one time step is staged through HBM per compute call.  fill_value:
+ * the variable's _FillValue (datagen.py:191,204: 1e20) -- NaN and fill_value both count as missing ->
+ * 0 (field.py:157); pass NaN for "no _FillValue". */
+int nf_field_set_uv(nf_field **self, const void *u, const void *v, long nt, int dtype, int on_device,
+                    double fill_value);
+/* field.py:19,225-228: scale fluxes by 6371000/1e6 */
+int nf_field_set_sverdrup(nf_field **self, int sverdrup);
+/* Multi-GPU ownership: this rank integrates the flattened slabs s = t*nz + z in [s_begin, s_end)
+ * (SURVEY.md section 8e).  Default: all of them. */
+int nf_field_set_slab_range(nf_field **self, long s_begin, long s_end);
+/* Transects (field.py:43-49): add polylines, then build all weights in one batched pass.
+ * xyz: (npts,3) host.  *transect_id receives the index. */
+int nf_field_add_transect(nf_field **self, const double *xyz, int npts, int counterclock, int *transect_id);
+int nf_field_build_weights(nf_field **self, int numCellsPerBucket, double periodX);
+int nf_field_num_transects(nf_field **self, int *n);
+int nf_field_num_segments(nf_field **self, int *nseg_total);             /* over all transects */
+int nf_field_segment_offsets(nf_field **self, int *offsets /* ntransect+1 */);
+int nf_field_num_weights(nf_field **self, size_t *n);
+int nf_field_get_weights(nf_field **self, int64_t *cell_edge, double *weight, int *seg_global);
+/* Length of one output row: nseg_total + ntransect doubles = [per-segment sums | per-transect sums]. */
+int nf_field_row_length(nf_field **self, int *n);
+
+/* One time step (Field.update + getFluxText's integrals: field.py:112-120,98-103): vertical integral of
+ * this rank's slabs of step tIndex, edge fluxes into the resident integratedVelocity, then the transect
+ * reduction.  row_host (row_length doubles) may be NULL. */
+int nf_field_compute_flux(nf_field **self, long tIndex, double *row_host);
+/* All nt steps back to back, asynchronously on the field's stream; rows_dev: HBM (nt, row_length),
+ * fully overwritten (zeros where this rank owns no slab).  This is the timed "step" of bench.py. */
+int nf_field_compute_all_async(nf_field **self, double *rows_dev);
+/* Read-back of the resident per-step arrays into caller-owned HOST arrays, in place (fluxviz.py aliases
+ * them: fluxviz.py:148,160,168): integratedVelocity (ncell,4), edgeFluxesU/V (ncell) = |flux|; any may be
+ * NULL.  max_abs: running max (field.py:234). */
+int nf_field_read_step(nf_field **self, double *iV_host, double *eU_host, double *eV_host, double *max_abs);
+int nf_field_reset_max(nf_field **self);
+int nf_field_get_arclengths(nf_field **self, double *arc_host /* (ncell,4) */);
+int nf_field_get_points(nf_field **self, double *points_host /* (ncell,4,3) */);
+int nf_field_get_box(nf_field **self, double *lonmin, double *lonmax, double *latmin, double *latmax);
+/* HBM addresses of resident arrays (for zero-copy consumers / RCCL): which = 0 integratedVelocity,
+ * 1 |eU|, 2 |eV|, 3 arcLengths (ncell,4), 4 corner table (ncell,4,2) */
+int nf_field_device_ptr(nf_field **self, int which, void **dev);
+/* A Grid_t view of the field's corner table (so mint.PolylineIntegral objects can share it). */
+int nf_field_grid(nf_field **self, Grid_t **grid);
+/* Kernel timing with HIP events on the field's stream, around the vertical-integral+edge-flux launches
+ * (bench.py's roofline leg): enable, run, then read (launch count, total ms). */
+int nf_field_timing(nf_field **self, int enable);
+int nf_field_timing_read(nf_field **self, long *launches, double *total_ms);
+
+/* ------------------------------------------------------------------ synthetic data (datagen.py) */
+/* Stream functions offered on device (no eval on the GPU): psi = g(z,t) * h(x,y)
+ *   0 "x"                                                    README.md:26
+ *   1 "arctan2(y, x+180)/(2*pi)"                             README.md:50
+ *   2 "cos(2*pi*y/360) + sin(2*pi*x/360)"                    README.md:65
+ *   3 "(1+10*z)*(t+1)*(cos(2*pi*y/360) + sin(2*pi*x/360))"   README.md:89
+ *   4 "(cos(t*2*pi/nt)+2)*(0.5*(y/180)**2 + sin(2*pi*x/360))" datagen.py:211 (default)
+ *   5 "(1+10*z)*(t+1)*arctan2(y, x+180)/(2*pi)"              (config C4's modulated singular case) */
+#define NF_PSI_COUNT 6
+/* datagen.py:42-66 (+ rotatePole :116-166 when deltaDeg != (0,0)): writes bounds_lon/lat (ny,nx,4) f64
+ * into HBM.  lat_uses_dx=1 reproduces datagen.py:49 (latitude spaced with dx). */
+int nf_datagen_bounds(double *bounds_lon_dev, double *bounds_lat_dev, long ny, long nx, double xmin,
+                      double xmax, double ymin, double ymax, double delta_lon_deg, double delta_lat_deg,
+                      int lat_uses_dx, void *hip_stream);
+/* datagen.py:69-113 for time steps [t_begin, t_end): writes u,v ((t_end-t_begin),nz,ny,nx) of dtype into
+ * HBM; nt is the series length (enters psi 4).  zhalf_k = zmin+(k+0.5)dz. */
+int nf_datagen_uv(void *u_dev, void *v_dev, int dtype, long t_begin, long t_end, long nt, long nz, long ny,
+                  long nx, double xmin, double xmax, double ymin, double ymax, double zmin, double zmax,
+                  int lat_uses_dx, int psi, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEMOFLUX_AMD_H */

@@ -1,0 +1,885 @@
+// nf_capi.hip -- the C ABI of libnemoflux_amd.so (declared in include/nemoflux_amd.h).
+//
+// Level 1 mirrors the entry points nemoflux reaches in the mint C library through python-mint's ctypes
+// wrapper (horizgrid.py:23-24,30,43; field.py:45-48,102); Level 2 is the Field-shaped engine
+// (field.py:15-234).  Host-side orchestration only: every number is produced by the HIP kernels of
+// nf_geom.hip / nf_flux.hip / nf_weights.hip / nf_integral.hip / nf_datagen.hip.  There is no CPU path.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "nf_common.h"
+
+namespace nf {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    g_err = buf;
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? NF_ERR_NO_DEVICE : NF_ERR_HIP;
+}
+
+static int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no usable AMD GPU (hipGetDeviceCount); nemoflux_amd has no CPU fallback");
+        return NF_ERR_NO_DEVICE;
+    }
+    return NF_OK;
+}
+#define NF_NEED_DEVICE()                      \
+    do {                                      \
+        int rc_ = nf::require_device();       \
+        if (rc_ != NF_OK) return rc_;         \
+    } while (0)
+#define NF_TRY(call)                  \
+    do {                              \
+        int rc_ = (call);             \
+        if (rc_ != NF_OK) return rc_; \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(T **p, size_t count)
+{
+    NF_HIP(hipMalloc((void **)p, sizeof(T) * (count ? count : 1)));
+    return NF_OK;
+}
+template <typename T>
+static void dev_free(T *&p)
+{
+    if (p) (void)hipFree((void *)p);
+    p = nullptr;
+}
+
+}  // namespace nf
+
+using namespace nf;
+
+// =============================================================================================== plumbing
+extern "C" {
+
+const char *nf_last_error(void) { return g_err.c_str(); }
+int nf_version(void) { return 100; }
+
+int nf_device_count(int *count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return NF_OK;
+}
+int nf_set_device(int device)
+{
+    NF_NEED_DEVICE();
+    NF_HIP(hipSetDevice(device));
+    return NF_OK;
+}
+int nf_device_name(char *buf, int buflen)
+{
+    NF_NEED_DEVICE();
+    int dev = 0;
+    NF_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    NF_HIP(hipGetDeviceProperties(&p, dev));
+    snprintf(buf, buflen, "%s:%s:%dCU", p.gcnArchName, p.name, p.multiProcessorCount);
+    return NF_OK;
+}
+int nf_malloc(void **dev, size_t bytes)
+{
+    NF_NEED_DEVICE();
+    NF_HIP(hipMalloc(dev, bytes ? bytes : 16));
+    return NF_OK;
+}
+int nf_free(void *dev)
+{
+    if (dev) NF_HIP(hipFree(dev));
+    return NF_OK;
+}
+int nf_host_alloc(void **host, size_t bytes)
+{
+    NF_NEED_DEVICE();
+    NF_HIP(hipHostMalloc(host, bytes ? bytes : 16, hipHostMallocDefault));
+    return NF_OK;
+}
+int nf_host_free(void *host)
+{
+    if (host) NF_HIP(hipHostFree(host));
+    return NF_OK;
+}
+int nf_memcpy_h2d(void *dev, const void *host, size_t bytes)
+{
+    NF_NEED_DEVICE();
+    NF_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+    return NF_OK;
+}
+int nf_memcpy_d2h(void *host, const void *dev, size_t bytes)
+{
+    NF_NEED_DEVICE();
+    NF_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    return NF_OK;
+}
+int nf_memset(void *dev, int value, size_t bytes)
+{
+    NF_NEED_DEVICE();
+    NF_HIP(hipMemset(dev, value, bytes));
+    return NF_OK;
+}
+int nf_synchronize(void)
+{
+    NF_NEED_DEVICE();
+    NF_HIP(hipDeviceSynchronize());
+    return NF_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================================== Level 1
+struct Grid_t {
+    long ncell = 0;
+    double *host_points = nullptr;  // borrowed (ncell,4,3)
+    double *d_xy = nullptr;         // corner table (ncell,4,2)
+    bool owns_xy = true;
+};
+
+struct PolylineIntegral_t {
+    Grid_t *grid = nullptr;
+    bool locator = false;
+    double periodX = 0.0;
+    WeightSet ws;
+    int *d_tr_off = nullptr;
+    double *d_scratch = nullptr;
+    double *d_row = nullptr;
+    double *d_stage = nullptr;  // host data staged to HBM for getIntegral
+    long stage_cells = 0;
+    int nseg = 0;
+};
+
+extern "C" {
+
+int mnt_grid_new(Grid_t **self)
+{
+    *self = new Grid_t();
+    return NF_OK;
+}
+int mnt_grid_del(Grid_t **self)
+{
+    if (self && *self) {
+        if ((*self)->owns_xy) dev_free((*self)->d_xy);
+        delete *self;
+        *self = nullptr;
+    }
+    return NF_OK;
+}
+int mnt_grid_setPointsPtr(Grid_t **self, double *points)
+{
+    NF_REQUIRE(self && *self && points, NF_ERR_ARG, "mnt_grid_setPointsPtr: null argument");
+    (*self)->host_points = points;
+    return NF_OK;
+}
+int mnt_grid_build(Grid_t **self, int nVertsPerCell, long long ncells)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_grid_build: null grid");
+    Grid_t *g = *self;
+    NF_REQUIRE(nVertsPerCell == 4, NF_ERR_ARG, "mnt_grid_build: only quad cells (4 vertices) are supported");
+    NF_REQUIRE(g->host_points, NF_ERR_STATE, "mnt_grid_build: setPointsPtr first");
+    NF_REQUIRE(ncells > 0 && ncells < (1ll << 31), NF_ERR_ARG, "mnt_grid_build: bad cell count");
+    NF_NEED_DEVICE();
+    if (g->owns_xy) dev_free(g->d_xy);
+    g->owns_xy = true;
+    g->ncell = (long)ncells;
+    double *d_points = nullptr;
+    NF_TRY(dev_alloc(&d_points, (size_t)ncells * 12));
+    NF_TRY(dev_alloc(&g->d_xy, (size_t)ncells * 8));
+    hipError_t e = hipMemcpy(d_points, g->host_points, sizeof(double) * 12 * (size_t)ncells, hipMemcpyHostToDevice);
+    int rc = (e == hipSuccess) ? launch_corner_table_from_points(d_points, g->ncell, g->d_xy, nullptr) : NF_ERR_HIP;
+    hipError_t e2 = hipDeviceSynchronize();
+    dev_free(d_points);
+    NF_HIP(e);
+    NF_HIP(e2);
+    return rc;
+}
+int mnt_grid_getNumberOfCells(Grid_t **self, size_t *numCells)
+{
+    NF_REQUIRE(self && *self && numCells, NF_ERR_ARG, "mnt_grid_getNumberOfCells: null argument");
+    *numCells = (size_t)(*self)->ncell;
+    return NF_OK;
+}
+int mnt_grid_dump(Grid_t **self, const char *fileName)
+{
+    NF_REQUIRE(self && *self && fileName, NF_ERR_ARG, "mnt_grid_dump: null argument");
+    Grid_t *g = *self;
+    NF_REQUIRE(g->ncell > 0, NF_ERR_STATE, "mnt_grid_dump: grid not built");
+    std::vector<double> pts;
+    const double *p = g->host_points;
+    if (!p) {  // grid view of a Field: rebuild (lon,lat,0) from the corner table
+        NF_NEED_DEVICE();
+        double *d_points = nullptr;
+        NF_TRY(dev_alloc(&d_points, (size_t)g->ncell * 12));
+        int rc = launch_points_from_corner_table(g->d_xy, g->ncell, d_points, nullptr);
+        pts.resize((size_t)g->ncell * 12);
+        hipError_t e = hipMemcpy(pts.data(), d_points, sizeof(double) * pts.size(), hipMemcpyDeviceToHost);
+        dev_free(d_points);
+        NF_TRY(rc);
+        NF_HIP(e);
+        p = pts.data();
+    }
+    FILE *f = fopen(fileName, "w");
+    NF_REQUIRE(f, NF_ERR_ARG, std::string("mnt_grid_dump: cannot open ") + fileName);
+    fprintf(f, "# vtk DataFile Version 3.0\nnemoflux_amd grid\nASCII\nDATASET UNSTRUCTURED_GRID\n");
+    fprintf(f, "POINTS %ld double\n", g->ncell * 4);
+    for (long k = 0; k < g->ncell * 4; ++k) fprintf(f, "%.17g %.17g %.17g\n", p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+    fprintf(f, "CELLS %ld %ld\n", g->ncell, g->ncell * 5);
+    for (long c = 0; c < g->ncell; ++c) fprintf(f, "4 %ld %ld %ld %ld\n", 4 * c, 4 * c + 1, 4 * c + 2, 4 * c + 3);
+    fprintf(f, "CELL_TYPES %ld\n", g->ncell);
+    for (long c = 0; c < g->ncell; ++c) fprintf(f, "9\n");  // VTK_QUAD
+    fclose(f);
+    return NF_OK;
+}
+
+int mnt_polylineintegral_new(PolylineIntegral_t **self)
+{
+    *self = new PolylineIntegral_t();
+    return NF_OK;
+}
+int mnt_polylineintegral_del(PolylineIntegral_t **self)
+{
+    if (self && *self) {
+        PolylineIntegral_t *p = *self;
+        p->ws.release();
+        dev_free(p->d_tr_off);
+        dev_free(p->d_scratch);
+        dev_free(p->d_row);
+        dev_free(p->d_stage);
+        delete p;
+        *self = nullptr;
+    }
+    return NF_OK;
+}
+int mnt_polylineintegral_setGrid(PolylineIntegral_t **self, Grid_t *grid)
+{
+    NF_REQUIRE(self && *self && grid, NF_ERR_ARG, "mnt_polylineintegral_setGrid: null argument");
+    NF_REQUIRE(grid->ncell > 0 && grid->d_xy, NF_ERR_STATE, "mnt_polylineintegral_setGrid: grid not built");
+    (*self)->grid = grid;
+    return NF_OK;
+}
+int mnt_polylineintegral_buildLocator(PolylineIntegral_t **self, int numCellsPerBucket, double periodX,
+                                      int enableFolding)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_polylineintegral_buildLocator: null argument");
+    NF_REQUIRE((*self)->grid, NF_ERR_STATE, "mnt_polylineintegral_buildLocator: setGrid first");
+    NF_REQUIRE(numCellsPerBucket > 0, NF_ERR_ARG, "mnt_polylineintegral_buildLocator: numCellsPerBucket <= 0");
+    NF_REQUIRE(periodX >= 0.0, NF_ERR_ARG, "mnt_polylineintegral_buildLocator: negative periodX");
+    NF_REQUIRE(!enableFolding, NF_ERR_ARG, "mnt_polylineintegral_buildLocator: enableFolding is not supported");
+    (*self)->periodX = periodX;
+    (*self)->locator = true;  // the cull tile is the 64-cell wavefront tile, rebuilt inside computeWeights
+    return NF_OK;
+}
+
+static int polyline_segments(const double *xyz, int npoints, int counterclock, std::vector<double> &segs,
+                             std::vector<int> &cc)
+{
+    for (int s = 0; s + 1 < npoints; ++s) {
+        segs.push_back(xyz[3 * s]);
+        segs.push_back(xyz[3 * s + 1]);
+        segs.push_back(xyz[3 * (s + 1)] - xyz[3 * s]);
+        segs.push_back(xyz[3 * (s + 1) + 1] - xyz[3 * s + 1]);
+        cc.push_back(counterclock ? 1 : 0);
+    }
+    return npoints > 1 ? npoints - 1 : 0;
+}
+
+int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, const double xyz[],
+                                        int counterclock)
+{
+    NF_REQUIRE(self && *self && xyz, NF_ERR_ARG, "mnt_polylineintegral_computeWeights: null argument");
+    PolylineIntegral_t *p = *self;
+    NF_REQUIRE(p->grid && p->locator, NF_ERR_STATE, "mnt_polylineintegral_computeWeights: setGrid/buildLocator first");
+    NF_REQUIRE(npoints >= 2, NF_ERR_ARG, "mnt_polylineintegral_computeWeights: need at least 2 points");
+    NF_NEED_DEVICE();
+    std::vector<double> segs;
+    std::vector<int> cc;
+    p->nseg = polyline_segments(xyz, npoints, counterclock, segs, cc);
+    NF_TRY(build_weights(p->grid->d_xy, p->grid->ncell, segs.data(), cc.data(), p->nseg, p->periodX, &p->ws, nullptr));
+    dev_free(p->d_tr_off);
+    dev_free(p->d_scratch);
+    dev_free(p->d_row);
+    NF_TRY(dev_alloc(&p->d_tr_off, 2));
+    NF_TRY(dev_alloc(&p->d_scratch, (size_t)p->ws.n));
+    NF_TRY(dev_alloc(&p->d_row, (size_t)p->nseg + 1));
+    const int off[2] = {0, p->nseg};
+    NF_HIP(hipMemcpy(p->d_tr_off, off, sizeof off, hipMemcpyHostToDevice));
+    return NF_OK;
+}
+
+int mnt_polylineintegral_getIntegralDev(PolylineIntegral_t **self, const double *data_dev, int placement,
+                                        double *result, double *seg_totals_host)
+{
+    NF_REQUIRE(self && *self && data_dev && result, NF_ERR_ARG, "mnt_polylineintegral_getIntegral: null argument");
+    PolylineIntegral_t *p = *self;
+    NF_REQUIRE(p->d_row, NF_ERR_STATE, "mnt_polylineintegral_getIntegral: computeWeights first");
+    NF_REQUIRE(placement == MNT_CELL_BY_CELL_DATA, NF_ERR_ARG,
+               "mnt_polylineintegral_getIntegral: only CELL_BY_CELL_DATA is supported (field.py:102)");
+    NF_NEED_DEVICE();
+    NF_TRY(launch_integral(p->ws, data_dev, p->grid->ncell, 0, p->d_tr_off, 1, p->d_scratch, p->d_row, nullptr));
+    std::vector<double> row((size_t)p->nseg + 1);
+    NF_HIP(hipMemcpy(row.data(), p->d_row, sizeof(double) * row.size(), hipMemcpyDeviceToHost));
+    *result = row[p->nseg];
+    if (seg_totals_host) memcpy(seg_totals_host, row.data(), sizeof(double) * p->nseg);
+    return NF_OK;
+}
+
+int mnt_polylineintegral_getIntegral(PolylineIntegral_t **self, const double data[], int placement, double *result)
+{
+    NF_REQUIRE(self && *self && data && result, NF_ERR_ARG, "mnt_polylineintegral_getIntegral: null argument");
+    PolylineIntegral_t *p = *self;
+    NF_REQUIRE(p->grid, NF_ERR_STATE, "mnt_polylineintegral_getIntegral: setGrid first");
+    NF_NEED_DEVICE();
+    if (p->stage_cells != p->grid->ncell) {
+        dev_free(p->d_stage);
+        NF_TRY(dev_alloc(&p->d_stage, (size_t)p->grid->ncell * 4));
+        p->stage_cells = p->grid->ncell;
+    }
+    NF_HIP(hipMemcpy(p->d_stage, data, sizeof(double) * 4 * (size_t)p->grid->ncell, hipMemcpyHostToDevice));
+    return mnt_polylineintegral_getIntegralDev(self, p->d_stage, placement, result, nullptr);
+}
+
+int mnt_polylineintegral_getNumberOfWeights(PolylineIntegral_t **self, size_t *n)
+{
+    NF_REQUIRE(self && *self && n, NF_ERR_ARG, "mnt_polylineintegral_getNumberOfWeights: null argument");
+    *n = (size_t)(*self)->ws.n;
+    return NF_OK;
+}
+int mnt_polylineintegral_getWeights(PolylineIntegral_t **self, int64_t *cell_edge, double *weight, int *seg)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_polylineintegral_getWeights: null argument");
+    const WeightSet &w = (*self)->ws;
+    if (w.n == 0) return NF_OK;
+    NF_NEED_DEVICE();
+    if (cell_edge) NF_HIP(hipMemcpy(cell_edge, w.cell_edge, sizeof(int64_t) * w.n, hipMemcpyDeviceToHost));
+    if (weight) NF_HIP(hipMemcpy(weight, w.weight, sizeof(double) * w.n, hipMemcpyDeviceToHost));
+    if (seg) NF_HIP(hipMemcpy(seg, w.seg, sizeof(int) * w.n, hipMemcpyDeviceToHost));
+    return NF_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================================== Level 2
+struct nf_field {
+    hipStream_t stream = nullptr;
+    long ny = 0, nx = 0, ncell = 0, nz = 0, nt = 0;
+    // geometry
+    double *d_xy = nullptr, *d_arc4 = nullptr, *d_arcE = nullptr, *d_arcN = nullptr;
+    unsigned long long *d_box = nullptr;
+    double box[4] = {0, 0, 0, 0};
+    double *d_thick = nullptr;
+    // velocity fields
+    const void *u = nullptr, *v = nullptr;
+    int uv_dtype = NF_F64, uv_on_device = 1;
+    double fill = std::numeric_limits<double>::quiet_NaN();
+    void *d_stage_u = nullptr, *d_stage_v = nullptr;
+    int sverdrup = 0;
+    long s_begin = 0, s_end = -1;
+    // resident per-step outputs
+    double *d_iV = nullptr;   // [4][ncell]
+    double *d_abs = nullptr;  // [2][ncell]
+    unsigned long long *d_maxbits = nullptr;
+    // transects
+    std::vector<std::vector<double>> polylines;
+    std::vector<int> poly_cc;
+    std::vector<int> tr_off;
+    WeightSet ws;
+    bool weights_built = false;
+    int *d_tr_off = nullptr;
+    double *d_scratch = nullptr, *d_row = nullptr;
+    Grid_t grid_view;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // pairs
+};
+
+static int field_free_geometry(nf_field *f)
+{
+    dev_free(f->d_xy);
+    dev_free(f->d_arc4);
+    dev_free(f->d_arcE);
+    dev_free(f->d_arcN);
+    dev_free(f->d_box);
+    dev_free(f->d_iV);
+    dev_free(f->d_abs);
+    dev_free(f->d_maxbits);
+    return NF_OK;
+}
+
+static int elem_size(int dtype) { return dtype == NF_F32 ? 4 : 8; }
+
+static int field_row_length(const nf_field *f) { return f->ws.nseg + (int)f->polylines.size(); }
+
+// one time step on the field's stream; row_dev receives [segments | transects]
+static int field_step_async(nf_field *f, long t, double *row_dev)
+{
+    NF_REQUIRE(f->d_arcE && f->d_thick && f->u && f->v, NF_ERR_STATE,
+               "compute: set_bounds, set_thickness and set_uv first");
+    NF_REQUIRE(t >= 0 && t < f->nt, NF_ERR_ARG, "compute: time index out of range");
+    const long s_end = f->s_end < 0 ? f->nt * f->nz : f->s_end;
+    long lo = t * f->nz, hi = (t + 1) * f->nz;
+    if (lo < f->s_begin) lo = f->s_begin;
+    if (hi > s_end) hi = s_end;
+    const int rowlen = field_row_length(f);
+    if (hi <= lo) {  // this rank owns no slab of step t: contributes zeros
+        if (row_dev && rowlen > 0) NF_HIP(hipMemsetAsync(row_dev, 0, sizeof(double) * rowlen, f->stream));
+        return NF_OK;
+    }
+    const int z0 = (int)(lo - t * f->nz), z1 = (int)(hi - t * f->nz);
+    const size_t es = elem_size(f->uv_dtype);
+    const size_t step_bytes = (size_t)f->nz * f->ncell * es;
+    const void *ut, *vt;
+    if (f->uv_on_device) {
+        ut = (const char *)f->u + (size_t)t * step_bytes;
+        vt = (const char *)f->v + (size_t)t * step_bytes;
+    } else {  // host-resident fields: stage the owned slabs of this step (PCIe-inclusive path)
+        if (!f->d_stage_u) {
+            NF_HIP(hipMalloc(&f->d_stage_u, step_bytes));
+            NF_HIP(hipMalloc(&f->d_stage_v, step_bytes));
+        }
+        const size_t off = (size_t)z0 * f->ncell * es, len = (size_t)(z1 - z0) * f->ncell * es;
+        NF_HIP(hipMemcpyAsync((char *)f->d_stage_u + off, (const char *)f->u + (size_t)t * step_bytes + off, len,
+                              hipMemcpyHostToDevice, f->stream));
+        NF_HIP(hipMemcpyAsync((char *)f->d_stage_v + off, (const char *)f->v + (size_t)t * step_bytes + off, len,
+                              hipMemcpyHostToDevice, f->stream));
+        ut = f->d_stage_u;
+        vt = f->d_stage_v;
+    }
+    FluxArgs a{};
+    a.u = ut;
+    a.v = vt;
+    a.dtype = f->uv_dtype;
+    a.ncell = f->ncell;
+    a.ny = f->ny;
+    a.nx = f->nx;
+    a.z0 = z0;
+    a.z1 = z1;
+    a.thickness = f->d_thick;
+    a.arcE = f->d_arcE;
+    a.arcN = f->d_arcN;
+    a.fill = f->fill;
+    a.scale = kEarthRadiusSv / 1.e6;  // field.py:226
+    a.sverdrup = f->sverdrup;
+    a.iV = f->d_iV;
+    a.absU = f->d_abs;
+    a.absV = f->d_abs + f->ncell;
+    a.maxbits = f->d_maxbits;
+    if (f->timing) {
+        hipEvent_t e0, e1;
+        NF_HIP(hipEventCreate(&e0));
+        NF_HIP(hipEventCreate(&e1));
+        NF_HIP(hipEventRecord(e0, f->stream));
+        NF_TRY(launch_flux(a, f->stream));
+        NF_HIP(hipEventRecord(e1, f->stream));
+        f->ev.push_back(e0);
+        f->ev.push_back(e1);
+    } else {
+        NF_TRY(launch_flux(a, f->stream));
+    }
+    if (row_dev && rowlen > 0) {
+        NF_REQUIRE(f->weights_built, NF_ERR_STATE, "compute: build_weights first");
+        NF_TRY(launch_integral(f->ws, f->d_iV, f->ncell, 1, f->d_tr_off, (int)f->polylines.size(), f->d_scratch,
+                               row_dev, f->stream));
+    }
+    return NF_OK;
+}
+
+extern "C" {
+
+int nf_field_new(nf_field **self)
+{
+    *self = new nf_field();
+    (*self)->grid_view.owns_xy = false;
+    return NF_OK;
+}
+int nf_field_del(nf_field **self)
+{
+    if (self && *self) {
+        nf_field *f = *self;
+        field_free_geometry(f);
+        dev_free(f->d_thick);
+        if (f->d_stage_u) (void)hipFree(f->d_stage_u);
+        if (f->d_stage_v) (void)hipFree(f->d_stage_v);
+        f->ws.release();
+        dev_free(f->d_tr_off);
+        dev_free(f->d_scratch);
+        dev_free(f->d_row);
+        for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
+        delete f;
+        *self = nullptr;
+    }
+    return NF_OK;
+}
+int nf_field_set_stream(nf_field **self, void *hip_stream)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_stream: null field");
+    (*self)->stream = (hipStream_t)hip_stream;
+    return NF_OK;
+}
+
+int nf_field_set_bounds(nf_field **self, const void *bounds_lon, const void *bounds_lat, long ny, long nx,
+                        int dtype, int on_device)
+{
+    NF_REQUIRE(self && *self && bounds_lon && bounds_lat, NF_ERR_ARG, "nf_field_set_bounds: null argument");
+    NF_REQUIRE(ny > 0 && nx > 0 && ny * nx < (1l << 31), NF_ERR_ARG, "nf_field_set_bounds: bad (ny, nx)");
+    NF_REQUIRE(dtype == NF_F64 || dtype == NF_F32, NF_ERR_ARG, "nf_field_set_bounds: dtype must be NF_F64/NF_F32");
+    NF_NEED_DEVICE();
+    nf_field *f = *self;
+    field_free_geometry(f);
+    f->ny = ny;
+    f->nx = nx;
+    f->ncell = ny * nx;
+    const size_t n = (size_t)f->ncell;
+    NF_TRY(dev_alloc(&f->d_xy, n * 8));
+    NF_TRY(dev_alloc(&f->d_arc4, n * 4));
+    NF_TRY(dev_alloc(&f->d_arcE, n));
+    NF_TRY(dev_alloc(&f->d_arcN, n));
+    NF_TRY(dev_alloc(&f->d_box, 4));
+    NF_TRY(dev_alloc(&f->d_iV, n * 4));
+    NF_TRY(dev_alloc(&f->d_abs, n * 2));
+    NF_TRY(dev_alloc(&f->d_maxbits, 1));
+    // field.py:59-63: the per-step arrays start as zeros (row 0's south slot stays zero for ever)
+    NF_HIP(hipMemsetAsync(f->d_iV, 0, sizeof(double) * n * 4, f->stream));
+    NF_HIP(hipMemsetAsync(f->d_abs, 0, sizeof(double) * n * 2, f->stream));
+    NF_HIP(hipMemsetAsync(f->d_maxbits, 0, sizeof(unsigned long long), f->stream));
+    const size_t bytes = n * 4 * elem_size(dtype);
+    void *d_lon = nullptr, *d_lat = nullptr;
+    const void *plon = bounds_lon, *plat = bounds_lat;
+    if (!on_device) {
+        NF_HIP(hipMalloc(&d_lon, bytes));
+        NF_HIP(hipMalloc(&d_lat, bytes));
+        NF_HIP(hipMemcpyAsync(d_lon, bounds_lon, bytes, hipMemcpyHostToDevice, f->stream));
+        NF_HIP(hipMemcpyAsync(d_lat, bounds_lat, bytes, hipMemcpyHostToDevice, f->stream));
+        plon = d_lon;
+        plat = d_lat;
+    }
+    int rc = launch_geometry(plon, plat, dtype, f->ncell, f->d_xy, f->d_arc4, f->d_arcE, f->d_arcN, f->d_box, f->stream);
+    unsigned long long keys[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpyAsync(keys, f->d_box, sizeof keys, hipMemcpyDeviceToHost, f->stream);
+    hipError_t e2 = hipStreamSynchronize(f->stream);
+    if (d_lon) (void)hipFree(d_lon);
+    if (d_lat) (void)hipFree(d_lat);
+    NF_TRY(rc);
+    NF_HIP(e);
+    NF_HIP(e2);
+    for (int k = 0; k < 4; ++k) f->box[k] = box_key_to_double(keys[k]);
+    f->grid_view.ncell = f->ncell;
+    f->grid_view.d_xy = f->d_xy;
+    f->grid_view.owns_xy = false;
+    f->weights_built = false;
+    return NF_OK;
+}
+
+int nf_field_set_thickness(nf_field **self, const double *thickness, long nz)
+{
+    NF_REQUIRE(self && *self && thickness, NF_ERR_ARG, "nf_field_set_thickness: null argument");
+    NF_REQUIRE(nz > 0 && nz < (1l << 30), NF_ERR_ARG, "nf_field_set_thickness: bad nz");
+    NF_NEED_DEVICE();
+    nf_field *f = *self;
+    dev_free(f->d_thick);
+    NF_TRY(dev_alloc(&f->d_thick, (size_t)nz));
+    NF_HIP(hipMemcpy(f->d_thick, thickness, sizeof(double) * nz, hipMemcpyHostToDevice));
+    f->nz = nz;
+    return NF_OK;
+}
+
+int nf_field_set_uv(nf_field **self, const void *u, const void *v, long nt, int dtype, int on_device,
+                    double fill_value)
+{
+    NF_REQUIRE(self && *self && u && v, NF_ERR_ARG, "nf_field_set_uv: null argument");
+    NF_REQUIRE(nt > 0, NF_ERR_ARG, "nf_field_set_uv: nt must be positive");
+    NF_REQUIRE(dtype == NF_F64 || dtype == NF_F32, NF_ERR_ARG, "nf_field_set_uv: dtype must be NF_F64/NF_F32");
+    nf_field *f = *self;
+    f->u = u;
+    f->v = v;
+    f->nt = nt;
+    f->uv_dtype = dtype;
+    f->uv_on_device = on_device;
+    f->fill = fill_value;
+    if (f->d_stage_u) (void)hipFree(f->d_stage_u);
+    if (f->d_stage_v) (void)hipFree(f->d_stage_v);
+    f->d_stage_u = f->d_stage_v = nullptr;
+    return NF_OK;
+}
+
+int nf_field_set_sverdrup(nf_field **self, int sverdrup)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_sverdrup: null field");
+    (*self)->sverdrup = sverdrup ? 1 : 0;
+    return NF_OK;
+}
+
+int nf_field_set_slab_range(nf_field **self, long s_begin, long s_end)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_slab_range: null field");
+    NF_REQUIRE(s_begin >= 0 && s_end >= s_begin, NF_ERR_ARG, "nf_field_set_slab_range: need 0 <= begin <= end");
+    (*self)->s_begin = s_begin;
+    (*self)->s_end = s_end;
+    return NF_OK;
+}
+
+int nf_field_add_transect(nf_field **self, const double *xyz, int npts, int counterclock, int *transect_id)
+{
+    NF_REQUIRE(self && *self && xyz, NF_ERR_ARG, "nf_field_add_transect: null argument");
+    NF_REQUIRE(npts >= 2, NF_ERR_ARG, "nf_field_add_transect: need at least 2 points");
+    nf_field *f = *self;
+    f->polylines.emplace_back(xyz, xyz + 3 * (size_t)npts);
+    f->poly_cc.push_back(counterclock ? 1 : 0);
+    f->weights_built = false;
+    if (transect_id) *transect_id = (int)f->polylines.size() - 1;
+    return NF_OK;
+}
+
+int nf_field_build_weights(nf_field **self, int numCellsPerBucket, double periodX)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_build_weights: null field");
+    nf_field *f = *self;
+    NF_REQUIRE(f->d_xy, NF_ERR_STATE, "nf_field_build_weights: set_bounds first");
+    NF_REQUIRE(numCellsPerBucket > 0 && periodX >= 0.0, NF_ERR_ARG, "nf_field_build_weights: bad locator arguments");
+    NF_NEED_DEVICE();
+    std::vector<double> segs;
+    std::vector<int> cc;
+    f->tr_off.assign(1, 0);
+    for (size_t p = 0; p < f->polylines.size(); ++p) {
+        polyline_segments(f->polylines[p].data(), (int)(f->polylines[p].size() / 3), f->poly_cc[p], segs, cc);
+        f->tr_off.push_back((int)cc.size());
+    }
+    NF_TRY(build_weights(f->d_xy, f->ncell, segs.data(), cc.data(), (int)cc.size(), periodX, &f->ws, f->stream));
+    dev_free(f->d_tr_off);
+    dev_free(f->d_scratch);
+    dev_free(f->d_row);
+    NF_TRY(dev_alloc(&f->d_tr_off, f->tr_off.size()));
+    NF_TRY(dev_alloc(&f->d_scratch, (size_t)f->ws.n));
+    NF_TRY(dev_alloc(&f->d_row, (size_t)field_row_length(f)));
+    NF_HIP(hipMemcpy(f->d_tr_off, f->tr_off.data(), sizeof(int) * f->tr_off.size(), hipMemcpyHostToDevice));
+    f->weights_built = true;
+    return NF_OK;
+}
+
+int nf_field_num_transects(nf_field **self, int *n)
+{
+    NF_REQUIRE(self && *self && n, NF_ERR_ARG, "nf_field_num_transects: null argument");
+    *n = (int)(*self)->polylines.size();
+    return NF_OK;
+}
+int nf_field_num_segments(nf_field **self, int *nseg_total)
+{
+    NF_REQUIRE(self && *self && nseg_total, NF_ERR_ARG, "nf_field_num_segments: null argument");
+    NF_REQUIRE((*self)->weights_built, NF_ERR_STATE, "nf_field_num_segments: build_weights first");
+    *nseg_total = (*self)->ws.nseg;
+    return NF_OK;
+}
+int nf_field_segment_offsets(nf_field **self, int *offsets)
+{
+    NF_REQUIRE(self && *self && offsets, NF_ERR_ARG, "nf_field_segment_offsets: null argument");
+    NF_REQUIRE((*self)->weights_built, NF_ERR_STATE, "nf_field_segment_offsets: build_weights first");
+    memcpy(offsets, (*self)->tr_off.data(), sizeof(int) * (*self)->tr_off.size());
+    return NF_OK;
+}
+int nf_field_num_weights(nf_field **self, size_t *n)
+{
+    NF_REQUIRE(self && *self && n, NF_ERR_ARG, "nf_field_num_weights: null argument");
+    *n = (size_t)(*self)->ws.n;
+    return NF_OK;
+}
+int nf_field_get_weights(nf_field **self, int64_t *cell_edge, double *weight, int *seg_global)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_get_weights: null field");
+    const WeightSet &w = (*self)->ws;
+    if (w.n == 0) return NF_OK;
+    NF_NEED_DEVICE();
+    if (cell_edge) NF_HIP(hipMemcpy(cell_edge, w.cell_edge, sizeof(int64_t) * w.n, hipMemcpyDeviceToHost));
+    if (weight) NF_HIP(hipMemcpy(weight, w.weight, sizeof(double) * w.n, hipMemcpyDeviceToHost));
+    if (seg_global) NF_HIP(hipMemcpy(seg_global, w.seg, sizeof(int) * w.n, hipMemcpyDeviceToHost));
+    return NF_OK;
+}
+int nf_field_row_length(nf_field **self, int *n)
+{
+    NF_REQUIRE(self && *self && n, NF_ERR_ARG, "nf_field_row_length: null argument");
+    *n = field_row_length(*self);
+    return NF_OK;
+}
+
+int nf_field_compute_flux(nf_field **self, long tIndex, double *row_host)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_compute_flux: null field");
+    NF_NEED_DEVICE();
+    nf_field *f = *self;
+    const int rowlen = field_row_length(f);
+    NF_TRY(field_step_async(f, tIndex, (f->weights_built && rowlen > 0) ? f->d_row : nullptr));
+    if (row_host && rowlen > 0 && f->weights_built)
+        NF_HIP(hipMemcpyAsync(row_host, f->d_row, sizeof(double) * rowlen, hipMemcpyDeviceToHost, f->stream));
+    NF_HIP(hipStreamSynchronize(f->stream));
+    return NF_OK;
+}
+
+int nf_field_compute_all_async(nf_field **self, double *rows_dev)
+{
+    NF_REQUIRE(self && *self && rows_dev, NF_ERR_ARG, "nf_field_compute_all_async: null argument");
+    NF_NEED_DEVICE();
+    nf_field *f = *self;
+    NF_REQUIRE(f->weights_built, NF_ERR_STATE, "nf_field_compute_all_async: build_weights first");
+    const int rowlen = field_row_length(f);
+    for (long t = 0; t < f->nt; ++t) NF_TRY(field_step_async(f, t, rows_dev + (size_t)t * rowlen));
+    return NF_OK;
+}
+
+int nf_field_read_step(nf_field **self, double *iV_host, double *eU_host, double *eV_host, double *max_abs)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_read_step: null field");
+    nf_field *f = *self;
+    NF_REQUIRE(f->d_iV, NF_ERR_STATE, "nf_field_read_step: set_bounds first");
+    NF_NEED_DEVICE();
+    const size_t n = (size_t)f->ncell;
+    if (iV_host) {
+        double *d_aos = nullptr;
+        NF_TRY(dev_alloc(&d_aos, n * 4));
+        int rc = launch_planes_to_aos(f->d_iV, f->ncell, d_aos, f->stream);
+        hipError_t e = hipMemcpyAsync(iV_host, d_aos, sizeof(double) * n * 4, hipMemcpyDeviceToHost, f->stream);
+        hipError_t e2 = hipStreamSynchronize(f->stream);
+        dev_free(d_aos);
+        NF_TRY(rc);
+        NF_HIP(e);
+        NF_HIP(e2);
+    }
+    if (eU_host) NF_HIP(hipMemcpyAsync(eU_host, f->d_abs, sizeof(double) * n, hipMemcpyDeviceToHost, f->stream));
+    if (eV_host) NF_HIP(hipMemcpyAsync(eV_host, f->d_abs + n, sizeof(double) * n, hipMemcpyDeviceToHost, f->stream));
+    if (max_abs) {
+        unsigned long long b = 0;
+        NF_HIP(hipMemcpyAsync(&b, f->d_maxbits, sizeof b, hipMemcpyDeviceToHost, f->stream));
+        NF_HIP(hipStreamSynchronize(f->stream));
+        memcpy(max_abs, &b, 8);
+    }
+    NF_HIP(hipStreamSynchronize(f->stream));
+    return NF_OK;
+}
+
+int nf_field_reset_max(nf_field **self)
+{
+    NF_REQUIRE(self && *self && (*self)->d_maxbits, NF_ERR_STATE, "nf_field_reset_max: set_bounds first");
+    NF_HIP(hipMemsetAsync((*self)->d_maxbits, 0, sizeof(unsigned long long), (*self)->stream));
+    return NF_OK;
+}
+
+int nf_field_get_arclengths(nf_field **self, double *arc_host)
+{
+    NF_REQUIRE(self && *self && arc_host, NF_ERR_ARG, "nf_field_get_arclengths: null argument");
+    NF_REQUIRE((*self)->d_arc4, NF_ERR_STATE, "nf_field_get_arclengths: set_bounds first");
+    NF_HIP(hipMemcpy(arc_host, (*self)->d_arc4, sizeof(double) * 4 * (size_t)(*self)->ncell, hipMemcpyDeviceToHost));
+    return NF_OK;
+}
+
+int nf_field_get_points(nf_field **self, double *points_host)
+{
+    NF_REQUIRE(self && *self && points_host, NF_ERR_ARG, "nf_field_get_points: null argument");
+    nf_field *f = *self;
+    NF_REQUIRE(f->d_xy, NF_ERR_STATE, "nf_field_get_points: set_bounds first");
+    double *d_points = nullptr;
+    NF_TRY(dev_alloc(&d_points, (size_t)f->ncell * 12));
+    int rc = launch_points_from_corner_table(f->d_xy, f->ncell, d_points, f->stream);
+    hipError_t e = hipMemcpyAsync(points_host, d_points, sizeof(double) * 12 * (size_t)f->ncell,
+                                  hipMemcpyDeviceToHost, f->stream);
+    hipError_t e2 = hipStreamSynchronize(f->stream);
+    dev_free(d_points);
+    NF_TRY(rc);
+    NF_HIP(e);
+    NF_HIP(e2);
+    return NF_OK;
+}
+
+int nf_field_get_box(nf_field **self, double *lonmin, double *lonmax, double *latmin, double *latmax)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_get_box: null field");
+    NF_REQUIRE((*self)->d_xy, NF_ERR_STATE, "nf_field_get_box: set_bounds first");
+    *lonmin = (*self)->box[0];
+    *lonmax = (*self)->box[1];
+    *latmin = (*self)->box[2];
+    *latmax = (*self)->box[3];
+    return NF_OK;
+}
+
+int nf_field_device_ptr(nf_field **self, int which, void **dev)
+{
+    NF_REQUIRE(self && *self && dev, NF_ERR_ARG, "nf_field_device_ptr: null argument");
+    nf_field *f = *self;
+    switch (which) {
+        case 0: *dev = f->d_iV; break;
+        case 1: *dev = f->d_abs; break;
+        case 2: *dev = f->d_abs ? f->d_abs + f->ncell : nullptr; break;
+        case 3: *dev = f->d_arc4; break;
+        case 4: *dev = f->d_xy; break;
+        default: NF_REQUIRE(false, NF_ERR_ARG, "nf_field_device_ptr: unknown array id");
+    }
+    return NF_OK;
+}
+
+int nf_field_grid(nf_field **self, Grid_t **grid)
+{
+    NF_REQUIRE(self && *self && grid, NF_ERR_ARG, "nf_field_grid: null argument");
+    NF_REQUIRE((*self)->d_xy, NF_ERR_STATE, "nf_field_grid: set_bounds first");
+    *grid = &(*self)->grid_view;
+    return NF_OK;
+}
+
+int nf_field_timing(nf_field **self, int enable)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_timing: null field");
+    nf_field *f = *self;
+    for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
+    f->ev.clear();
+    f->timing = enable != 0;
+    return NF_OK;
+}
+int nf_field_timing_read(nf_field **self, long *launches, double *total_ms)
+{
+    NF_REQUIRE(self && *self && launches && total_ms, NF_ERR_ARG, "nf_field_timing_read: null argument");
+    nf_field *f = *self;
+    NF_HIP(hipStreamSynchronize(f->stream));
+    double tot = 0.0;
+    for (size_t k = 0; k + 1 < f->ev.size(); k += 2) {
+        float ms = 0.f;
+        NF_HIP(hipEventElapsedTime(&ms, f->ev[k], f->ev[k + 1]));
+        tot += ms;
+    }
+    *launches = (long)(f->ev.size() / 2);
+    *total_ms = tot;
+    for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
+    f->ev.clear();
+    return NF_OK;
+}
+
+// ------------------------------------------------------------------------------------------- datagen
+int nf_datagen_bounds(double *bounds_lon_dev, double *bounds_lat_dev, long ny, long nx, double xmin, double xmax,
+                      double ymin, double ymax, double delta_lon_deg, double delta_lat_deg, int lat_uses_dx,
+                      void *hip_stream)
+{
+    NF_REQUIRE(bounds_lon_dev && bounds_lat_dev, NF_ERR_ARG, "nf_datagen_bounds: null argument");
+    NF_NEED_DEVICE();
+    NF_TRY(launch_datagen_bounds(bounds_lon_dev, bounds_lat_dev, ny, nx, xmin, xmax, ymin, ymax, delta_lon_deg,
+                                 delta_lat_deg, lat_uses_dx, (hipStream_t)hip_stream));
+    NF_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+    return NF_OK;
+}
+int nf_datagen_uv(void *u_dev, void *v_dev, int dtype, long t_begin, long t_end, long nt, long nz, long ny, long nx,
+                  double xmin, double xmax, double ymin, double ymax, double zmin, double zmax, int lat_uses_dx,
+                  int psi, void *hip_stream)
+{
+    NF_REQUIRE(u_dev && v_dev, NF_ERR_ARG, "nf_datagen_uv: null argument");
+    NF_REQUIRE(dtype == NF_F64 || dtype == NF_F32, NF_ERR_ARG, "nf_datagen_uv: dtype must be NF_F64/NF_F32");
+    NF_NEED_DEVICE();
+    return launch_datagen_uv(u_dev, v_dev, dtype, t_begin, t_end, nt, nz, ny, nx, xmin, xmax, ymin, ymax, zmin, zmax,
+                             lat_uses_dx, psi, (hipStream_t)hip_stream);
+}
+
+}  // extern "C"

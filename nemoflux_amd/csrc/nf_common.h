@@ -1,0 +1,98 @@
+// nf_common.h -- shared declarations of the gfx950 transect-flux engine (internal; the public surface is
+// include/nemoflux_amd.h).  Written for CDNA4 only: 64-lane wavefronts, 256 CUs in 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/nemoflux_amd.h"
+
+namespace nf {
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kBlock = 256;      // 4 waves per workgroup
+constexpr int kXcds = 8;         // MI355X: 8 XCDs, workgroups are dealt round-robin over them
+constexpr double kDeg2Rad = 3.14159265358979323846 / 180.0;  // geo.py:4
+constexpr double kEarthRadiusSv = 6371000.0;                 // field.py:12
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define NF_HIP(call)                                                   \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) return nf::hip_fail(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define NF_REQUIRE(cond, code, msg)            \
+    do {                                       \
+        if (!(cond)) {                         \
+            nf::set_error(msg);                \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+// ---- XCD-aware tile mapping -------------------------------------------------------------------------
+// Workgroup b lands on XCD b % 8.  Give every XCD one CONTIGUOUS band of logical tiles so that (a) the
+// neighbour-slot stores of the edge-flux kernel (row j -> row j+1, column i -> i+1) meet the owning row's
+// stores in the SAME L2 and leave it as whole lines, and (b) each L2 streams one band of every slab.
+// Grid must be launched with xcd_grid(ntiles) workgroups; tiles >= ntiles exit.
+__host__ __device__ inline unsigned xcd_grid(unsigned ntiles) { return ((ntiles + kXcds - 1) / kXcds) * kXcds; }
+__device__ inline unsigned xcd_tile(unsigned b, unsigned grid) { return (b % kXcds) * (grid / kXcds) + b / kXcds; }
+
+// ---- launchers (defined in the .hip files) ----------------------------------------------------------
+// K0: geometry.  bounds (ncell,4) of T -> corner table xy (ncell,4,2), arc (ncell,4), arcE/arcN (ncell),
+// lon/lat box (4 doubles: lonmin, lonmax, latmin, latmax as order-preserving keys; see nf_geom.hip).
+int launch_geometry(const void *blon, const void *blat, int dtype, long ncell, double *xy, double *arc4,
+                    double *arcE, double *arcN, unsigned long long *box_keys, hipStream_t s);
+int launch_corner_table_from_points(const double *points, long ncell, double *xy, hipStream_t s);
+int launch_points_from_corner_table(const double *xy, long ncell, double *points, hipStream_t s);
+double box_key_to_double(unsigned long long k);
+
+// K1: vertical integral of one time step's slabs [z0,z1) + edge fluxes (the bandwidth-bound kernel).
+struct FluxArgs {
+    const void *u, *v;        // base of the time step: (nz, ncell)
+    int dtype;                // NF_F64 / NF_F32
+    long ncell, ny, nx;
+    int z0, z1;
+    const double *thickness;  // device, nz
+    const double *arcE, *arcN;
+    double fill;              // NaN = none
+    double scale;             // 1 or 6371000/1e6
+    int sverdrup;
+    double *iV, *absU, *absV; // resident outputs
+    unsigned long long *maxbits;  // running max as the bits of a non-negative double
+};
+int launch_flux(const FluxArgs &a, hipStream_t s);
+int launch_planes_to_aos(const double *planes, long ncell, double *aos, hipStream_t s);
+
+// K2: batched polyline weights.
+struct WeightSet {  // device-resident result, sorted by global target segment
+    long n = 0;     // entries (4 per crossed cell)
+    int64_t *cell_edge = nullptr;
+    double *weight = nullptr;
+    int *seg = nullptr;        // global segment id of every entry
+    int nseg = 0;              // total target segments
+    int *seg_start = nullptr;  // (nseg+1) CSR over entries
+    void release();
+};
+// segs_host: (nseg,4) = x0,y0,dx,dy ; seg_cc_host: counterclock flag per segment
+int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
+                  double periodX, WeightSet *out, hipStream_t s);
+
+// K3: gather + wavefront segmented reduction -> per-segment sums, then per-transect sums.
+// row: (nseg + ntransect) doubles in HBM; tr_offsets_dev: (ntransect+1) segment offsets.
+// scratch: at least ws.n doubles.
+// data: (ncell,4) AoS (planes = 0) or the resident [4][ncell] planes (planes = 1).
+int launch_integral(const WeightSet &ws, const double *data, long ncell, int planes, const int *tr_offsets_dev,
+                    int ntransect, double *scratch, double *row, hipStream_t s);
+
+// datagen
+int launch_datagen_bounds(double *blon, double *blat, long ny, long nx, double xmin, double xmax, double ymin,
+                          double ymax, double dlon, double dlat, int lat_uses_dx, hipStream_t s);
+int launch_datagen_uv(void *u, void *v, int dtype, long t0, long t1, long nt, long nz, long ny, long nx,
+                      double xmin, double xmax, double ymin, double ymax, double zmin, double zmax,
+                      int lat_uses_dx, int psi, hipStream_t s);
+
+}  // namespace nf

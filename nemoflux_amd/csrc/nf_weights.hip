@@ -1,0 +1,388 @@
+// nf_weights.hip -- K2: target-line / cell-edge intersection weights for a BATCH of polylines on gfx950.
+//
+// Replaces  mint.PolylineIntegral.buildLocator + computeWeights as nemoflux drives them
+//           (nemoflux/field.py:45-48: numCellsPerBucket=128, periodX=360., enableFolding=False,
+//            counterclock=False) -- python-mint >= 1.24.4, third-party, not vendored (README.md:12).
+//
+// Algorithm: in the planar (lon,lat) plane, every target segment q + t d, t in [0,1]
+// (tried at x-shifts -periodX, 0, +periodX) is clipped against every convex quad cell (Cyrus-Beck); the
+// two ends of the sub-segment [ta,tb] are mapped to the cell's bilinear parameters xi (Newton), giving the
+// four edge weights
+//      w_S = dxi0 (1 - xim1)   w_E = dxi1 xim0   w_N = dxi0 xim1   w_W = dxi1 (1 - xim0)
+// (all edges oriented in +xi: counterclock = False), times 1/n when the same [ta,tb] is found in n cells
+// (a sub-segment running along a shared edge is counted once).
+//
+// Mapping to the hardware.  One wavefront owns 64 consecutive cells.  Their corner table rows (64 x 64 B =
+// 4 KiB contiguous) are read coalesced and staged in LDS, then each lane keeps its own 4 corners in
+// registers for the whole kernel.  The segment list is wave-uniform (scalar loads); a wave-level bounding
+// box test (the "locator": numCellsPerBucket -> one 64-cell wave tile) rejects almost every (tile, segment)
+// pair with a uniform branch.  Hits are compacted with ballot/popcount into a deterministic order
+// (tile, segment, shift, lane): pass 1 counts per wave, a single-workgroup scan turns counts into offsets,
+// pass 2 recomputes and writes records.  Records are then stably radix-sorted by global segment id
+// (rocPRIM), the multiplicity is resolved per record against the records of the same segment, and each
+// record expands into 4 (cell*4+edge, weight, segment) entries -- already in the order K3's wavefront
+// segmented reduction wants.  No atomics, so the result is bitwise reproducible run to run.
+#include <cstring>  // rocprim's texture iterator needs host memset declared first
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "nf_common.h"
+
+namespace nf {
+
+// tolerances: same values as the oracle (oracle/nf_oracle.c) -- they are part of the algorithm's definition
+constexpr double kEpsPar = 1.e-12;
+constexpr double kTolDistRel = 1.e-12;
+constexpr double kTolT = 1.e-10;
+constexpr int kNewtonMax = 16;
+
+__device__ inline double dmax2(double a, double b) { return a > b ? a : b; }
+
+__device__ inline bool clip_cell(const double *v, double qx, double qy, double dx, double dy, double &ta,
+                                 double &tb)
+{
+    double area2 = ((v[2] - v[0]) * (v[5] - v[1]) - (v[4] - v[0]) * (v[3] - v[1])) +
+                   ((v[4] - v[0]) * (v[7] - v[1]) - (v[6] - v[0]) * (v[5] - v[1]));
+    if (!(area2 != 0.0)) return false;
+    const double sgn = area2 > 0.0 ? 1.0 : -1.0;
+    double M = dmax2(dmax2(fabs(qx), fabs(qy)), dmax2(fabs(qx + dx), fabs(qy + dy)));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) M = dmax2(M, fabs(v[k]));
+    const double told = kTolDistRel * M;
+    const double dd = dx * dx + dy * dy;
+    double t0 = 0.0, t1 = 1.0;
+    bool outside = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int e1 = (e + 1) & 3;
+        const double ax = v[2 * e], ay = v[2 * e + 1];
+        const double gx = v[2 * e1] - ax, gy = v[2 * e1 + 1] - ay;
+        const double gg = gx * gx + gy * gy;
+        if (gg <= told * told) continue;  // collapsed edge (pole): no constraint
+        const double nx = -gy * sgn, ny = gx * sgn;  // inward normal
+        const double num = nx * (qx - ax) + ny * (qy - ay);
+        const double den = nx * dx + ny * dy;
+        if (den * den <= (kEpsPar * kEpsPar) * gg * dd) {
+            if (num < 0.0 && num * num > told * told * gg) outside = true;  // parallel and outside
+        } else {
+            const double t = -num / den;
+            if (den > 0.0) {
+                if (t > t0) t0 = t;
+            } else {
+                if (t < t1) t1 = t;
+            }
+        }
+    }
+    if (outside) return false;
+    if (!(t1 - t0 > kTolT)) return false;
+    ta = t0;
+    tb = t1;
+    return true;
+}
+
+__device__ inline void inv_bilinear(const double *v, double px, double py, double &xi0, double &xi1)
+{
+    const double ax = v[0], ay = v[1];
+    const double e1x = v[2] - v[0], e1y = v[3] - v[1];
+    const double e3x = v[6] - v[0], e3y = v[7] - v[1];
+    const double hx = (v[0] - v[2]) + (v[4] - v[6]), hy = (v[1] - v[3]) + (v[5] - v[7]);
+    double s = 0.5, t = 0.5;
+    for (int it = 0; it < kNewtonMax; ++it) {
+        const double fx = ((ax + s * e1x) + t * e3x) + (s * t) * hx - px;
+        const double fy = ((ay + s * e1y) + t * e3y) + (s * t) * hy - py;
+        const double j00 = e1x + t * hx, j01 = e3x + s * hx;
+        const double j10 = e1y + t * hy, j11 = e3y + s * hy;
+        const double det = j00 * j11 - j01 * j10;
+        if (!(det != 0.0)) break;
+        const double ds = (fx * j11 - fy * j01) / det;
+        const double dt = (fy * j00 - fx * j10) / det;
+        s -= ds;
+        t -= dt;
+        if (fabs(ds) + fabs(dt) < 1.e-15) break;
+    }
+    xi0 = s;
+    xi1 = t;
+}
+
+__device__ inline double wmin(double x)
+{
+    for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o, kWave));
+    return x;
+}
+__device__ inline double wmax(double x)
+{
+    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, kWave));
+    return x;
+}
+
+struct Records {  // SoA, device
+    int *seg, *cell;
+    double *ta, *tb, *w;  // w: 4 per record
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, long ncell,
+                                                 const double *__restrict__ segs,
+                                                 const int *__restrict__ seg_cc, int nseg, int nshift,
+                                                 double periodX, const int *__restrict__ wave_off,
+                                                 int *__restrict__ wave_cnt, Records rec)
+{
+    __shared__ double s_xy[kBlock * 8];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const long c0 = (long)blockIdx.x * kBlock;
+    const long nval = ncell * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {  // coalesced stage of 256 cells x 4 corners x (lon,lat)
+        long g = c0 * 8 + tid + r * kBlock;
+        if (g < nval) s_xy[tid + r * kBlock] = xy[g];
+    }
+    __syncthreads();
+    const long c = c0 + tid;
+    const bool valid = c < ncell;
+    double v[8];
+    double cxmin = 1e300, cxmax = -1e300, cymin = 1e300, cymax = -1e300;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = valid ? s_xy[tid * 8 + k] : 0.0;
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cxmin = fmin(cxmin, v[2 * i]);
+            cxmax = fmax(cxmax, v[2 * i]);
+            cymin = fmin(cymin, v[2 * i + 1]);
+            cymax = fmax(cymax, v[2 * i + 1]);
+        }
+    }
+    const double slack = valid ? 1.e-9 * (fabs(cxmin) + fabs(cxmax) + fabs(cymin) + fabs(cymax) + 1.0) : 0.0;
+    // wave tile bounding box (the locator bucket)
+    const double wslack = wmax(slack);
+    const double wxmin = wmin(cxmin) - wslack, wxmax = wmax(cxmax) + wslack;
+    const double wymin = wmin(cymin) - wslack, wymax = wmax(cymax) + wslack;
+    const long wave_id = (c0 + tid) / kWave;
+    int count = 0;
+    const int base = (FILL && wave_id * kWave < ncell) ? wave_off[wave_id] : 0;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int s = 0; s < nseg; ++s) {
+        const double p0x = segs[4 * s], p0y = segs[4 * s + 1];
+        const double dx = segs[4 * s + 2], dy = segs[4 * s + 3];
+        if (dx == 0.0 && dy == 0.0) continue;
+        for (int k = 0; k < nshift; ++k) {
+            const int shift = nshift == 3 ? k - 1 : 0;
+            const double qx = p0x + shift * periodX, qy = p0y;
+            const double sxmin = qx < qx + dx ? qx : qx + dx, sxmax = qx < qx + dx ? qx + dx : qx;
+            const double symin = qy < qy + dy ? qy : qy + dy, symax = qy < qy + dy ? qy + dy : qy;
+            if (wxmin > sxmax || wxmax < sxmin || wymin > symax || wymax < symin) continue;  // wave-uniform
+            bool hit = valid && !(cxmin > sxmax + slack || cxmax < sxmin - slack || cymin > symax + slack ||
+                                  cymax < symin - slack);
+            double ta = 0.0, tb = 0.0;
+            if (hit) hit = clip_cell(v, qx, qy, dx, dy, ta, tb);
+            const unsigned long long mask = __ballot(hit);
+            if (mask == 0ull) continue;
+            if (FILL && hit) {
+                const long pos = (long)base + count + __popcll(mask & lt_mask);
+                double a0, a1, b0, b1;
+                inv_bilinear(v, qx + ta * dx, qy + ta * dy, a0, a1);
+                inv_bilinear(v, qx + tb * dx, qy + tb * dy, b0, b1);
+                const double d0 = b0 - a0, d1 = b1 - a1;
+                const double m0 = 0.5 * (a0 + b0), m1 = 0.5 * (a1 + b1);
+                double w0 = d0 * (1.0 - m1), w1 = d1 * m0, w2 = d0 * m1, w3 = d1 * (1.0 - m0);
+                if (seg_cc[s]) {
+                    w2 = -w2;
+                    w3 = -w3;
+                }
+                rec.seg[pos] = s;
+                rec.cell[pos] = (int)c;
+                rec.ta[pos] = ta;
+                rec.tb[pos] = tb;
+                double2 *pw = reinterpret_cast<double2 *>(rec.w + 4 * pos);
+                pw[0] = make_double2(w0, w1);
+                pw[1] = make_double2(w2, w3);
+            }
+            count += __popcll(mask);
+        }
+    }
+    if (!FILL && lane == 0 && wave_id * kWave < ncell) wave_cnt[wave_id] = count;
+}
+
+// exclusive scan of n ints by ONE workgroup (n ~ ncell/64: 1e5 for ORCA12); total -> out[n]
+__global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ in, long n, int *__restrict__ out)
+{
+    __shared__ long s_sum[1024];
+    const int tid = threadIdx.x;
+    const long chunk = (n + 1023) / 1024;
+    const long lo = tid * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    long acc = 0;
+    for (long k = lo; k < hi; ++k) acc += in[k];
+    s_sum[tid] = acc;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive
+        long t = (tid >= o) ? s_sum[tid - o] : 0;
+        __syncthreads();
+        s_sum[tid] += t;
+        __syncthreads();
+    }
+    long run = s_sum[tid] - acc;
+    for (long k = lo; k < hi; ++k) {
+        out[k] = (int)run;
+        run += in[k];
+    }
+    if (tid == 1023) out[n] = (int)s_sum[1023];
+}
+
+__global__ __launch_bounds__(kBlock) void k_iota(unsigned *p, long n)
+{
+    long k = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (k < n) p[k] = (unsigned)k;
+}
+
+// lower bound of every segment id in the sorted key list -> CSR over records
+__global__ __launch_bounds__(kBlock) void k_seg_bounds(const unsigned *__restrict__ keys, long nrec, int nseg,
+                                                       int *__restrict__ rec_start)
+{
+    int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s > nseg) return;
+    long lo = 0, hi = nrec;
+    while (lo < hi) {
+        long mid = (lo + hi) >> 1;
+        if (keys[mid] < (unsigned)s) lo = mid + 1;
+        else hi = mid;
+    }
+    rec_start[s] = (int)lo;
+}
+
+// multiplicity + expansion into 4 entries per record
+__global__ __launch_bounds__(kBlock) void k_expand(const unsigned *__restrict__ keys,
+                                                   const unsigned *__restrict__ perm, long nrec, Records rec,
+                                                   const int *__restrict__ rec_start,
+                                                   int64_t *__restrict__ cell_edge, double *__restrict__ weight,
+                                                   int *__restrict__ seg_out)
+{
+    long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nrec) return;
+    const unsigned s = keys[i];
+    const unsigned r = perm[i];
+    const double ta = rec.ta[r], tb = rec.tb[r];
+    int n = 0;
+    for (int j = rec_start[s]; j < rec_start[s + 1]; ++j) {
+        const unsigned rj = perm[j];
+        if (fabs(rec.ta[rj] - ta) <= kTolT && fabs(rec.tb[rj] - tb) <= kTolT) ++n;
+    }
+    const double coef = 1.0 / (double)n;
+    const int64_t cell = rec.cell[r];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        cell_edge[4 * i + e] = cell * 4 + e;
+        weight[4 * i + e] = rec.w[4 * (long)r + e] * coef;
+        seg_out[4 * i + e] = (int)s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scale4(const int *__restrict__ in, int n, int *__restrict__ out)
+{
+    int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < n) out[k] = 4 * in[k];
+}
+
+void WeightSet::release()
+{
+    if (cell_edge) (void)hipFree(cell_edge);
+    if (weight) (void)hipFree(weight);
+    if (seg) (void)hipFree(seg);
+    if (seg_start) (void)hipFree(seg_start);
+    cell_edge = nullptr;
+    weight = nullptr;
+    seg = nullptr;
+    seg_start = nullptr;
+    n = 0;
+    nseg = 0;
+}
+
+namespace {
+struct DevBuf {  // frees on scope exit
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <typename T> T *as() { return reinterpret_cast<T *>(p); }
+};
+}  // namespace
+
+int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
+                  double periodX, WeightSet *out, hipStream_t s)
+{
+    out->release();
+    out->nseg = nseg;
+    NF_REQUIRE(ncell > 0 && ncell < (1l << 31), NF_ERR_ARG, "weights: ncell out of range");
+    NF_REQUIRE(nseg >= 0, NF_ERR_ARG, "weights: negative segment count");
+    const int nshift = periodX > 0.0 ? 3 : 1;
+    const long nwaves = (ncell + kWave - 1) / kWave;
+    const unsigned nblocks = (unsigned)((ncell + kBlock - 1) / kBlock);
+
+    DevBuf d_segs, d_cc, d_cnt, d_off;
+    NF_HIP(d_segs.alloc(sizeof(double) * 4 * (size_t)nseg));
+    NF_HIP(d_cc.alloc(sizeof(int) * (size_t)nseg));
+    NF_HIP(d_cnt.alloc(sizeof(int) * (size_t)nwaves));
+    NF_HIP(d_off.alloc(sizeof(int) * (size_t)(nwaves + 1)));
+    if (nseg > 0) {
+        NF_HIP(hipMemcpyAsync(d_segs.p, segs_host, sizeof(double) * 4 * (size_t)nseg, hipMemcpyHostToDevice, s));
+        NF_HIP(hipMemcpyAsync(d_cc.p, seg_cc_host, sizeof(int) * (size_t)nseg, hipMemcpyHostToDevice, s));
+    }
+    NF_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(int) * (size_t)nwaves, s));
+
+    Records none{};
+    hipLaunchKernelGGL(k_clip<false>, dim3(nblocks), dim3(kBlock), 0, s, xy, ncell, d_segs.as<double>(),
+                       d_cc.as<int>(), nseg, nshift, periodX, (const int *)nullptr, d_cnt.as<int>(), none);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_cnt.as<int>(), nwaves, d_off.as<int>());
+    int nrec_i = 0;
+    NF_HIP(hipMemcpyAsync(&nrec_i, d_off.as<int>() + nwaves, sizeof(int), hipMemcpyDeviceToHost, s));
+    NF_HIP(hipStreamSynchronize(s));
+    const long nrec = nrec_i;
+
+    NF_HIP(hipMalloc((void **)&out->seg_start, sizeof(int) * (size_t)(nseg + 1)));
+    if (nrec == 0) {
+        NF_HIP(hipMemsetAsync(out->seg_start, 0, sizeof(int) * (size_t)(nseg + 1), s));
+        NF_HIP(hipStreamSynchronize(s));
+        return NF_OK;
+    }
+
+    DevBuf r_seg, r_cell, r_ta, r_tb, r_w, k_out, v_in, v_out, tmp, rstart;
+    NF_HIP(r_seg.alloc(sizeof(int) * nrec));
+    NF_HIP(r_cell.alloc(sizeof(int) * nrec));
+    NF_HIP(r_ta.alloc(sizeof(double) * nrec));
+    NF_HIP(r_tb.alloc(sizeof(double) * nrec));
+    NF_HIP(r_w.alloc(sizeof(double) * 4 * nrec));
+    Records rec{r_seg.as<int>(), r_cell.as<int>(), r_ta.as<double>(), r_tb.as<double>(), r_w.as<double>()};
+    hipLaunchKernelGGL(k_clip<true>, dim3(nblocks), dim3(kBlock), 0, s, xy, ncell, d_segs.as<double>(),
+                       d_cc.as<int>(), nseg, nshift, periodX, d_off.as<int>(), (int *)nullptr, rec);
+    NF_HIP(hipGetLastError());
+
+    // stable sort of record indices by global segment id
+    NF_HIP(k_out.alloc(sizeof(unsigned) * nrec));
+    NF_HIP(v_in.alloc(sizeof(unsigned) * nrec));
+    NF_HIP(v_out.alloc(sizeof(unsigned) * nrec));
+    const unsigned nb_rec = (unsigned)((nrec + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_iota, dim3(nb_rec), dim3(kBlock), 0, s, v_in.as<unsigned>(), nrec);
+    int bits = 1;
+    while ((1l << bits) < (long)nseg + 1 && bits < 32) ++bits;
+    size_t tmp_bytes = 0;
+    NF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned *)r_seg.p, k_out.as<unsigned>(),
+                                     v_in.as<unsigned>(), v_out.as<unsigned>(), (size_t)nrec, 0u, (unsigned)bits, s));
+    NF_HIP(tmp.alloc(tmp_bytes));
+    NF_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (const unsigned *)r_seg.p, k_out.as<unsigned>(),
+                                     v_in.as<unsigned>(), v_out.as<unsigned>(), (size_t)nrec, 0u, (unsigned)bits, s));
+    NF_HIP(rstart.alloc(sizeof(int) * (size_t)(nseg + 1)));
+    hipLaunchKernelGGL(k_seg_bounds, dim3((unsigned)((nseg + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       k_out.as<unsigned>(), nrec, nseg, rstart.as<int>());
+
+    out->n = 4 * nrec;
+    NF_HIP(hipMalloc((void **)&out->cell_edge, sizeof(int64_t) * (size_t)out->n));
+    NF_HIP(hipMalloc((void **)&out->weight, sizeof(double) * (size_t)out->n));
+    NF_HIP(hipMalloc((void **)&out->seg, sizeof(int) * (size_t)out->n));
+    hipLaunchKernelGGL(k_expand, dim3(nb_rec), dim3(kBlock), 0, s, k_out.as<unsigned>(), v_out.as<unsigned>(),
+                       nrec, rec, rstart.as<int>(), out->cell_edge, out->weight, out->seg);
+    hipLaunchKernelGGL(k_scale4, dim3((unsigned)((nseg + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       rstart.as<int>(), nseg + 1, out->seg_start);
+    NF_HIP(hipGetLastError());
+    NF_HIP(hipStreamSynchronize(s));
+    return NF_OK;
+}
+
+}  // namespace nf

@@ -1,0 +1,376 @@
+"""Field: the flux engine, same surface as nemoflux/field.py:15-234, running on the gfx950 kernels.
+
+What fluxviz.py / fluxplot.py read stays available under the same names: timeIndex, nt, nz,
+ny, nx, dx, lonmin..latmax, sverdrup, maxAbsFlux, lonlat, edgeFluxesUArray, edgeFluxesVArray,
+integratedVelocity, vectorPoints, vectorValues, plis, timeObj, gr, thickness, arcLengths; update(),
+getFluxText(); plus computeFlux(tIndex) / computeAll() (BASELINE.json north_star).  The host arrays that
+VTK aliases (fluxviz.py:148,160,168) are written IN PLACE at every update().
+"""
+import ctypes
+import re
+
+import numpy
+
+from . import _lib, mint
+from ._lib import lib, check, NF_F64, NF_F32
+from .horizgrid import HorizGrid
+from .io import open_tfile, open_uvfile
+
+EARTH_RADIUS = 6371000.0  # field.py:12
+
+
+def _dtype_code(a):
+    import torch
+    dt = a.dtype
+    if dt in (numpy.float64, torch.float64):
+        return NF_F64
+    if dt in (numpy.float32, torch.float32):
+        return NF_F32
+    raise RuntimeError(f'ERROR: unsupported dtype {dt} (need float64 or float32)')
+
+
+def _geometry_only(bounds_lon, bounds_lat):
+    """Run the geometry kernel alone: {'points': (ncell,4,3), 'arcLengths': (ncell,4), 'box': 4 floats}."""
+    h = ctypes.c_void_p()
+    check(lib.nf_field_new(ctypes.byref(h)))
+    try:
+        blon = numpy.ascontiguousarray(bounds_lon)
+        blat = numpy.ascontiguousarray(bounds_lat)
+        if blon.dtype != blat.dtype:
+            blat = blat.astype(blon.dtype)
+        ny, nx, _ = blon.shape
+        check(lib.nf_field_set_bounds(ctypes.byref(h), blon.ctypes.data, blat.ctypes.data, ny, nx, _dtype_code(blon), 0))
+        pts = numpy.empty((ny * nx, 4, 3), numpy.float64)
+        arc = numpy.empty((ny * nx, 4), numpy.float64)
+        check(lib.nf_field_get_points(ctypes.byref(h), _lib.dptr(pts)))
+        check(lib.nf_field_get_arclengths(ctypes.byref(h), _lib.dptr(arc)))
+        b = [ctypes.c_double() for _ in range(4)]
+        check(lib.nf_field_get_box(ctypes.byref(h), *[ctypes.byref(x) for x in b]))
+        return dict(points=pts, arcLengths=arc, box=[x.value for x in b])
+    finally:
+        lib.nf_field_del(ctypes.byref(h))
+
+
+class _TimeObj(object):
+    """timeobj.TimeObj stand-in that tolerates a missing time axis."""
+
+    def __init__(self, timeValues=None):
+        self.timeVarName = 'time_counter' if timeValues is not None else ''
+        self.timeValues = timeValues
+
+    def getSize(self):
+        return 0 if self.timeValues is None else len(self.timeValues)
+
+    def getValues(self):
+        return self.timeValues
+
+    def getTimeAsDate(self, timeIndex):
+        return timeIndex if self.timeValues is None else self.timeValues[timeIndex]
+
+    def getTimeAsString(self, timeIndex):
+        return f'{timeIndex}' if self.timeValues is None else f'{self.timeValues[timeIndex]}'
+
+
+class _Transect(object):
+    """Entry of Field.plis: quacks like mint.PolylineIntegral.getIntegral (fluxplot.py:56).
+
+    When asked about the Field's own integratedVelocity it returns the value the batched on-device
+    reduction produced for the current step; any other data goes through a real PolylineIntegral."""
+
+    def __init__(self, field, index, xyz):
+        self._field, self._index, self._xyz = field, index, xyz
+        self._pli = None
+
+    def getIntegral(self, data, placement=mint.CELL_BY_CELL_DATA):
+        f = self._field
+        if data is f.integratedVelocity and f._row_valid:
+            return float(f._row[f._nseg + self._index])
+        if self._pli is None:
+            self._pli = mint.PolylineIntegral()
+            self._pli.setGrid(f.gr.getMintGrid())
+            self._pli.buildLocator(numCellsPerBucket=128, periodX=f.periodX, enableFolding=False)
+            self._pli.computeWeights(self._xyz, counterclock=False)
+        return self._pli.getIntegral(data, placement)
+
+    def getSegmentIntegrals(self):
+        f = self._field
+        o = f._tr_off
+        return numpy.array(f._row[o[self._index]:o[self._index + 1]])
+
+
+class Field(object):
+
+    def __init__(self, tFile, uFile, vFile, lonLatZPoints, sverdrup=False, **kw):
+        """Same positional signature as the reference (field.py:17).  tFile/uFile/vFile: NetCDF (needs
+        xarray) or the .npz bundles of nemoflux_amd.datagen; see fromArrays for in-memory / HBM data."""
+        t = open_tfile(tFile)
+        if 'deptht_bounds' not in t:
+            raise RuntimeError(f'ERROR: {tFile} has no variable deptht_bounds')
+        uo, fu = open_uvfile(uFile, 'uo')
+        vo, fv = open_uvfile(vFile, 'vo')
+        fill = kw.pop('fill_value', fu if not numpy.isnan(fu) else fv)
+        self._setup(t['bounds_lon'], t['bounds_lat'], t['deptht_bounds'], uo, vo, lonLatZPoints, sverdrup,
+                    fill_value=fill, **kw)
+
+    @classmethod
+    def fromArrays(cls, bounds_lon, bounds_lat, deptht_bounds, uo, vo, lonLatZPoints, sverdrup=False, **kw):
+        """bounds_*: (ny,nx,4) host arrays (f64/f32) or torch CUDA tensors; uo/vo: (nt,nz,ny,nx) [or (nz,ny,nx)]
+        host arrays, torch CUDA tensors or DeviceArray (HBM-resident, used in place)."""
+        self = cls.__new__(cls)
+        self._setup(bounds_lon, bounds_lat, deptht_bounds, uo, vo, lonLatZPoints, sverdrup, **kw)
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    def _setup(self, bounds_lon, bounds_lat, deptht_bounds, uo, vo, lonLatZPoints, sverdrup,
+               fill_value=numpy.nan, periodX=360., numCellsPerBucket=128, slab_range=None, readback=True,
+               timeValues=None, stream=None):
+        _lib.require_gpu()
+        self.sverdrup = sverdrup
+        self.periodX = periodX
+        self._readback = readback
+        self._h = ctypes.c_void_p()
+        check(lib.nf_field_new(ctypes.byref(self._h)))
+        if stream is not None:
+            check(lib.nf_field_set_stream(ctypes.byref(self._h), ctypes.c_void_p(stream)))
+        self._keep = [bounds_lon, bounds_lat, uo, vo]  # borrowed buffers must outlive the handle
+
+        # --- cell bounds -> geometry kernel (field.py:22-31, 42, 56)
+        plon, plat = _lib.device_pointer(bounds_lon), _lib.device_pointer(bounds_lat)
+        if plon is None:
+            bounds_lon = numpy.ascontiguousarray(bounds_lon)
+            bounds_lat = numpy.ascontiguousarray(bounds_lat)
+            if bounds_lat.dtype != bounds_lon.dtype:
+                bounds_lat = bounds_lat.astype(bounds_lon.dtype)
+            self._keep += [bounds_lon, bounds_lat]
+            plon, plat, on_dev = bounds_lon.ctypes.data, bounds_lat.ctypes.data, 0
+        else:
+            on_dev = 1
+        if len(bounds_lon.shape) != 3 or bounds_lon.shape[2] != 4 or tuple(bounds_lon.shape) != tuple(bounds_lat.shape):
+            raise RuntimeError('ERROR: bounds_lat/bounds_lon must have shape (ny, nx, 4)')
+        self._bounds = (bounds_lon, bounds_lat)
+        ny, nx = int(bounds_lon.shape[0]), int(bounds_lon.shape[1])
+        check(lib.nf_field_set_bounds(ctypes.byref(self._h), plon, plat, ny, nx, _dtype_code(bounds_lon), on_dev))
+        b = [ctypes.c_double() for _ in range(4)]
+        check(lib.nf_field_get_box(ctypes.byref(self._h), *[ctypes.byref(x) for x in b]))
+        self.lonmin, self.lonmax, self.latmin, self.latmax = [x.value for x in b]
+        print(f'lon-lat box: {self.lonmin}, {self.latmin} -> {self.lonmax}, {self.latmax}')  # field.py:31
+
+        self.timeIndex = 0
+        self.timeObj = _TimeObj(timeValues)
+
+        # --- uo / vo (field.py:34-35, 122-136)
+        self.nt, self.nz, sy, sx = self.getSizes(tuple(uo.shape))
+        if (sy, sx) != (ny, nx) or tuple(vo.shape) != tuple(uo.shape):
+            raise RuntimeError("ERROR: uo/vo shapes do not match the (ny, nx) of the cell bounds")
+        self.ny, self.nx = ny, nx
+        pu, pv = _lib.device_pointer(uo), _lib.device_pointer(vo)
+        if pu is None:
+            uo = numpy.ascontiguousarray(uo)
+            vo = numpy.ascontiguousarray(vo)
+            if vo.dtype != uo.dtype:
+                vo = vo.astype(uo.dtype)
+            self._keep += [uo, vo]
+            pu, pv, uv_dev = uo.ctypes.data, vo.ctypes.data, 0
+        else:
+            uv_dev = 1
+        check(lib.nf_field_set_uv(ctypes.byref(self._h), pu, pv, self.nt, _dtype_code(uo), uv_dev, float(fill_value)))
+        check(lib.nf_field_set_sverdrup(ctypes.byref(self._h), 1 if sverdrup else 0))
+        if slab_range is not None:
+            check(lib.nf_field_set_slab_range(ctypes.byref(self._h), int(slab_range[0]), int(slab_range[1])))
+        self.slab_range = slab_range
+
+        # --- layer thickness (field.py:51)
+        self.bounds_depth = numpy.asarray(deptht_bounds)
+        self.thickness = numpy.ascontiguousarray(self.bounds_depth[:, 1] - self.bounds_depth[:, 0], dtype=numpy.float64)
+        if self.thickness.shape[0] != self.nz:
+            raise RuntimeError('ERROR: deptht_bounds does not match the number of levels of uo')
+        check(lib.nf_field_set_thickness(ctypes.byref(self._h), _lib.dptr(self.thickness), self.nz))
+
+        # --- grid + transects (field.py:42-49): all polylines in one batched weight build
+        self.gr = HorizGrid(_field=self)
+        self._polylines = [numpy.ascontiguousarray(numpy.array(p, dtype=numpy.float64)).reshape(-1, 3)
+                           for p in lonLatZPoints]
+        self.plis = []
+        for i, xyz in enumerate(self._polylines):
+            tid = ctypes.c_int()
+            check(lib.nf_field_add_transect(ctypes.byref(self._h), _lib.dptr(xyz), xyz.shape[0], 0, ctypes.byref(tid)))
+            self.plis.append(_Transect(self, i, xyz))
+        check(lib.nf_field_build_weights(ctypes.byref(self._h), int(numCellsPerBucket), float(periodX)))
+        n = ctypes.c_int()
+        check(lib.nf_field_num_segments(ctypes.byref(self._h), ctypes.byref(n)))
+        self._nseg = n.value
+        self._tr_off = numpy.zeros(len(self.plis) + 1, numpy.int32)
+        check(lib.nf_field_segment_offsets(ctypes.byref(self._h), self._tr_off.ctypes.data_as(_lib.c_int_p)))
+        check(lib.nf_field_row_length(ctypes.byref(self._h), ctypes.byref(n)))
+        self._rowlen = n.value
+        self._row = numpy.zeros(max(self._rowlen, 1), numpy.float64)
+        self._row_valid = False
+
+        numCells = self.ny * self.nx
+        self.dx = min((self.lonmax - self.lonmin) / float(self.nx), (self.latmax - self.latmin) / float(self.ny))
+        self._arc = None
+
+        # --- host mirrors of the per-step arrays (field.py:59-63); pinned, updated in place
+        self._pinned = []
+        self.edgeFluxesUArray = self._host_zeros((numCells,))
+        self.edgeFluxesVArray = self._host_zeros((numCells,))
+        self.integratedVelocity = self._host_zeros((numCells, 4))
+        self.maxAbsFlux = 0.
+
+        # first step (field.py:65-67)
+        self._compute(self.timeIndex)
+        print(f'max vertically integrated edge |flux|: {self.maxAbsFlux}')
+
+        self._lonlat = None
+        # arrow seed points along the target lines (field.py:71-87)
+        vectorPoints = []
+        self.uVectors = []
+        for lonlatpts in self._polylines:
+            for i in range(len(lonlatpts) - 1):
+                begPoint = numpy.array(lonlatpts[i])
+                endPoint = numpy.array(lonlatpts[i + 1])
+                u = endPoint - begPoint
+                distance = numpy.sqrt(u.dot(u))
+                if distance == 0 or self.dx <= 0:
+                    continue
+                u /= distance
+                nvpts = max(2, int(distance / self.dx))
+                vdx = distance / float(nvpts - 1)
+                for j in range(nvpts):
+                    vectorPoints.append(begPoint + u * j * vdx)
+                    self.uVectors.append(u)
+        self.vectorPoints = numpy.array(vectorPoints) if vectorPoints else numpy.zeros((0, 3))
+        # mint.VectorInterp (field.py:90-95) is SURVEY.md 8f rank 2 ("next"): arrows are not computed yet
+        self.vectorValues = numpy.zeros((self.vectorPoints.shape[0], 3), numpy.float64)
+
+    # ------------------------------------------------------------------------------------------
+    def _host_zeros(self, shape):
+        n = int(numpy.prod(shape))
+        p = ctypes.c_void_p()
+        check(lib.nf_host_alloc(ctypes.byref(p), max(n, 1) * 8))
+        self._pinned.append(p.value)
+        a = numpy.ctypeslib.as_array((ctypes.c_double * max(n, 1)).from_address(p.value))[:n].reshape(shape)
+        a[...] = 0.0
+        return a
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                lib.nf_field_del(ctypes.byref(self._h))
+            for p in getattr(self, '_pinned', []):
+                lib.nf_host_free(p)
+            self._pinned = []
+        except Exception:
+            pass
+
+    def _download_points(self):
+        pts = numpy.empty((self.ny * self.nx, 4, 3), numpy.float64)
+        check(lib.nf_field_get_points(ctypes.byref(self._h), _lib.dptr(pts)))
+        return pts
+
+    @property
+    def arcLengths(self):
+        """(ncell, 4) great-circle edge lengths on the unit sphere (field.py:55-56, 170-181)."""
+        if self._arc is None:
+            self._arc = numpy.empty((self.ny * self.nx, 4), numpy.float64)
+            check(lib.nf_field_get_arclengths(ctypes.byref(self._h), _lib.dptr(self._arc)))
+        return self._arc
+
+    @property
+    def lonlat(self):
+        """(ny, nx, 4, 3) corner coordinates for the VTK edge grids (field.py:138-143)."""
+        if self._lonlat is None:
+            self._lonlat = self.gr.getPoints().reshape((self.ny, self.nx, 4, 3))
+        return self._lonlat
+
+    def buildEdgeUVGrids(self, bounds_lon=None, bounds_lat=None):
+        return self.lonlat
+
+    def getSizes(self, shapeU=None):
+        """field.py:122-136."""
+        nt, nz, ny, nx = 1, 1, 0, 0
+        if shapeU is None:
+            return self.nt, self.nz, self.ny, self.nx
+        if len(shapeU) == 4:
+            nt, nz, ny, nx = shapeU
+        elif len(shapeU) == 3:
+            nz, ny, nx = shapeU
+        elif len(shapeU) == 2:
+            ny, nx = shapeU
+        else:
+            raise RuntimeError("ERROR: uo's shape does not match (t, z, y, x), (z, y, x) or (y, x)")
+        return int(nt), int(nz), int(ny), int(nx)
+
+    # ------------------------------------------------------------------------------------------
+    def _compute(self, tIndex, readback=None):
+        if not (0 <= tIndex < self.nt):
+            raise RuntimeError(f'ERROR: time index {tIndex} out of range [0, {self.nt})')
+        check(lib.nf_field_compute_flux(ctypes.byref(self._h), int(tIndex), _lib.dptr(self._row)))
+        self._row_valid = True
+        if self._readback if readback is None else readback:
+            m = ctypes.c_double()
+            check(lib.nf_field_read_step(ctypes.byref(self._h), _lib.dptr(self.integratedVelocity),
+                                         _lib.dptr(self.edgeFluxesUArray), _lib.dptr(self.edgeFluxesVArray),
+                                         ctypes.byref(m)))
+            self.maxAbsFlux = max(self.maxAbsFlux, m.value)  # field.py:234
+        return self._row
+
+    def update(self):
+        """field.py:112-120: recompute the current time step; host arrays are refreshed in place."""
+        self._compute(self.timeIndex, readback=True)
+        # self.vectorValues[:] = vinterp.getFaceVectors(...)  (field.py:119-120) -- "next" row 8f-2
+
+    def computeFlux(self, tIndex, readback=False):
+        """BASELINE north_star's computeFlux(tIndex): set the time index, run the step on the GPU and return
+        the total flux of every transect (list of floats).  = fluxplot.py:51-59 for one step."""
+        self.timeIndex = int(tIndex)
+        row = self._compute(self.timeIndex, readback=readback)
+        return [float(row[self._nseg + i]) for i in range(len(self.plis))]
+
+    def getSegmentFluxes(self):
+        """Per-target-segment sums of the last computed step, one array per transect."""
+        return [numpy.array(self._row[self._tr_off[i]:self._tr_off[i + 1]]) for i in range(len(self.plis))]
+
+    def computeAll(self, out=None):
+        """All nt steps back to back on the GPU (no host round trip per step).  Returns (nt, ntransect)
+        totals and (nt, nseg) per-segment sums.  `out`: optional torch CUDA tensor (nt, row_length) to
+        receive the raw rows in HBM (for the RCCL reduce of nemoflux_amd.dist)."""
+        import torch
+        if out is None:
+            out = torch.empty((self.nt, max(self._rowlen, 1)), dtype=torch.float64, device='cuda')
+        check(lib.nf_field_compute_all_async(ctypes.byref(self._h), ctypes.c_void_p(out.data_ptr())))
+        rows = out.cpu().numpy()
+        return rows[:, self._nseg:self._nseg + len(self.plis)], rows[:, :self._nseg]
+
+    def getFluxText(self):
+        """field.py:98-109."""
+        txt = ""
+        for pli in self.plis:
+            totalFlux = pli.getIntegral(self.integratedVelocity, mint.CELL_BY_CELL_DATA)
+            txt += f"{totalFlux:4.3g}, "
+        if self.sverdrup:
+            txt += "(Sv) "
+        else:
+            txt += "(A m^2/s) "
+        txt = re.sub(r',\s*\(', ' (', txt)
+        return txt
+
+    def getWeights(self):
+        """(cell*4+edge, weight, global segment id) of the batched transect set."""
+        n = ctypes.c_size_t()
+        check(lib.nf_field_num_weights(ctypes.byref(self._h), ctypes.byref(n)))
+        ce = numpy.empty(n.value, numpy.int64)
+        w = numpy.empty(n.value, numpy.float64)
+        sg = numpy.empty(n.value, numpy.int32)
+        check(lib.nf_field_get_weights(ctypes.byref(self._h), ce.ctypes.data_as(_lib.c_int64_p), _lib.dptr(w),
+                                       sg.ctypes.data_as(_lib.c_int_p)))
+        return ce, w, sg
+
+    # timing hooks for bench.py
+    def enableKernelTiming(self, on=True):
+        check(lib.nf_field_timing(ctypes.byref(self._h), 1 if on else 0))
+
+    def readKernelTiming(self):
+        n, ms = ctypes.c_long(), ctypes.c_double()
+        check(lib.nf_field_timing_read(ctypes.byref(self._h), ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value

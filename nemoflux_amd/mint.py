@@ -1,0 +1,135 @@
+"""Drop-in for the subset of the `mint` Python package that nemoflux uses (python-mint >= 1.24.4,
+/root/reference/README.md:12), backed by the gfx950 engine:
+
+    mint.Grid().setPoints / getNumberOfCells / dump             horizgrid.py:23-24,30,43
+    mint.PolylineIntegral().setGrid / buildLocator /
+        computeWeights / getIntegral                            field.py:45-48,102; fluxplot.py:56
+    mint.CELL_BY_CELL_DATA                                      field.py:102
+
+`import nemoflux_amd.mint as mint` in place of `import mint` is the whole integration.
+Same names, argument meaning and error behaviour; all numbers come from HIP kernels (no CPU fallback).
+"""
+import ctypes
+
+import numpy
+
+from . import _lib
+from ._lib import lib, check
+
+CELL_BY_CELL_DATA = 0  # mint.CELL_BY_CELL_DATA
+UNIQUE_EDGE_DATA = 1   # mint.UNIQUE_EDGE_DATA (unused by nemoflux; rejected by getIntegral)
+
+
+class Grid(object):
+    """mint.Grid: ncell independent quads in the planar (lon, lat) space."""
+
+    def __init__(self):
+        self.obj = ctypes.c_void_p()
+        self._owner = True
+        self.points = None
+        check(lib.mnt_grid_new(ctypes.byref(self.obj)))
+
+    @classmethod
+    def _view(cls, handle, keepalive):
+        """Wrap a Grid_t owned by a Field (shares the resident corner table)."""
+        g = cls.__new__(cls)
+        g.obj = ctypes.c_void_p(handle)
+        g._owner = False
+        g.points = None
+        g._keepalive = keepalive
+        return g
+
+    def __del__(self):
+        if getattr(self, '_owner', False) and self.obj:
+            lib.mnt_grid_del(ctypes.byref(self.obj))
+
+    def setPoints(self, points):
+        """points: float64 (ncell, 4, 3), C-contiguous; BORROWED like in mint (kept alive on self)."""
+        pts = numpy.asarray(points)
+        if pts.dtype != numpy.float64 or pts.ndim != 3 or pts.shape[1:] != (4, 3) or not pts.flags['C_CONTIGUOUS']:
+            raise RuntimeError('ERROR: points must be a C-contiguous float64 array of shape (numCells, 4, 3)')
+        self.points = pts
+        check(lib.mnt_grid_setPointsPtr(ctypes.byref(self.obj), _lib.dptr(pts)))
+        check(lib.mnt_grid_build(ctypes.byref(self.obj), 4, pts.shape[0]))
+
+    def getNumberOfCells(self):
+        n = ctypes.c_size_t()
+        check(lib.mnt_grid_getNumberOfCells(ctypes.byref(self.obj), ctypes.byref(n)))
+        return n.value
+
+    def dump(self, fileName):
+        check(lib.mnt_grid_dump(ctypes.byref(self.obj), str(fileName).encode('utf-8')))
+
+
+class PolylineIntegral(object):
+    """mint.PolylineIntegral: flux of cell-by-cell edge data across a target polyline."""
+
+    def __init__(self):
+        self.obj = ctypes.c_void_p()
+        self.grid = None
+        self.numSegments = 0
+        check(lib.mnt_polylineintegral_new(ctypes.byref(self.obj)))
+
+    def __del__(self):
+        if self.obj:
+            lib.mnt_polylineintegral_del(ctypes.byref(self.obj))
+
+    def setGrid(self, grid):
+        self.grid = grid  # keep the grid (and its borrowed points) alive
+        check(lib.mnt_polylineintegral_setGrid(ctypes.byref(self.obj), grid.obj))
+
+    def buildLocator(self, numCellsPerBucket=128, periodX=360., enableFolding=False):
+        check(lib.mnt_polylineintegral_buildLocator(ctypes.byref(self.obj), int(numCellsPerBucket), float(periodX),
+                                                    1 if enableFolding else 0))
+
+    def computeWeights(self, xyz, counterclock=False):
+        xyz = numpy.ascontiguousarray(xyz, dtype=numpy.float64)
+        if xyz.ndim != 2 or xyz.shape[1] != 3:
+            raise RuntimeError('ERROR: xyz must have shape (numPoints, 3)')
+        self.numSegments = xyz.shape[0] - 1
+        check(lib.mnt_polylineintegral_computeWeights(ctypes.byref(self.obj), xyz.shape[0], _lib.dptr(xyz),
+                                                      1 if counterclock else 0))
+
+    def getIntegral(self, data, placement=CELL_BY_CELL_DATA):
+        """data: float64 (ncell, 4) [or flat]; host numpy (staged over PCIe) or HBM-resident
+        (torch CUDA tensor / DeviceBuffer in the same (ncell,4) layout)."""
+        res = ctypes.c_double()
+        p = _lib.device_pointer(data)
+        if p is not None:
+            check(lib.mnt_polylineintegral_getIntegralDev(ctypes.byref(self.obj), p, int(placement),
+                                                          ctypes.byref(res), None))
+        else:
+            d = numpy.ascontiguousarray(data, dtype=numpy.float64)
+            if d.size != self.grid.getNumberOfCells() * 4:
+                raise RuntimeError('ERROR: data must hold 4 edge values per cell')
+            check(lib.mnt_polylineintegral_getIntegral(ctypes.byref(self.obj), _lib.dptr(d), int(placement),
+                                                       ctypes.byref(res)))
+        return res.value
+
+    # ---- extensions beyond mint
+    def getSegmentIntegrals(self, data):
+        """Per-target-segment sums (numSegments,) and the total."""
+        res = ctypes.c_double()
+        seg = numpy.zeros(max(self.numSegments, 1), numpy.float64)
+        p = _lib.device_pointer(data)
+        buf = None
+        if p is None:
+            d = numpy.ascontiguousarray(data, dtype=numpy.float64)
+            buf = _lib.DeviceBuffer(d.nbytes).upload(d)
+            p = buf.ptr
+        check(lib.mnt_polylineintegral_getIntegralDev(ctypes.byref(self.obj), p, CELL_BY_CELL_DATA,
+                                                      ctypes.byref(res), _lib.dptr(seg)))
+        if buf is not None:
+            buf.free()
+        return seg[:self.numSegments], res.value
+
+    def getWeights(self):
+        """(cell*4+edge int64, weight float64, segment int32) of every entry, sorted by segment."""
+        n = ctypes.c_size_t()
+        check(lib.mnt_polylineintegral_getNumberOfWeights(ctypes.byref(self.obj), ctypes.byref(n)))
+        ce = numpy.empty(n.value, numpy.int64)
+        w = numpy.empty(n.value, numpy.float64)
+        sg = numpy.empty(n.value, numpy.int32)
+        check(lib.mnt_polylineintegral_getWeights(ctypes.byref(self.obj), ce.ctypes.data_as(_lib.c_int64_p),
+                                                  _lib.dptr(w), sg.ctypes.data_as(_lib.c_int_p)))
+        return ce, w, sg

@@ -1,0 +1,341 @@
+/*
+ * nf_oracle.c -- CPU restatement of the nemoflux transect-flux hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in nemoflux_amd/ (the product) may include, link, import or
+ * execute this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * and only as the checker / the timed CPU baseline.
+ *
+ * Every function cites the reference lines it restates (paths relative to /root/reference):
+ *   A1  nfo_assemble_points      nemoflux/horizgrid.py:17-22
+ *   A3  nfo_arc_lengths          nemoflux/field.py:170-181, nemoflux/geo.py:14-27 (R = 1, geo.py:3)
+ *   A4  nfo_vertical_integral    nemoflux/field.py:145-163 (fillna(0) :157, tensordot :161)
+ *   A5  nfo_edge_flux            nemoflux/field.py:183-234
+ *   A6  nfo_polyline_weights     mint.PolylineIntegral.computeWeights as driven by field.py:45-48
+ *   A7  nfo_get_integral         mint.PolylineIntegral.getIntegral as driven by field.py:102
+ *
+ * Parity pinning:
+ *   A1,A3,A4,A5 are pinned by tests/golden (npz files), which were produced by RUNNING the reference's own
+ *   datagen.py / field.py / geo.py (oracle/gen_golden.py).
+ *   A6,A7 restate a THIRD-PARTY dependency that is absent from /root/reference and from this image:
+ *   conda-forge python-mint >= 1.24.4 (README.md:12; no lock file, no vendored source).  The
+ *   reference holds no tests for it.  The restatement follows the published algorithm (SURVEY.md
+ *   section 8a row A6: planar lon/lat, per-cell clip of every target segment, inverse bilinear map,
+ *   four edge weights, 1/n multiplicity for sub-segments shared by n cells, periodicity in x) and is
+ *   pinned by the reference's README known answers only (360, 0.5, 0, ~1e-15, ~1e-11:
+ *   tests/golden/known_answers.json) plus the path-independence property README.md:45,58 states.
+ *   Edge-case behaviour beyond those (tolerances, non-convex cells) is "parity unpinned".
+ *
+ * Build: see oracle/Makefile (gcc -O2 -mfma -ffp-contract=off).  fma() is used explicitly where the
+ * HIP kernels use it so the two can be compared bit-for-bit; no other contraction is allowed.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+
+#define NFO_DEG2RAD (3.14159265358979323846 / 180.0) /* geo.py:4 numpy.pi/180. */
+#define NFO_EARTH_RADIUS_GEO 1.0                     /* geo.py:3 */
+#define NFO_EARTH_RADIUS_SV 6371000.0                /* field.py:12 */
+
+/* ---- A1: horizgrid.py:17-22 : points[c][v] = (lon, lat, 0) ------------------------------------ */
+void nfo_assemble_points(const double *bounds_lon, const double *bounds_lat, long ncell, double *points)
+{
+    for (long k = 0; k < ncell * 4; ++k) {
+        points[3 * k + 0] = bounds_lon[k];
+        points[3 * k + 1] = bounds_lat[k];
+        points[3 * k + 2] = 0.0;
+    }
+}
+
+/* ---- A3: field.py:170-181 + geo.py:14-27 ------------------------------------------------------ */
+static void lonlat2xyz(const double *p, double *xyz)
+{
+    /* geo.py:15-21 */
+    double lam = p[0] * NFO_DEG2RAD;
+    double the = p[1] * NFO_DEG2RAD;
+    double rho = NFO_EARTH_RADIUS_GEO * cos(the);
+    xyz[0] = rho * cos(lam);
+    xyz[1] = rho * sin(lam);
+    xyz[2] = NFO_EARTH_RADIUS_GEO * sin(the);
+}
+
+void nfo_arc_lengths(const double *points, long ncell, double *arc)
+{
+    const double r2 = NFO_EARTH_RADIUS_GEO * NFO_EARTH_RADIUS_GEO;
+    for (long c = 0; c < ncell; ++c) {
+        double xyz[4][3];
+        for (int v = 0; v < 4; ++v) lonlat2xyz(points + (c * 4 + v) * 3, xyz[v]);
+        for (int i0 = 0; i0 < 4; ++i0) { /* field.py:179-181 */
+            int i1 = (i0 + 1) % 4;
+            /* geo.py:26 numpy.sum(xyzA*xyzB, axis=-1): ((x + y) + z) */
+            double dot = (xyz[i0][0] * xyz[i1][0] + xyz[i0][1] * xyz[i1][1]) + xyz[i0][2] * xyz[i1][2];
+            double angle = acos(dot / r2);
+            arc[c * 4 + i0] = fabs(NFO_EARTH_RADIUS_GEO * angle); /* geo.py:27 */
+        }
+    }
+}
+
+/* ---- A4: field.py:145-163 ---------------------------------------------------------------------
+ * f: (nz, ncell) x-fastest, float64 (is_f32 = 0) or float32 (is_f32 = 1).  Missing -> 0 (:157): xarray
+ * decodes values equal to _FillValue into NaN and fillna(0.0) zeroes them; fill = NaN means "no
+ * _FillValue attribute".  Vertical integral (:161) as a sequential fma chain over z (numpy hands the
+ * contraction to BLAS, whose summation order is unspecified; see tests for the tolerance). */
+void nfo_vertical_integral(const void *f, int is_f32, long nz, long ncell, const double *thickness,
+                           double fill, double *out)
+{
+    const double *fd = (const double *)f;
+    const float *ff = (const float *)f;
+    const float fillf = (float)fill;
+    for (long c = 0; c < ncell; ++c) out[c] = 0.0;
+    for (long z = 0; z < nz; ++z) {
+        double th = thickness[z];
+        for (long c = 0; c < ncell; ++c) {
+            double x;
+            if (is_f32) {
+                float xf = ff[z * ncell + c];
+                x = (xf != xf || xf == fillf) ? 0.0 : (double)xf;
+            } else {
+                x = fd[z * ncell + c];
+                x = (x != x || x == fill) ? 0.0 : x;
+            }
+            out[c] = fma(th, x, out[c]);
+        }
+    }
+}
+
+/* ---- A5: field.py:183-234 ---------------------------------------------------------------------
+ * iV must be zero-initialised ONCE by the caller (field.py:62) and then carried across calls: row 0's
+ * south slot is never written (:219).  max_abs is the running maximum (:234). */
+void nfo_edge_flux(const double *uInt, const double *vInt, const double *arc /* (ncell,4) */, long ny,
+                   long nx, int sverdrup, double *iV, double *eU, double *eV, double *max_abs)
+{
+    long ncell = ny * nx;
+    for (long c = 0; c < ncell; ++c) {
+        eU[c] = +uInt[c] * arc[c * 4 + 1]; /* :195 */
+        eV[c] = -vInt[c] * arc[c * 4 + 2]; /* :196 */
+        iV[c * 4 + 1] = eU[c];             /* :209 */
+        iV[c * 4 + 2] = eV[c];             /* :211 */
+    }
+    for (long j = 1; j < ny; ++j)
+        for (long i = 0; i < nx; ++i) iV[(j * nx + i) * 4 + 0] = eV[(j - 1) * nx + i]; /* :219 */
+    for (long j = 0; j < ny; ++j) {
+        for (long i = 1; i < nx; ++i) iV[(j * nx + i) * 4 + 3] = eU[j * nx + i - 1]; /* :221 */
+        iV[(j * nx) * 4 + 3] = eU[j * nx + nx - 1];                                 /* :223 */
+    }
+    if (sverdrup) { /* :225-228 */
+        const double s = NFO_EARTH_RADIUS_SV / 1.e6;
+        for (long c = 0; c < ncell; ++c) { eU[c] *= s; eV[c] *= s; }
+        for (long k = 0; k < ncell * 4; ++k) iV[k] *= s;
+    }
+    double m = *max_abs;
+    for (long c = 0; c < ncell; ++c) { /* :231-234 */
+        eU[c] = fabs(eU[c]);
+        eV[c] = fabs(eV[c]);
+        if (eU[c] > m) m = eU[c];
+        if (eV[c] > m) m = eV[c];
+    }
+    *max_abs = m;
+}
+
+/* ---- A6: mint.PolylineIntegral.computeWeights (field.py:45-48) --------------------------------- */
+#define NFO_EPS_PAR 1.e-12     /* |sin(angle)| below which a cell edge and the target are parallel */
+#define NFO_TOL_DIST_REL 1.e-12 /* on-the-edge distance tolerance, relative to max |coordinate| */
+#define NFO_TOL_T 1.e-10        /* min sub-segment length / interval matching tolerance, in t */
+#define NFO_NEWTON_MAX 16
+
+typedef struct {
+    int seg;
+    int shift;
+    long cell;
+    double ta, tb;
+    double w[4];
+    double coef;
+} nfo_rec;
+
+static double max2(double a, double b) { return a > b ? a : b; }
+
+/* Clip the segment q + t d, t in [0,1], against the convex quad v (x0,y0,...,x3,y3). */
+static int clip_cell(const double *v, double qx, double qy, double dx, double dy, double *ta, double *tb)
+{
+    double area2 = ((v[2] - v[0]) * (v[5] - v[1]) - (v[4] - v[0]) * (v[3] - v[1])) +
+                   ((v[4] - v[0]) * (v[7] - v[1]) - (v[6] - v[0]) * (v[5] - v[1]));
+    if (!(area2 != 0.0)) return 0;
+    double sgn = area2 > 0.0 ? 1.0 : -1.0;
+    double M = max2(max2(fabs(qx), fabs(qy)), max2(fabs(qx + dx), fabs(qy + dy)));
+    for (int k = 0; k < 8; ++k) M = max2(M, fabs(v[k]));
+    double told = NFO_TOL_DIST_REL * M;
+    double dd = dx * dx + dy * dy;
+    double t0 = 0.0, t1 = 1.0;
+    for (int e = 0; e < 4; ++e) {
+        int e1 = (e + 1) & 3;
+        double ax = v[2 * e], ay = v[2 * e + 1];
+        double gx = v[2 * e1] - ax, gy = v[2 * e1 + 1] - ay;
+        double gg = gx * gx + gy * gy;
+        if (gg <= told * told) continue; /* collapsed edge (pole): no constraint */
+        double nx = -gy * sgn, ny = gx * sgn; /* inward normal */
+        double num = nx * (qx - ax) + ny * (qy - ay);
+        double den = nx * dx + ny * dy;
+        if (den * den <= (NFO_EPS_PAR * NFO_EPS_PAR) * gg * dd) {
+            if (num < 0.0 && num * num > told * told * gg) return 0; /* parallel and outside */
+        } else {
+            double t = -num / den;
+            if (den > 0.0) { if (t > t0) t0 = t; }
+            else           { if (t < t1) t1 = t; }
+        }
+    }
+    if (!(t1 - t0 > NFO_TOL_T)) return 0;
+    *ta = t0;
+    *tb = t1;
+    return 1;
+}
+
+/* Inverse of the bilinear map of quad v at point p (Newton from the cell centre). */
+static void inv_bilinear(const double *v, double px, double py, double *xi0, double *xi1)
+{
+    double ax = v[0], ay = v[1];
+    double e1x = v[2] - v[0], e1y = v[3] - v[1];
+    double e3x = v[6] - v[0], e3y = v[7] - v[1];
+    double hx = (v[0] - v[2]) + (v[4] - v[6]), hy = (v[1] - v[3]) + (v[5] - v[7]);
+    double s = 0.5, t = 0.5;
+    for (int it = 0; it < NFO_NEWTON_MAX; ++it) {
+        double fx = ((ax + s * e1x) + t * e3x) + (s * t) * hx - px;
+        double fy = ((ay + s * e1y) + t * e3y) + (s * t) * hy - py;
+        double j00 = e1x + t * hx, j01 = e3x + s * hx;
+        double j10 = e1y + t * hy, j11 = e3y + s * hy;
+        double det = j00 * j11 - j01 * j10;
+        if (!(det != 0.0)) break;
+        double ds = (fx * j11 - fy * j01) / det;
+        double dt = (fy * j00 - fx * j10) / det;
+        s -= ds;
+        t -= dt;
+        if (fabs(ds) + fabs(dt) < 1.e-15) break;
+    }
+    *xi0 = s;
+    *xi1 = t;
+}
+
+static int rec_cmp(const void *a, const void *b)
+{
+    const nfo_rec *x = (const nfo_rec *)a, *y = (const nfo_rec *)b;
+    if (x->seg != y->seg) return x->seg < y->seg ? -1 : 1;
+    if (x->ta != y->ta) return x->ta < y->ta ? -1 : 1;
+    if (x->cell != y->cell) return x->cell < y->cell ? -1 : 1;
+    if (x->shift != y->shift) return x->shift < y->shift ? -1 : 1;
+    return 0;
+}
+
+/*
+ * points: (ncell,4,3) as handed to mint.Grid.setPoints (horizgrid.py:24); xyz: (npts,3) target polyline
+ * (field.py:48); periodX: buildLocator's periodX (field.py:47; 0 = not periodic); counterclock:
+ * computeWeights' flag (field.py:48 passes False = all edges oriented in +xi).
+ * Output (sorted by segment, ta, cell): cell_edge[k] = cell*4 + edge, weight[k], seg[k] (0-based target
+ * segment).  Returns the number of entries (4 per crossed cell), or -(needed) if cap is too small.
+ */
+long nfo_polyline_weights(const double *points, long ncell, const double *xyz, int npts, double periodX,
+                          int counterclock, long cap, int64_t *cell_edge, double *weight, int *seg)
+{
+    long nrec = 0, rcap = 1024;
+    nfo_rec *recs = (nfo_rec *)malloc(rcap * sizeof(nfo_rec));
+    int nshift = periodX > 0.0 ? 3 : 1;
+    for (int s = 0; s + 1 < npts; ++s) {
+        double p0x = xyz[3 * s], p0y = xyz[3 * s + 1];
+        double dx = xyz[3 * (s + 1)] - p0x, dy = xyz[3 * (s + 1) + 1] - p0y;
+        if (dx == 0.0 && dy == 0.0) continue;
+        for (int k = 0; k < nshift; ++k) {
+            int shift = nshift == 3 ? k - 1 : 0;
+            double qx = p0x + shift * periodX, qy = p0y;
+            double sxmin = qx < qx + dx ? qx : qx + dx, sxmax = qx < qx + dx ? qx + dx : qx;
+            double symin = qy < qy + dy ? qy : qy + dy, symax = qy < qy + dy ? qy + dy : qy;
+            for (long c = 0; c < ncell; ++c) {
+                double v[8];
+                double cxmin = 1e300, cxmax = -1e300, cymin = 1e300, cymax = -1e300;
+                for (int i = 0; i < 4; ++i) {
+                    v[2 * i] = points[(c * 4 + i) * 3];
+                    v[2 * i + 1] = points[(c * 4 + i) * 3 + 1];
+                    if (v[2 * i] < cxmin) cxmin = v[2 * i];
+                    if (v[2 * i] > cxmax) cxmax = v[2 * i];
+                    if (v[2 * i + 1] < cymin) cymin = v[2 * i + 1];
+                    if (v[2 * i + 1] > cymax) cymax = v[2 * i + 1];
+                }
+                /* cheap reject (pure speed-up; one part in 1e9 slack so it never decides anything) */
+                double slack = 1.e-9 * (fabs(cxmin) + fabs(cxmax) + fabs(cymin) + fabs(cymax) + 1.0);
+                if (cxmin > sxmax + slack || cxmax < sxmin - slack || cymin > symax + slack || cymax < symin - slack)
+                    continue;
+                double ta, tb;
+                if (!clip_cell(v, qx, qy, dx, dy, &ta, &tb)) continue;
+                double a0, a1, b0, b1;
+                inv_bilinear(v, qx + ta * dx, qy + ta * dy, &a0, &a1);
+                inv_bilinear(v, qx + tb * dx, qy + tb * dy, &b0, &b1);
+                double d0 = b0 - a0, d1 = b1 - a1;
+                double m0 = 0.5 * (a0 + b0), m1 = 0.5 * (a1 + b1);
+                if (nrec == rcap) {
+                    rcap *= 2;
+                    recs = (nfo_rec *)realloc(recs, rcap * sizeof(nfo_rec));
+                }
+                nfo_rec *r = &recs[nrec++];
+                r->seg = s;
+                r->shift = shift;
+                r->cell = c;
+                r->ta = ta;
+                r->tb = tb;
+                r->w[0] = d0 * (1.0 - m1); /* south  0->1 */
+                r->w[1] = d1 * m0;         /* east   1->2 */
+                r->w[2] = d0 * m1;         /* north  3->2 */
+                r->w[3] = d1 * (1.0 - m0); /* west   0->3 */
+                if (counterclock) { r->w[2] = -r->w[2]; r->w[3] = -r->w[3]; } /* edges 2->3, 3->0 */
+                r->coef = 1.0;
+            }
+        }
+    }
+    qsort(recs, nrec, sizeof(nfo_rec), rec_cmp);
+    /* multiplicity: a sub-segment found with the same [ta,tb] in n cells counts 1/n in each */
+    for (long i = 0; i < nrec; ++i) {
+        int n = 0;
+        for (long j = i; j >= 0 && recs[j].seg == recs[i].seg && recs[i].ta - recs[j].ta <= NFO_TOL_T; --j)
+            if (fabs(recs[j].tb - recs[i].tb) <= NFO_TOL_T) ++n;
+        for (long j = i + 1; j < nrec && recs[j].seg == recs[i].seg && recs[j].ta - recs[i].ta <= NFO_TOL_T; ++j)
+            if (fabs(recs[j].tb - recs[i].tb) <= NFO_TOL_T) ++n;
+        recs[i].coef = 1.0 / (double)n;
+    }
+    long need = nrec * 4;
+    if (need > cap) { free(recs); return -need; }
+    for (long i = 0; i < nrec; ++i)
+        for (int e = 0; e < 4; ++e) {
+            cell_edge[4 * i + e] = (int64_t)recs[i].cell * 4 + e;
+            weight[4 * i + e] = recs[i].w[e] * recs[i].coef;
+            seg[4 * i + e] = recs[i].seg;
+        }
+    free(recs);
+    return need;
+}
+
+/* ---- A7: mint.PolylineIntegral.getIntegral(data, CELL_BY_CELL_DATA) (field.py:102) -------------
+ * data: flat (ncell*4).  seg_totals (nseg, may be NULL) receives the per-target-segment sums. */
+double nfo_get_integral(const double *data, long n, const int64_t *cell_edge, const double *weight,
+                        const int *seg, int nseg, double *seg_totals)
+{
+    double total = 0.0;
+    if (seg_totals) for (int s = 0; s < nseg; ++s) seg_totals[s] = 0.0;
+    long k = 0;
+    while (k < n) {
+        int s = seg[k];
+        double acc = 0.0;
+        for (; k < n && seg[k] == s; ++k) acc += weight[k] * data[cell_edge[k]];
+        if (seg_totals && s < nseg) seg_totals[s] = acc;
+        total += acc;
+    }
+    return total;
+}
+
+/* One whole time step the way Field.update()+getFluxText() run it (field.py:112-120,98-103), for the
+ * CPU-baseline timing of bench.py: A4 (u and v) -> A5 -> A7. */
+double nfo_step(const void *u, const void *v, int is_f32, long nz, long ny, long nx, const double *thickness,
+                double fill, const double *arc, int sverdrup, double *uInt, double *vInt, double *iV,
+                double *eU, double *eV, double *max_abs, long nw, const int64_t *cell_edge,
+                const double *weight, const int *seg)
+{
+    nfo_vertical_integral(u, is_f32, nz, ny * nx, thickness, fill, uInt);
+    nfo_vertical_integral(v, is_f32, nz, ny * nx, thickness, fill, vInt);
+    nfo_edge_flux(uInt, vInt, arc, ny, nx, sverdrup, iV, eU, eV, max_abs);
+    return nfo_get_integral(iV, nw, cell_edge, weight, seg, 0, NULL);
+}
