@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the transect-flux hot path on MI355X.
+
+Metric (BASELINE.json): edge-flux integrals/sec = (t,z,j,i) grid points per wall-second through the full-field
+pass  A4 (missing->0, vertical integral) + A5 (edge fluxes, 4-slot array, |.|, running max) + A7 (all transects),
+inputs resident in HBM; plus the absolute error of every transect total against the closed form (fluxexact).
+
+Workload at N=1 (config C4 of BASELINE.json, the one the metric is quoted on; it fits one 288 GB GPU):
+    3600 x 1800 x 75 levels x 12 time steps, float64, psi = (1+10z)(t+1) arctan2(y, x+180)/(2 pi) (singular),
+    transects: README.md:51's singular transect + 64 seeded node-snapped polylines (config C5's batch).
+A "step" = one pass over all (t,z) slabs this rank owns (12 launches of the flux kernel + the transect
+reduction per time step), followed -- for N>1 -- by ONE RCCL all-reduce of the (nt, nseg+ntransect) rows.
+
+Scaling: weak (default; every rank owns a C4-sized block of 12 time steps of a 12*N-step series) or strong
+(--scaling strong: the 900 slabs of C4 are cut into N contiguous ranges).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_transects(nx, ny, xmin, xmax, ymin, ymax, nbatch, seed=20260401):
+    """README.md:51 singular transect + `nbatch` seeded polylines: 8-64 vertices snapped to grid
+    nodes, |lat| <= 80, half of them closed, all inside the lon box and clear of column 0: psi is not x-periodic,
+    and the west slot of column 0 is always the periodic copy of column nx-1 (field.py:223), so a polyline that
+    cuts through column 0 would not see psi(-180, .)."""
+    dx, dy = (xmax - xmin) / nx, (ymax - ymin) / ny
+    polys = [[(-180., -80.), (-10., -80.), (-10., 80.), (-180., 80.)]]
+    rng = numpy.random.default_rng(seed)
+    jlo, jhi = int(numpy.ceil((-80. - ymin) / dy)), int(numpy.floor((80. - ymin) / dy))
+    for p in range(nbatch):
+        n = int(rng.integers(8, 65))
+        i = rng.integers(1, nx + 1, size=n)
+        j = rng.integers(jlo, jhi + 1, size=n)
+        pts = [(xmin + int(a) * dx, ymin + int(b) * dy) for a, b in zip(i, j)]
+        if p % 2 == 1:
+            pts.append(pts[0])
+        polys.append(pts)
+    return polys
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--nx', type=int, default=3600)
+    ap.add_argument('--ny', type=int, default=1800)
+    ap.add_argument('--nz', type=int, default=75)
+    ap.add_argument('--nt', type=int, default=12, help='time steps per rank (weak) or in total (strong)')
+    ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--batch', type=int, default=64, help='number of extra seeded transects')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nemoflux_amd import dist as nfdist
+    from nemoflux_amd._lib import DeviceArray
+    from nemoflux_amd.datagen import DataGen, STREAM_FUNCTIONS
+    from nemoflux_amd.field import Field
+    from nemoflux_amd.fluxexact import exactFlux
+
+    rank, world, local = nfdist.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f'# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: nemoflux_amd has no CPU fallback')
+    torch.cuda.set_device(local)
+
+    nx, ny, nz = args.nx, args.ny, args.nz
+    psi = STREAM_FUNCTIONS[5]
+    nt_global = args.nt * world if args.scaling == 'weak' else args.nt
+    srange = nfdist.slab_range(nt_global, nz, rank, world)
+    t_begin, t_end = nfdist.time_steps_touched(srange, nz)
+    real = 'float64' if args.dtype == 'f64' else 'float32'
+
+    # ---- synthetic input, generated on the device (datagen.py counterpart)
+    dg = DataGen(real=real)
+    dg.setSizes(nx, ny, nz, nt_global)
+    dg.setBoundingBox(-180., 180., -90., 90., 0., 1.)
+    dg.build()
+    dg.applyStreamFunction(psi)
+    u, v = dg.computeUVFromPotential(t_begin, t_end)
+    slab_elems = ny * nx
+    ug = DeviceArray(nfdist.virtual_base(u, t_begin * nz, slab_elems), (nt_global, nz, ny, nx), real, u)
+    vg = DeviceArray(nfdist.virtual_base(v, t_begin * nz, slab_elems), (nt_global, nz, ny, nx), real, v)
+    polys = make_transects(nx, ny, -180., 180., -90., 90., args.batch)
+    xyzs = [numpy.array([(x, y, 0.) for x, y in p]) for p in polys]
+    stream = torch.cuda.current_stream().cuda_stream
+    t0 = time.time()
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        fld = Field.fromArrays(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, ug, vg, xyzs, slab_range=srange,
+                               readback=False, stream=stream)
+    setup_s = time.time() - t0
+    rows = torch.zeros((nt_global, fld._rowlen), dtype=torch.float64, device='cuda')
+
+    from nemoflux_amd._lib import lib, check
+    import ctypes
+
+    def step():
+        check(lib.nf_field_compute_all_async(ctypes.byref(fld._h), ctypes.c_void_p(rows.data_ptr())))
+        nfdist.reduce_rows(rows)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fld.enableKernelTiming(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    nlaunch, kernel_ms = fld.readKernelTiming()
+    fld.enableKernelTiming(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    units_total = float(nt_global) * nz * ny * nx
+    value = units_total * args.steps / elapsed
+
+    # ---- accuracy: every transect total of every time step vs the closed form (fluxexact.py:36-46)
+    res = rows.cpu().numpy()
+    nseg = fld._nseg
+    max_err, max_ref = 0.0, 0.0
+    for p, pts in enumerate(polys):
+        ex = exactFlux(psi, pts, nz, nt_global)
+        got = res[:, nseg + p]
+        max_err = max(max_err, float(numpy.abs(got - numpy.array(ex)).max()))
+        max_ref = max(max_ref, float(numpy.abs(ex).max()))
+    singular_t0 = float(res[0, nseg + 0])
+
+    # ---- roofline of the dominant kernel (vertical integral + edge flux), HIP events on its stream
+    s = 8 if args.dtype == 'f64' else 4
+    bytes_per_unit = 2 * s + 64.0 / nz                      # u,v reads + (arc 16 + iV 32 + abs 16)/nz
+    own = srange[1] - srange[0]
+    units_per_launch = own * ny * nx / max(1.0, (nlaunch / args.steps))   # owned slabs / launches per step
+    avg_ms = kernel_ms / max(1, nlaunch)
+    achieved = bytes_per_unit * units_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    wl_key = f'{nx}x{ny}x{nz}x{args.nt}_{args.dtype}'
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = json.load(f).get(wl_key, {}).get('hbm_bytes_per_launch')
+    roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                'kernel': 'nf::k_flux', 'avg_launch_ms': round(avg_ms, 4), 'launches': nlaunch,
+                'algorithmic_bytes_per_unit': round(bytes_per_unit, 3)}
+
+    out = {
+        'metric': 'edge-flux integrals/sec', 'value': value, 'unit': 'integrals/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype,
+        'data': 'synthetic',
+        'config': {'workload': f'C4 ORCA12-like {nx}x{ny}x{nz}x{args.nt}' +
+                               (' per GPU' if args.scaling == 'weak' else ' total') +
+                               f', psi={psi}, README singular transect + {args.batch} node-snapped transects',
+                   'nx': nx, 'ny': ny, 'nz': nz, 'nt_global': nt_global, 'transects': len(polys),
+                   'target_segments': nseg, 'weight_entries': int(fld.getWeights()[0].size), 'parallelism': f'(t,z)-slab sharding x{world}, 1 all-reduce',
+                   'setup_s': round(setup_s, 3)},
+        'roofline': roofline,
+        'accuracy': {'max_abs_err_vs_fluxexact': max_err, 'max_abs_exact': max_ref,
+                     'singular_transect_t0': singular_t0, 'transect_steps_checked': len(polys) * nt_global},
+    }
+
+    # ---- CPU baseline (rank 0, N=1 only): the reference's numpy statements on one time step
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out['cpu_baseline'] = cpu_baseline(dg, u, v, nz, ny, nx, xyzs[0], args)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(dg, u, v, nz, ny, nx, xyz0, args):
+    """Reference CPU path timed on this box's host cores: numpy restatement of field.py:157,161 (missing->0,
+    tensordot over z) + field.py:183-234 (edge fluxes) + the oracle's A7 for the README transect, on ONE time
+    step of the bench workload already in RAM (NetCDF I/O excluded, like the GPU side)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import nf_oracle as o
+    o.build()
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    uh, vh = u[0].cpu().numpy(), v[0].cpu().numpy()
+    blon, blat = dg.bounds_lon.cpu().numpy(), dg.bounds_lat.cpu().numpy()
+    pts = o.assemble_points(blon, blat)
+    t0 = time.perf_counter()
+    arc = o.np_arc_lengths(pts)
+    t_arc = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    w = o.polyline_weights(pts, xyz0)
+    t_w = time.perf_counter() - t0
+    th = dg.zbot - dg.ztop
+    st = o.EdgeFluxState(ny, nx)
+    best = 1e30
+    reps = 0
+    t_all = time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t_all < 10.0 and reps < 8):
+        t0 = time.perf_counter()
+        U = o.np_read_field(uh, th)
+        V = o.np_read_field(vh, th)
+        o.np_edge_flux(st, U, V, arc)
+        tot = o.get_integral(w, st.integratedVelocity)
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    units = float(nz) * ny * nx
+    # the plain-C port, one thread, same step
+    t0 = time.perf_counter()
+    Uc = o.vertical_integral(uh, th)
+    Vc = o.vertical_integral(vh, th)
+    o.edge_flux(o.EdgeFluxState(ny, nx), Uc, Vc, arc)
+    t_c = time.perf_counter() - t0
+    return {'value': units / best, 'unit': 'integrals/s', 'cores': int(threads), 'kind': 'port',
+            'sample': f'1 of {args.nt} time steps of the bench workload ({nx}x{ny}x{nz}, {args.dtype}), best of {reps} '
+                      f'reps of the numpy restatement of field.py:157-234 (+oracle A7, README transect): '
+                      f'{best:.3f} s/step; one-off arc lengths {t_arc:.2f} s, oracle weights {t_w:.2f} s; '
+                      f'single-thread C port of the same step: {units / t_c:.3e} integrals/s; flux {tot:.6g}'}
+
+
+if __name__ == '__main__':
+    main()

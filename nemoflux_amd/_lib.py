@@ -167,9 +167,18 @@ class DeviceBuffer(object):
             pass
 
 
+class DeviceArray(object):
+    """An HBM array described by (address, shape, dtype); `keepalive` owns the memory.  Used for the virtual
+    global view of a rank's local slabs (nemoflux_amd.dist.virtual_base)."""
+
+    def __init__(self, ptr, shape, dtype, keepalive=None):
+        import numpy
+        self.ptr, self.shape, self.dtype, self.keepalive = int(ptr), tuple(int(x) for x in shape), numpy.dtype(dtype), keepalive
+
+
 def device_pointer(obj):
     """HBM address of a DeviceBuffer, a torch CUDA tensor or a raw int; None if obj lives on the host."""
-    if isinstance(obj, DeviceBuffer):
+    if isinstance(obj, (DeviceBuffer, DeviceArray)):
         return obj.ptr
     if isinstance(obj, int):
         return obj

@@ -311,7 +311,7 @@ int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, 
     dev_free(p->d_scratch);
     dev_free(p->d_row);
     NF_TRY(dev_alloc(&p->d_tr_off, 2));
-    NF_TRY(dev_alloc(&p->d_scratch, (size_t)p->ws.n));
+    NF_TRY(dev_alloc(&p->d_scratch, (size_t)p->ws.nrec));
     NF_TRY(dev_alloc(&p->d_row, (size_t)p->nseg + 1));
     const int off[2] = {0, p->nseg};
     NF_HIP(hipMemcpy(p->d_tr_off, off, sizeof off, hipMemcpyHostToDevice));
@@ -353,19 +353,15 @@ int mnt_polylineintegral_getIntegral(PolylineIntegral_t **self, const double dat
 int mnt_polylineintegral_getNumberOfWeights(PolylineIntegral_t **self, size_t *n)
 {
     NF_REQUIRE(self && *self && n, NF_ERR_ARG, "mnt_polylineintegral_getNumberOfWeights: null argument");
-    *n = (size_t)(*self)->ws.n;
+    *n = (size_t)(*self)->ws.entries();
     return NF_OK;
 }
 int mnt_polylineintegral_getWeights(PolylineIntegral_t **self, int64_t *cell_edge, double *weight, int *seg)
 {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_polylineintegral_getWeights: null argument");
-    const WeightSet &w = (*self)->ws;
-    if (w.n == 0) return NF_OK;
+    if ((*self)->ws.nrec == 0) return NF_OK;
     NF_NEED_DEVICE();
-    if (cell_edge) NF_HIP(hipMemcpy(cell_edge, w.cell_edge, sizeof(int64_t) * w.n, hipMemcpyDeviceToHost));
-    if (weight) NF_HIP(hipMemcpy(weight, w.weight, sizeof(double) * w.n, hipMemcpyDeviceToHost));
-    if (seg) NF_HIP(hipMemcpy(seg, w.seg, sizeof(int) * w.n, hipMemcpyDeviceToHost));
-    return NF_OK;
+    return weights_to_host((*self)->ws, cell_edge, weight, seg);
 }
 
 }  // extern "C"
@@ -660,7 +656,7 @@ int nf_field_build_weights(nf_field **self, int numCellsPerBucket, double period
     dev_free(f->d_scratch);
     dev_free(f->d_row);
     NF_TRY(dev_alloc(&f->d_tr_off, f->tr_off.size()));
-    NF_TRY(dev_alloc(&f->d_scratch, (size_t)f->ws.n));
+    NF_TRY(dev_alloc(&f->d_scratch, (size_t)f->ws.nrec));
     NF_TRY(dev_alloc(&f->d_row, (size_t)field_row_length(f)));
     NF_HIP(hipMemcpy(f->d_tr_off, f->tr_off.data(), sizeof(int) * f->tr_off.size(), hipMemcpyHostToDevice));
     f->weights_built = true;
@@ -690,19 +686,15 @@ int nf_field_segment_offsets(nf_field **self, int *offsets)
 int nf_field_num_weights(nf_field **self, size_t *n)
 {
     NF_REQUIRE(self && *self && n, NF_ERR_ARG, "nf_field_num_weights: null argument");
-    *n = (size_t)(*self)->ws.n;
+    *n = (size_t)(*self)->ws.entries();
     return NF_OK;
 }
 int nf_field_get_weights(nf_field **self, int64_t *cell_edge, double *weight, int *seg_global)
 {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_get_weights: null field");
-    const WeightSet &w = (*self)->ws;
-    if (w.n == 0) return NF_OK;
+    if ((*self)->ws.nrec == 0) return NF_OK;
     NF_NEED_DEVICE();
-    if (cell_edge) NF_HIP(hipMemcpy(cell_edge, w.cell_edge, sizeof(int64_t) * w.n, hipMemcpyDeviceToHost));
-    if (weight) NF_HIP(hipMemcpy(weight, w.weight, sizeof(double) * w.n, hipMemcpyDeviceToHost));
-    if (seg_global) NF_HIP(hipMemcpy(seg_global, w.seg, sizeof(int) * w.n, hipMemcpyDeviceToHost));
-    return NF_OK;
+    return weights_to_host((*self)->ws, cell_edge, weight, seg_global);
 }
 int nf_field_row_length(nf_field **self, int *n)
 {

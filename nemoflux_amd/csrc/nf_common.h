@@ -68,22 +68,25 @@ int launch_flux(const FluxArgs &a, hipStream_t s);
 int launch_planes_to_aos(const double *planes, long ncell, double *aos, hipStream_t s);
 
 // K2: batched polyline weights.
-struct WeightSet {  // device-resident result, sorted by global target segment
-    long n = 0;     // entries (4 per crossed cell)
-    int64_t *cell_edge = nullptr;
-    double *weight = nullptr;
-    int *seg = nullptr;        // global segment id of every entry
+struct WeightSet {  // device-resident result: one record per (target segment, crossed cell), sorted by segment, ta
+    long nrec = 0;
+    int *cell = nullptr;       // cell id of the record
+    double *w4 = nullptr;      // 4 edge weights per record (S,E,N,W), multiplicity applied
+    int *seg = nullptr;        // global segment id of the record
     int nseg = 0;              // total target segments
-    int *seg_start = nullptr;  // (nseg+1) CSR over entries
+    int *seg_start = nullptr;  // (nseg+1) CSR over records
+    long entries() const { return 4 * nrec; }  // mint's view: (cell*4+edge, weight) entries
     void release();
 };
+// expands records into mint-style entries (host arrays): cell_edge = cell*4+edge, weight, seg
+int weights_to_host(const WeightSet &ws, int64_t *cell_edge, double *weight, int *seg);
 // segs_host: (nseg,4) = x0,y0,dx,dy ; seg_cc_host: counterclock flag per segment
 int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
                   double periodX, WeightSet *out, hipStream_t s);
 
 // K3: gather + wavefront segmented reduction -> per-segment sums, then per-transect sums.
 // row: (nseg + ntransect) doubles in HBM; tr_offsets_dev: (ntransect+1) segment offsets.
-// scratch: at least ws.n doubles.
+// scratch: at least ws.nrec doubles.
 // data: (ncell,4) AoS (planes = 0) or the resident [4][ncell] planes (planes = 1).
 int launch_integral(const WeightSet &ws, const double *data, long ncell, int planes, const int *tr_offsets_dev,
                     int ntransect, double *scratch, double *row, hipStream_t s);

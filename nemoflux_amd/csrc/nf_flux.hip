@@ -212,7 +212,7 @@ static int launch_flux_t(const FluxArgs &a, hipStream_t s)
 template <typename T, int VEC>
 static int launch_flux_v(const FluxArgs &a, hipStream_t s)
 {
-    static const int uz = env_int("NF_FLUX_UZ", 5);
+    static const int uz = env_int("NF_FLUX_UZ", 4);
     static const int nt = env_int("NF_FLUX_NT", 1);
     if (VEC == 1) return launch_flux_t<T, VEC, 4, false>(a, s);
     if (nt) {

@@ -3,21 +3,21 @@
 // Replaces  mint.PolylineIntegral.getIntegral(data, mint.CELL_BY_CELL_DATA) as driven by
 //           nemoflux/field.py:102 and nemoflux/fluxplot.py:56, for ALL transects of a Field at once.
 //
-// Entries (cell*4+edge, weight, global segment id) are sorted by segment (K2).  Stage A: one lane per
-// entry gathers data[cell,edge] (either the reference's (ncell,4) AoS or the engine's resident [4][ncell]
-// planes), multiplies by the weight and runs a WAVEFRONT SEGMENTED SCAN keyed by the segment id (6
-// shuffle steps); the last lane of every run inside the wave stores the run's sum.  Stage B: one wavefront
-// per transect; each lane stitches the per-wave run sums of its segments (in wave order) into the
-// per-segment total, then a butterfly adds the segments into the transect total.  No atomics: the
-// summation tree is fixed, so results are bitwise reproducible.
+// Records (cell, 4 edge weights, global segment id) are sorted by segment (K2).  Stage A: one lane per
+// record gathers the cell's 4 edge values (either the reference's (ncell,4) AoS: one 32-B read, or the engine's
+// resident [4][ncell] planes), forms the weighted sum and runs a WAVEFRONT SEGMENTED SCAN keyed by the
+// segment id (6 shuffle steps); the last lane of every run inside the wave stores the run's sum.  Stage B: one
+// wavefront per target segment stitches the run sums of the waves the segment spans.  Stage C: one wavefront
+// per transect adds its segments.  No atomics: the summation tree is fixed, so results are bitwise
+// reproducible.
 //
 // Output row: [ per-segment sums (nseg) | per-transect sums (ntransect) ].
 #include "nf_common.h"
 
 namespace nf {
 
-__global__ __launch_bounds__(kBlock) void k_gather_segscan(const int64_t *__restrict__ cell_edge,
-                                                           const double *__restrict__ weight,
+__global__ __launch_bounds__(kBlock) void k_gather_segscan(const int *__restrict__ cell,
+                                                           const double *__restrict__ w4,
                                                            const int *__restrict__ seg, long n,
                                                            const double *__restrict__ data, long ncell,
                                                            int planes, double *__restrict__ runsum)
@@ -27,9 +27,21 @@ __global__ __launch_bounds__(kBlock) void k_gather_segscan(const int64_t *__rest
     double val = 0.0;
     int key = -1;
     if (k < n) {
-        const int64_t ce = cell_edge[k];
-        const long addr = planes ? (long)(ce & 3) * ncell + (long)(ce >> 2) : (long)ce;
-        val = weight[k] * data[addr];
+        const long c = cell[k];
+        const double2 *pw = reinterpret_cast<const double2 *>(w4 + 4 * k);
+        const double2 wa = pw[0], wb = pw[1];
+        double d0, d1, d2, d3;
+        if (planes) {
+            d0 = data[c];
+            d1 = data[ncell + c];
+            d2 = data[2 * ncell + c];
+            d3 = data[3 * ncell + c];
+        } else {
+            const double2 *pd = reinterpret_cast<const double2 *>(data + 4 * c);
+            const double2 da = pd[0], db = pd[1];
+            d0 = da.x; d1 = da.y; d2 = db.x; d3 = db.y;
+        }
+        val = ((wa.x * d0 + wa.y * d1) + wb.x * d2) + wb.y * d3;
         key = seg[k];
     }
 #pragma unroll
@@ -42,28 +54,38 @@ __global__ __launch_bounds__(kBlock) void k_gather_segscan(const int64_t *__rest
     if (k < n && (lane == kWave - 1 || k == n - 1 || nk != key)) runsum[k] = val;
 }
 
-__global__ __launch_bounds__(kBlock) void k_finalize(const double *__restrict__ runsum,
-                                                     const int *__restrict__ seg_start,
-                                                     const int *__restrict__ tr_off, int ntransect, int nseg,
-                                                     double *__restrict__ row)
+// one wavefront per target segment: stitch the per-wave run sums of the segment (one per 64-record wave it
+// spans) with a lane-strided sum and a butterfly
+__global__ __launch_bounds__(kBlock) void k_finalize_seg(const double *__restrict__ runsum,
+                                                         const int *__restrict__ seg_start, int nseg,
+                                                         double *__restrict__ row)
 {
-    const int p = (blockIdx.x * kBlock + threadIdx.x) / kWave;  // one wavefront per transect
+    const int s = (blockIdx.x * kBlock + threadIdx.x) / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    if (s >= nseg) return;
+    const long lo = seg_start[s], hi = seg_start[s + 1];
+    double acc = 0.0;
+    if (hi > lo) {
+        const long w0 = lo / kWave, w1 = (hi - 1) / kWave;  // waves of stage A touched by this segment
+        for (long w = w0 + lane; w <= w1; w += kWave) {
+            long e = (w + 1) * kWave;
+            if (e > hi) e = hi;
+            acc += runsum[e - 1];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+    if (lane == 0) row[s] = acc;
+}
+
+// one wavefront per transect: sum of its segments
+__global__ __launch_bounds__(kBlock) void k_finalize_tr(const int *__restrict__ tr_off, int ntransect, int nseg,
+                                                        double *__restrict__ row)
+{
+    const int p = (blockIdx.x * kBlock + threadIdx.x) / kWave;
     const int lane = threadIdx.x & (kWave - 1);
     if (p >= ntransect) return;
     double part = 0.0;
-    for (int s = tr_off[p] + lane; s < tr_off[p + 1]; s += kWave) {
-        const long lo = seg_start[s], hi = seg_start[s + 1];
-        double acc = 0.0;
-        long first = lo;
-        while (first < hi) {  // the run's pieces, one per wave it spans, in order
-            long e = (first / kWave + 1) * kWave;
-            if (e > hi) e = hi;
-            acc += runsum[e - 1];
-            first = e;
-        }
-        row[s] = acc;
-        part += acc;
-    }
+    for (int s = tr_off[p] + lane; s < tr_off[p + 1]; s += kWave) part += row[s];
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, kWave);
     if (lane == 0) row[nseg + p] = part;
 }
@@ -71,14 +93,17 @@ __global__ __launch_bounds__(kBlock) void k_finalize(const double *__restrict__ 
 int launch_integral(const WeightSet &ws, const double *data, long ncell, int planes, const int *tr_offsets_dev,
                     int ntransect, double *scratch, double *row, hipStream_t s)
 {
-    if (ws.n > 0) {
-        hipLaunchKernelGGL(k_gather_segscan, dim3((unsigned)((ws.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                           ws.cell_edge, ws.weight, ws.seg, ws.n, data, ncell, planes, scratch);
+    if (ws.nrec > 0) {
+        hipLaunchKernelGGL(k_gather_segscan, dim3((unsigned)((ws.nrec + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                           ws.cell, ws.w4, ws.seg, ws.nrec, data, ncell, planes, scratch);
+    }
+    if (ws.nseg > 0) {
+        const unsigned nb = (unsigned)(((long)ws.nseg * kWave + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(k_finalize_seg, dim3(nb), dim3(kBlock), 0, s, scratch, ws.seg_start, ws.nseg, row);
     }
     if (ntransect > 0) {
         const unsigned nb = (unsigned)(((long)ntransect * kWave + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_finalize, dim3(nb), dim3(kBlock), 0, s, scratch, ws.seg_start, tr_offsets_dev,
-                           ntransect, ws.nseg, row);
+        hipLaunchKernelGGL(k_finalize_tr, dim3(nb), dim3(kBlock), 0, s, tr_offsets_dev, ntransect, ws.nseg, row);
     }
     NF_HIP(hipGetLastError());
     return NF_OK;

@@ -18,12 +18,14 @@
 // box test (the "locator": numCellsPerBucket -> one 64-cell wave tile) rejects almost every (tile, segment)
 // pair with a uniform branch.  Hits are compacted with ballot/popcount into a deterministic order
 // (tile, segment, shift, lane): pass 1 counts per wave, a single-workgroup scan turns counts into offsets,
-// pass 2 recomputes and writes records.  Records are then stably radix-sorted by global segment id
-// (rocPRIM), the multiplicity is resolved per record against the records of the same segment, and each
-// record expands into 4 (cell*4+edge, weight, segment) entries -- already in the order K3's wavefront
-// segmented reduction wants.  No atomics, so the result is bitwise reproducible run to run.
+// pass 2 recomputes and writes records.  Records are then stably radix-sorted (rocPRIM) by the 64-bit key
+// (global segment id, ta quantised to 2^-40), the multiplicity is resolved per record against its
+// neighbours in that order (same segment, |dta|,|dtb| <= 1e-10), and each record is written out as
+// (cell, 4 edge weights, segment) -- already in the order K3's wavefront segmented reduction wants.
+// No atomics, so the result is bitwise reproducible run to run.
 #include <cstring>  // rocprim's texture iterator needs host memset declared first
 #include <rocprim/device/device_radix_sort.hpp>
+#include <vector>
 
 #include "nf_common.h"
 
@@ -115,9 +117,13 @@ __device__ inline double wmax(double x)
 }
 
 struct Records {  // SoA, device
-    int *seg, *cell;
+    unsigned long long *key;  // (segment << 40) | floor(ta * 2^40)
+    int *cell;
     double *ta, *tb, *w;  // w: 4 per record
 };
+constexpr int kTaBits = 40;
+constexpr unsigned long long kTaOne = 1ull << kTaBits;
+constexpr unsigned long long kTaWindow = 112;  // > kTolT * 2^40 + 1
 
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, long ncell,
@@ -189,7 +195,9 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
                     w2 = -w2;
                     w3 = -w3;
                 }
-                rec.seg[pos] = s;
+                unsigned long long q = (unsigned long long)(ta * (double)kTaOne);
+                if (q >= kTaOne) q = kTaOne - 1;
+                rec.key[pos] = ((unsigned long long)s << kTaBits) | q;
                 rec.cell[pos] = (int)c;
                 rec.ta[pos] = ta;
                 rec.tb[pos] = tb;
@@ -235,65 +243,80 @@ __global__ __launch_bounds__(kBlock) void k_iota(unsigned *p, long n)
 }
 
 // lower bound of every segment id in the sorted key list -> CSR over records
-__global__ __launch_bounds__(kBlock) void k_seg_bounds(const unsigned *__restrict__ keys, long nrec, int nseg,
-                                                       int *__restrict__ rec_start)
+__global__ __launch_bounds__(kBlock) void k_seg_bounds(const unsigned long long *__restrict__ keys, long nrec,
+                                                       int nseg, int *__restrict__ rec_start)
 {
     int s = blockIdx.x * kBlock + threadIdx.x;
     if (s > nseg) return;
     long lo = 0, hi = nrec;
     while (lo < hi) {
         long mid = (lo + hi) >> 1;
-        if (keys[mid] < (unsigned)s) lo = mid + 1;
+        if ((keys[mid] >> kTaBits) < (unsigned long long)s) lo = mid + 1;
         else hi = mid;
     }
     rec_start[s] = (int)lo;
 }
 
 // multiplicity + expansion into 4 entries per record
-__global__ __launch_bounds__(kBlock) void k_expand(const unsigned *__restrict__ keys,
+__global__ __launch_bounds__(kBlock) void k_expand(const unsigned long long *__restrict__ keys,
                                                    const unsigned *__restrict__ perm, long nrec, Records rec,
-                                                   const int *__restrict__ rec_start,
-                                                   int64_t *__restrict__ cell_edge, double *__restrict__ weight,
+                                                   int *__restrict__ cell_out, double *__restrict__ w4_out,
                                                    int *__restrict__ seg_out)
 {
     long i = (long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= nrec) return;
-    const unsigned s = keys[i];
+    const unsigned long long key = keys[i];
+    const unsigned long long s = key >> kTaBits;
     const unsigned r = perm[i];
     const double ta = rec.ta[r], tb = rec.tb[r];
-    int n = 0;
-    for (int j = rec_start[s]; j < rec_start[s + 1]; ++j) {
+    int n = 1;
+    // neighbours in (segment, ta) order: only records within the ta window can match
+    for (long j = i - 1; j >= 0 && key - keys[j] <= kTaWindow; --j) {
+        const unsigned rj = perm[j];
+        if (fabs(rec.ta[rj] - ta) <= kTolT && fabs(rec.tb[rj] - tb) <= kTolT) ++n;
+    }
+    for (long j = i + 1; j < nrec && keys[j] - key <= kTaWindow; ++j) {
         const unsigned rj = perm[j];
         if (fabs(rec.ta[rj] - ta) <= kTolT && fabs(rec.tb[rj] - tb) <= kTolT) ++n;
     }
     const double coef = 1.0 / (double)n;
-    const int64_t cell = rec.cell[r];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        cell_edge[4 * i + e] = cell * 4 + e;
-        weight[4 * i + e] = rec.w[4 * (long)r + e] * coef;
-        seg_out[4 * i + e] = (int)s;
-    }
+    const double2 *pw = reinterpret_cast<const double2 *>(rec.w + 4 * (long)r);
+    const double2 a = pw[0], b = pw[1];
+    double2 *po = reinterpret_cast<double2 *>(w4_out + 4 * i);
+    po[0] = make_double2(a.x * coef, a.y * coef);
+    po[1] = make_double2(b.x * coef, b.y * coef);
+    cell_out[i] = rec.cell[r];
+    seg_out[i] = (int)s;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scale4(const int *__restrict__ in, int n, int *__restrict__ out)
-{
-    int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k < n) out[k] = 4 * in[k];
-}
 
 void WeightSet::release()
 {
-    if (cell_edge) (void)hipFree(cell_edge);
-    if (weight) (void)hipFree(weight);
+    if (cell) (void)hipFree(cell);
+    if (w4) (void)hipFree(w4);
     if (seg) (void)hipFree(seg);
     if (seg_start) (void)hipFree(seg_start);
-    cell_edge = nullptr;
-    weight = nullptr;
+    cell = nullptr;
+    w4 = nullptr;
     seg = nullptr;
     seg_start = nullptr;
-    n = 0;
+    nrec = 0;
     nseg = 0;
+}
+
+int weights_to_host(const WeightSet &ws, int64_t *cell_edge, double *weight, int *seg)
+{
+    if (ws.nrec == 0) return NF_OK;
+    std::vector<int> c((size_t)ws.nrec), sg((size_t)ws.nrec);
+    NF_HIP(hipMemcpy(c.data(), ws.cell, sizeof(int) * ws.nrec, hipMemcpyDeviceToHost));
+    NF_HIP(hipMemcpy(sg.data(), ws.seg, sizeof(int) * ws.nrec, hipMemcpyDeviceToHost));
+    if (weight) NF_HIP(hipMemcpy(weight, ws.w4, sizeof(double) * 4 * ws.nrec, hipMemcpyDeviceToHost));
+    for (long i = 0; i < ws.nrec; ++i)  // pure re-indexing of the device result for the caller
+        for (int e = 0; e < 4; ++e) {
+            if (cell_edge) cell_edge[4 * i + e] = (int64_t)c[i] * 4 + e;
+            if (seg) seg[4 * i + e] = sg[i];
+        }
+    return NF_OK;
 }
 
 namespace {
@@ -311,7 +334,7 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     out->release();
     out->nseg = nseg;
     NF_REQUIRE(ncell > 0 && ncell < (1l << 31), NF_ERR_ARG, "weights: ncell out of range");
-    NF_REQUIRE(nseg >= 0, NF_ERR_ARG, "weights: negative segment count");
+    NF_REQUIRE(nseg >= 0 && nseg < (1 << 23), NF_ERR_ARG, "weights: segment count out of range");
     const int nshift = periodX > 0.0 ? 3 : 1;
     const long nwaves = (ncell + kWave - 1) / kWave;
     const unsigned nblocks = (unsigned)((ncell + kBlock - 1) / kBlock);
@@ -343,43 +366,46 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
         return NF_OK;
     }
 
-    DevBuf r_seg, r_cell, r_ta, r_tb, r_w, k_out, v_in, v_out, tmp, rstart;
-    NF_HIP(r_seg.alloc(sizeof(int) * nrec));
+    DevBuf r_key, r_cell, r_ta, r_tb, r_w, k_out, v_in, v_out, tmp, rstart;
+    NF_HIP(r_key.alloc(sizeof(unsigned long long) * nrec));
     NF_HIP(r_cell.alloc(sizeof(int) * nrec));
     NF_HIP(r_ta.alloc(sizeof(double) * nrec));
     NF_HIP(r_tb.alloc(sizeof(double) * nrec));
     NF_HIP(r_w.alloc(sizeof(double) * 4 * nrec));
-    Records rec{r_seg.as<int>(), r_cell.as<int>(), r_ta.as<double>(), r_tb.as<double>(), r_w.as<double>()};
+    Records rec{r_key.as<unsigned long long>(), r_cell.as<int>(), r_ta.as<double>(), r_tb.as<double>(),
+                r_w.as<double>()};
     hipLaunchKernelGGL(k_clip<true>, dim3(nblocks), dim3(kBlock), 0, s, xy, ncell, d_segs.as<double>(),
                        d_cc.as<int>(), nseg, nshift, periodX, d_off.as<int>(), (int *)nullptr, rec);
     NF_HIP(hipGetLastError());
 
     // stable sort of record indices by global segment id
-    NF_HIP(k_out.alloc(sizeof(unsigned) * nrec));
+    NF_HIP(k_out.alloc(sizeof(unsigned long long) * nrec));
     NF_HIP(v_in.alloc(sizeof(unsigned) * nrec));
     NF_HIP(v_out.alloc(sizeof(unsigned) * nrec));
     const unsigned nb_rec = (unsigned)((nrec + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_iota, dim3(nb_rec), dim3(kBlock), 0, s, v_in.as<unsigned>(), nrec);
     int bits = 1;
-    while ((1l << bits) < (long)nseg + 1 && bits < 32) ++bits;
+    while ((1l << bits) < (long)nseg + 1 && bits < 24) ++bits;
+    const unsigned end_bit = (unsigned)(kTaBits + bits);
     size_t tmp_bytes = 0;
-    NF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned *)r_seg.p, k_out.as<unsigned>(),
-                                     v_in.as<unsigned>(), v_out.as<unsigned>(), (size_t)nrec, 0u, (unsigned)bits, s));
+    NF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned long long *)r_key.p,
+                                     k_out.as<unsigned long long>(), v_in.as<unsigned>(), v_out.as<unsigned>(),
+                                     (size_t)nrec, 0u, end_bit, s));
     NF_HIP(tmp.alloc(tmp_bytes));
-    NF_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (const unsigned *)r_seg.p, k_out.as<unsigned>(),
-                                     v_in.as<unsigned>(), v_out.as<unsigned>(), (size_t)nrec, 0u, (unsigned)bits, s));
+    NF_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (const unsigned long long *)r_key.p,
+                                     k_out.as<unsigned long long>(), v_in.as<unsigned>(), v_out.as<unsigned>(),
+                                     (size_t)nrec, 0u, end_bit, s));
     NF_HIP(rstart.alloc(sizeof(int) * (size_t)(nseg + 1)));
     hipLaunchKernelGGL(k_seg_bounds, dim3((unsigned)((nseg + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       k_out.as<unsigned>(), nrec, nseg, rstart.as<int>());
+                       k_out.as<unsigned long long>(), nrec, nseg, rstart.as<int>());
 
-    out->n = 4 * nrec;
-    NF_HIP(hipMalloc((void **)&out->cell_edge, sizeof(int64_t) * (size_t)out->n));
-    NF_HIP(hipMalloc((void **)&out->weight, sizeof(double) * (size_t)out->n));
-    NF_HIP(hipMalloc((void **)&out->seg, sizeof(int) * (size_t)out->n));
-    hipLaunchKernelGGL(k_expand, dim3(nb_rec), dim3(kBlock), 0, s, k_out.as<unsigned>(), v_out.as<unsigned>(),
-                       nrec, rec, rstart.as<int>(), out->cell_edge, out->weight, out->seg);
-    hipLaunchKernelGGL(k_scale4, dim3((unsigned)((nseg + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       rstart.as<int>(), nseg + 1, out->seg_start);
+    out->nrec = nrec;
+    NF_HIP(hipMalloc((void **)&out->cell, sizeof(int) * (size_t)nrec));
+    NF_HIP(hipMalloc((void **)&out->w4, sizeof(double) * 4 * (size_t)nrec));
+    NF_HIP(hipMalloc((void **)&out->seg, sizeof(int) * (size_t)nrec));
+    hipLaunchKernelGGL(k_expand, dim3(nb_rec), dim3(kBlock), 0, s, k_out.as<unsigned long long>(),
+                       v_out.as<unsigned>(), nrec, rec, out->cell, out->w4, out->seg);
+    NF_HIP(hipMemcpyAsync(out->seg_start, rstart.p, sizeof(int) * (size_t)(nseg + 1), hipMemcpyDeviceToDevice, s));
     NF_HIP(hipGetLastError());
     NF_HIP(hipStreamSynchronize(s));
     return NF_OK;

@@ -1,0 +1,57 @@
+"""Multi-GPU layer: (t,z) slab sharding + ONE reduce of the per-segment / per-transect rows.
+
+The reference has no distributed code; this is the MI355X-native addition of SURVEY.md 8e: every
+(t,z) slab contributes additively and independently to every transect total, so the flattened slab index
+s = t*nz + z is cut into contiguous ranges, one per rank (one process per GPU); each rank integrates only its
+slabs (nf_field_set_slab_range) and the (nt, nseg+ntransect) float64 rows are summed with a single
+torch.distributed all_reduce -- RCCL over xGMI on GPUs ('nccl' backend), gloo on CPU for tests.  The message is
+<= ~0.4 MB (latency-bound), so no bucketing is needed.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def slab_range(nt, nz, rank, world):
+    """Contiguous share of the nt*nz slabs for `rank` of `world` (balanced to within one slab)."""
+    total = nt * nz
+    return (rank * total) // world, ((rank + 1) * total) // world
+
+
+def time_steps_touched(srange, nz):
+    """[t_begin, t_end) of the time steps that contain at least one owned slab."""
+    b, e = srange
+    if e <= b:
+        return 0, 0
+    return b // nz, (e - 1) // nz + 1
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun) if WORLD_SIZE > 1.
+    Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def reduce_rows(rows, group=None):
+    """Sum the per-rank partial rows in place (all ranks get the totals).  One collective."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=group)
+    return rows
+
+
+def virtual_base(tensor, first_slab, slab_elems):
+    """HBM address such that address + s*slab_bytes is slab s of the GLOBAL (nt,nz,ny,nx) array, when
+    `tensor` holds only the slabs from `first_slab` on.  The engine never dereferences slabs it does not own."""
+    return tensor.data_ptr() - first_slab * slab_elems * tensor.element_size()

@@ -22,6 +22,8 @@ EARTH_RADIUS = 6371000.0  # field.py:12
 def _dtype_code(a):
     import torch
     dt = a.dtype
+    if isinstance(dt, numpy.dtype):
+        dt = dt.type
     if dt in (numpy.float64, torch.float64):
         return NF_F64
     if dt in (numpy.float32, torch.float32):
