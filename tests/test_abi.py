@@ -1,0 +1,111 @@
+"""CPU suite, part 2: the C-ABI library loads and exports every symbol include/nemoflux_amd.h declares; the
+host-side argument checking works without a GPU; compute entry points fail loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'nemoflux_amd.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    names = re.findall(r'\b((?:nf|mnt)_[A-Za-z0-9_]+)\s*\(', txt)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    from nemoflux_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 55
+    for s in syms:
+        assert hasattr(_lib.lib, s), f'{s} declared in include/nemoflux_amd.h but not exported'
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    import subprocess
+    src = tmp_path / 't.c'
+    src.write_text('#include "nemoflux_amd.h"\nint main(void){ return NF_OK + MNT_CELL_BY_CELL_DATA; }\n')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-c', str(src),
+                           '-o', str(tmp_path / 't.o')])
+
+
+def test_no_gpu_means_loud_failure():
+    """On a box without a GPU every compute path raises; on the GPU box this test is a no-op."""
+    from nemoflux_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip('GPU present')
+    from nemoflux_amd import mint
+    from nemoflux_amd.field import Field
+    g = mint.Grid()
+    pts = numpy.zeros((4, 4, 3))
+    with pytest.raises(_lib.NemofluxError, match='no usable AMD GPU'):
+        g.setPoints(pts)
+    with pytest.raises(_lib.NemofluxError, match='no CPU fallback'):
+        Field.fromArrays(numpy.zeros((2, 2, 4)), numpy.zeros((2, 2, 4)), numpy.zeros((1, 2)), numpy.zeros((1, 1, 2, 2)),
+                         numpy.zeros((1, 1, 2, 2)), [])
+
+
+def test_argument_errors_without_gpu():
+    from nemoflux_amd import _lib, mint
+    lib = _lib.lib
+    g = mint.Grid()
+    with pytest.raises(RuntimeError):
+        g.setPoints(numpy.zeros((3, 4, 2)))                     # wrong trailing shape
+    with pytest.raises(RuntimeError):
+        g.setPoints(numpy.zeros((3, 4, 3), numpy.float32))      # wrong dtype
+    assert g.getNumberOfCells() == 0
+    pli = mint.PolylineIntegral()
+    with pytest.raises(_lib.NemofluxError, match='setGrid first'):
+        pli.buildLocator()
+    h = ctypes.c_void_p()
+    assert lib.nf_field_new(ctypes.byref(h)) == 0
+    assert lib.nf_field_set_slab_range(ctypes.byref(h), 5, 2) != 0
+    assert b'begin <= end' in lib.nf_last_error()
+    assert lib.nf_field_set_sverdrup(ctypes.byref(h), 1) == 0
+    n = ctypes.c_int(-1)
+    assert lib.nf_field_num_transects(ctypes.byref(h), ctypes.byref(n)) == 0 and n.value == 0
+    xyz = numpy.zeros((1, 3))
+    assert lib.nf_field_add_transect(ctypes.byref(h), _lib.dptr(xyz), 1, 0, None) != 0   # needs >= 2 points
+    assert lib.nf_field_del(ctypes.byref(h)) == 0 and not h.value
+    assert lib.nf_version() == 100
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, 'nemoflux_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h', '.cpp')) or fn == 'Makefile':
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert 'nf_oracle' not in txt.replace('oracle/nf_oracle.c)', ''), fn
+                assert 'import oracle' not in txt and 'from oracle' not in txt, fn
+
+
+def test_stream_function_menu_and_fluxexact():
+    from nemoflux_amd.datagen import STREAM_FUNCTIONS, streamFunctionId
+    from nemoflux_amd.fluxexact import exactFlux
+    assert streamFunctionId('x') == 0
+    assert streamFunctionId('arctan2(y,x+180)/(2*pi)') == 1
+    assert streamFunctionId(' cos(2*pi*y/360)+sin(2*pi*x/360) ') == 2
+    with pytest.raises(RuntimeError):
+        streamFunctionId('x**2')
+    assert exactFlux('x', [(-180, -70), (180, 40)], 1, 1) == [360.0]
+    assert abs(exactFlux(STREAM_FUNCTIONS[1], [(-180, -80), (-180, 80)], 1, 1)[0] - 0.5) < 1e-15
+
+
+def test_get_sizes_and_flux_text_format():
+    """field.py:122-136 shape fallbacks and field.py:103-108 text format, on the host logic alone."""
+    import re as _re
+    from nemoflux_amd.field import Field
+    f = Field.__new__(Field)
+    assert f.getSizes((20, 10, 180, 360)) == (20, 10, 180, 360)
+    assert f.getSizes((10, 180, 360)) == (1, 10, 180, 360)
+    assert f.getSizes((180, 360)) == (1, 1, 180, 360)
+    with pytest.raises(RuntimeError):
+        f.getSizes((1, 2, 3, 4, 5))
+    txt = ''.join(f"{v:4.3g}, " for v in (360.0, -0.318)) + "(Sv) "
+    assert _re.sub(r',\s*\(', ' (', txt) == ' 360, -0.318 (Sv) '
