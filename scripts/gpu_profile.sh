@@ -1,0 +1,14 @@
+# Round-1 profile of the headline bench: kernel trace + stats, then HBM traffic counters in two separate PMC passes
+# (MI355X_MICROARCH.md: FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2 -- they do not fit one pass).
+set -e
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+R=${1:-r01}
+mkdir -p gpurun_out/$R
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/$R/bench_trace.json 2> gpurun_out/$R/bench_trace.err
+echo "trace done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu > gpurun_out/$R/bench_fetch.json 2> gpurun_out/$R/bench_fetch.err
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu > gpurun_out/$R/bench_write.json 2> gpurun_out/$R/bench_write.err
+echo "write done"
+python3 scripts/summarize_profile.py gpurun_out/$R $R
