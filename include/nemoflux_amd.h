@@ -60,6 +60,9 @@ int nf_memcpy_h2d(void *dev, const void *host, size_t bytes);
 int nf_memcpy_d2h(void *host, const void *dev, size_t bytes);
 int nf_memset(void *dev, int value, size_t bytes);
 int nf_synchronize(void);
+/* tuning knobs for A/B measurements inside one process: "flux_variant" (0 = default; see nf_flux.hip),
+ * "xcd_map" (1 = on), "ww_blocks_per_cu" */
+int nf_tuning_set(const char *name, int value);
 
 /* ------------------------------------------------------------------ Level 1: mint-shaped API */
 typedef struct Grid_t Grid_t;

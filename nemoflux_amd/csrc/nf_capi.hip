@@ -131,6 +131,13 @@ int nf_memset(void *dev, int value, size_t bytes)
     NF_HIP(hipMemset(dev, value, bytes));
     return NF_OK;
 }
+int nf_tuning_set(const char *name, int value)
+{
+    NF_REQUIRE(name, NF_ERR_ARG, "nf_tuning_set: null name");
+    int rc = tuning_set(name, value);
+    NF_REQUIRE(rc == NF_OK, NF_ERR_ARG, std::string("nf_tuning_set: unknown knob ") + name);
+    return NF_OK;
+}
 int nf_synchronize(void)
 {
     NF_NEED_DEVICE();

@@ -65,6 +65,7 @@ struct FluxArgs {
     unsigned long long *maxbits;  // running max as the bits of a non-negative double
 };
 int launch_flux(const FluxArgs &a, hipStream_t s);
+int tuning_set(const char *name, int value);
 int launch_planes_to_aos(const double *planes, long ncell, double *aos, hipStream_t s);
 
 // K2: batched polyline weights.

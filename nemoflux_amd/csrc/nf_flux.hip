@@ -21,6 +21,8 @@
 // nf_field_read_step() re-packs the planes into the reference's (ncell,4) layout on demand.
 //
 // Algorithmic bytes per (t,z,j,i) unit: 2*sizeof(T) read + (16 arc + 32 iV + 16 abs)/nz  (SURVEY 8d).
+#include <cstring>
+
 #include "nf_common.h"
 
 namespace nf {
@@ -64,126 +66,339 @@ __device__ inline void store2(double *p, double a, double b, bool aligned)
     }
 }
 
-template <typename T, int VEC, int UZ, bool NT>
-__global__ __launch_bounds__(kBlock) void k_flux(const T *__restrict__ u, const T *__restrict__ v, long ncell,
-                                                 unsigned ny, unsigned nx, int z0, int z1,
-                                                 const double *__restrict__ thickness,
-                                                 const double *__restrict__ arcE,
-                                                 const double *__restrict__ arcN, T fill, double scale,
-                                                 int sverdrup, double *__restrict__ iV,
-                                                 double *__restrict__ absUV, unsigned long long *maxbits,
-                                                 unsigned ntiles, int xcd_map)
+// stores of one lane's VEC consecutive cells starting at c0 (see the layout comment at the top)
+template <int VEC>
+__device__ inline void store_cells(long c0, const double *eU, const double *eV, long ncell, unsigned ny, unsigned nx,
+                                   double *__restrict__ iV, double *__restrict__ absUV)
+{
+    double *p0 = iV, *p1 = iV + ncell, *p2 = iV + 2 * ncell, *p3 = iV + 3 * ncell;
+    double *aU = absUV, *aV = absUV + ncell;
+    const unsigned j0 = (unsigned)(c0 / nx);
+    const unsigned i0 = (unsigned)(c0 - (long)j0 * nx);
+    if (VEC == 1) {
+        p1[c0] = eU[0];
+        p2[c0] = eV[0];
+        aU[c0] = fabs(eU[0]);
+        aV[c0] = fabs(eV[0]);
+        if (j0 + 1 < ny) p0[c0 + nx] = eV[0];
+        p3[(i0 + 1 < nx) ? c0 + 1 : c0 + 1 - nx] = eU[0];
+    } else {
+        // own slots and |.|: dense 16 B/lane stores (c0 is a multiple of VEC)
+#pragma unroll
+        for (int k = 0; k < VEC; k += 2) {
+            store2(p1 + c0 + k, eU[k], eU[k + 1], true);
+            store2(p2 + c0 + k, eV[k], eV[k + 1], true);
+            store2(aU + c0 + k, fabs(eU[k]), fabs(eU[k + 1]), true);
+            store2(aV + c0 + k, fabs(eV[k]), fabs(eV[k + 1]), true);
+        }
+        if (i0 + VEC <= nx) {
+            // lane's cells sit in one row: south slots of the row above = the same stream shifted by nx
+            if (j0 + 1 < ny) {
+                const bool al = (nx & 1u) == 0;
+#pragma unroll
+                for (int k = 0; k < VEC; k += 2) store2(p0 + c0 + nx + k, eV[k], eV[k + 1], al);
+            }
+            // west slots of the cells to the right: shifted by one (8 B stores; the row's last cell wraps to
+            // column 0, field.py:223)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) p3[(i0 + k + 1 < nx) ? c0 + k + 1 : c0 + k + 1 - nx] = eU[k];
+        } else {
+            // lane straddles a row end (nx % VEC != 0): per-cell bookkeeping
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const long c = c0 + k;
+                const unsigned j = (unsigned)(c / nx);
+                const unsigned i = (unsigned)(c - (long)j * nx);
+                if (j + 1 < ny) p0[c + nx] = eV[k];
+                p3[(i + 1 < nx) ? c + 1 : c + 1 - nx] = eU[k];
+            }
+        }
+    }
+}
+
+// BLOCK threads; every lane owns CH chunks of VEC cells, chunk q at tile_base + q*BLOCK*VEC + tid*VEC, so the
+// workgroup reads CH x (BLOCK x 16 B) contiguous bytes per (z, field).  SYNC keeps the workgroup's waves in
+// z-lockstep (one barrier per UZ levels) so that those contiguous pieces are requested close in time.
+template <typename T, int VEC, int UZ, bool NT, int BLOCK, int CH, bool SYNC, int DIAG = 0>
+__global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T *__restrict__ v, long ncell,
+                                                unsigned ny, unsigned nx, int z0, int z1,
+                                                const double *__restrict__ thickness,
+                                                const double *__restrict__ arcE, const double *__restrict__ arcN,
+                                                T fill, double scale, int sverdrup, double *__restrict__ iV,
+                                                double *__restrict__ absUV, unsigned long long *maxbits,
+                                                unsigned ntiles, int xcd_map)
 {
     const unsigned tile = xcd_map ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
     double tmax = 0.0;
-    if (tile < ntiles) {
-        const long c0 = ((long)tile * kBlock + threadIdx.x) * VEC;
-        if (c0 < ncell) {  // ncell % VEC == 0 is guaranteed by the launcher, so the lane is full
-            double accU[VEC], accV[VEC];
+    if (tile < ntiles) {  // workgroup-uniform
+        const long base = (long)tile * BLOCK * VEC * CH + (long)threadIdx.x * VEC;
+        constexpr long kChunk = (long)BLOCK * VEC;
+        // ncell % VEC == 0 is guaranteed by the launcher, so a chunk is either full or absent
+        bool on[CH];
+        double accU[CH][VEC], accV[CH][VEC];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) accU[k] = accV[k] = 0.0;
-            const T *pu = u + (long)z0 * ncell + c0;
-            const T *pv = v + (long)z0 * ncell + c0;
-            int z = z0;
-            for (; z + UZ <= z1; z += UZ) {
-                Lanes<T, VEC> lu[UZ], lv[UZ];
+        for (int q = 0; q < CH; ++q) {
+            on[q] = base + q * kChunk < ncell;
 #pragma unroll
-                for (int q = 0; q < UZ; ++q) {
-                    lu[q] = load_cells<T, VEC, NT>(pu + (long)q * ncell);
-                    lv[q] = load_cells<T, VEC, NT>(pv + (long)q * ncell);
-                }
+            for (int k = 0; k < VEC; ++k) accU[q][k] = accV[q][k] = 0.0;
+        }
+        const T *pu = u + (long)z0 * ncell + base;
+        const T *pv = v + (long)z0 * ncell + base;
+        int z = z0;
+        for (; z + UZ <= z1; z += UZ) {
+            Lanes<T, VEC> lu[UZ][CH], lv[UZ][CH];
 #pragma unroll
-                for (int q = 0; q < UZ; ++q) {
-                    const double th = thickness[z + q];
+            for (int r = 0; r < UZ; ++r)
+#pragma unroll
+                for (int q = 0; q < CH; ++q)
+                    if (on[q]) {
+                        lu[r][q] = load_cells<T, VEC, NT>(pu + (long)r * ncell + q * kChunk);
+                        lv[r][q] = load_cells<T, VEC, NT>(pv + (long)r * ncell + q * kChunk);
+                    }
+#pragma unroll
+            for (int r = 0; r < UZ; ++r) {
+                const double th = thickness[z + r];
+#pragma unroll
+                for (int q = 0; q < CH; ++q)
+                    if (on[q]) {
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) {
+                            accU[q][k] = fma(th, (DIAG & 2) ? (double)lu[r][q].x[k] : fixed<T>(lu[r][q].x[k], fill), accU[q][k]);
+                            accV[q][k] = fma(th, (DIAG & 2) ? (double)lv[r][q].x[k] : fixed<T>(lv[r][q].x[k], fill), accV[q][k]);
+                        }
+                    }
+            }
+            pu += (long)UZ * ncell;
+            pv += (long)UZ * ncell;
+            if (SYNC) __syncthreads();
+        }
+        for (; z < z1; ++z) {
+            const double th = thickness[z];
+#pragma unroll
+            for (int q = 0; q < CH; ++q)
+                if (on[q]) {
+                    Lanes<T, VEC> lu = load_cells<T, VEC, NT>(pu + q * kChunk);
+                    Lanes<T, VEC> lv = load_cells<T, VEC, NT>(pv + q * kChunk);
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
-                        accU[k] = fma(th, fixed<T>(lu[q].x[k], fill), accU[k]);
-                        accV[k] = fma(th, fixed<T>(lv[q].x[k], fill), accV[k]);
+                        accU[q][k] = fma(th, fixed<T>(lu.x[k], fill), accU[q][k]);
+                        accV[q][k] = fma(th, fixed<T>(lv.x[k], fill), accV[q][k]);
                     }
                 }
-                pu += (long)UZ * ncell;
-                pv += (long)UZ * ncell;
-            }
-            for (; z < z1; ++z) {
-                Lanes<T, VEC> lu = load_cells<T, VEC, NT>(pu);
-                Lanes<T, VEC> lv = load_cells<T, VEC, NT>(pv);
-                const double th = thickness[z];
+            pu += ncell;
+            pv += ncell;
+        }
+        // edge fluxes (field.py:195-196, 225-228)
+#pragma unroll
+        for (int q = 0; q < CH; ++q)
+            if (on[q]) {
+                const long c0 = base + q * kChunk;
+                double eU[VEC], eV[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    accU[k] = fma(th, fixed<T>(lu.x[k], fill), accU[k]);
-                    accV[k] = fma(th, fixed<T>(lv.x[k], fill), accV[k]);
-                }
-                pu += ncell;
-                pv += ncell;
-            }
-            // edge fluxes (field.py:195-196, 225-228)
-            double eU[VEC], eV[VEC];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                eU[k] = +accU[k] * arcE[c0 + k];
-                eV[k] = -accV[k] * arcN[c0 + k];
-                if (sverdrup) {
-                    eU[k] *= scale;
-                    eV[k] *= scale;
-                }
-                tmax = fmax(tmax, fmax(fabs(eU[k]), fabs(eV[k])));
-            }
-            double *p0 = iV, *p1 = iV + ncell, *p2 = iV + 2 * ncell, *p3 = iV + 3 * ncell;
-            double *aU = absUV, *aV = absUV + ncell;
-            const unsigned j0 = (unsigned)(c0 / nx);
-            const unsigned i0 = (unsigned)(c0 - (long)j0 * nx);
-            if (VEC == 1) {
-                p1[c0] = eU[0];
-                p2[c0] = eV[0];
-                aU[c0] = fabs(eU[0]);
-                aV[c0] = fabs(eV[0]);
-                if (j0 + 1 < ny) p0[c0 + nx] = eV[0];
-                p3[(i0 + 1 < nx) ? c0 + 1 : c0 + 1 - nx] = eU[0];
-            } else {
-                // own slots and |.|: dense 16 B/lane stores (c0 is a multiple of VEC)
-#pragma unroll
-                for (int k = 0; k < VEC; k += 2) {
-                    store2(p1 + c0 + k, eU[k], eU[k + 1], true);
-                    store2(p2 + c0 + k, eV[k], eV[k + 1], true);
-                    store2(aU + c0 + k, fabs(eU[k]), fabs(eU[k + 1]), true);
-                    store2(aV + c0 + k, fabs(eV[k]), fabs(eV[k + 1]), true);
-                }
-                if (i0 + VEC <= nx) {
-                    // lane's cells sit in one row: south slots of the row above = the same stream shifted by nx
-                    if (j0 + 1 < ny) {
-                        const bool al = (nx & 1u) == 0;
-#pragma unroll
-                        for (int k = 0; k < VEC; k += 2) store2(p0 + c0 + nx + k, eV[k], eV[k + 1], al);
+                    eU[k] = +accU[q][k] * ((DIAG & 8) ? 1.5 : arcE[c0 + k]);
+                    eV[k] = -accV[q][k] * ((DIAG & 8) ? 1.5 : arcN[c0 + k]);
+                    if (sverdrup) {
+                        eU[k] *= scale;
+                        eV[k] *= scale;
                     }
-                    // west slots of the cells to the right: shifted by one (8 B stores; the row's last cell
-                    // wraps to column 0, field.py:223)
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) p3[(i0 + k + 1 < nx) ? c0 + k + 1 : c0 + k + 1 - nx] = eU[k];
-                } else {
-                    // lane straddles a row end (nx % VEC != 0): per-cell bookkeeping
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        const long c = c0 + k;
-                        const unsigned j = (unsigned)(c / nx);
-                        const unsigned i = (unsigned)(c - (long)j * nx);
-                        if (j + 1 < ny) p0[c + nx] = eV[k];
-                        p3[(i + 1 < nx) ? c + 1 : c + 1 - nx] = eU[k];
-                    }
+                    tmax = fmax(tmax, fmax(fabs(eU[k]), fabs(eV[k])));
                 }
+                if (DIAG & 16) {  // only the two signed planes (the rest comes from k_expand_planes)
+#pragma unroll
+                    for (int k = 0; k < VEC; k += 2) {
+                        store2(iV + ncell + c0 + k, eU[k], eU[k + 1], true);
+                        store2(iV + 2 * ncell + c0 + k, eV[k], eV[k + 1], true);
+                    }
+                } else if (!(DIAG & 1)) store_cells<VEC>(c0, eU, eV, ncell, ny, nx, iV, absUV);
             }
-        }
     }
     // running max (field.py:234): wavefront butterfly, then one atomic per workgroup.  All values are
     // non-negative doubles, whose bit patterns order like unsigned integers.
     for (int o = 32; o > 0; o >>= 1) tmax = fmax(tmax, __shfl_xor(tmax, o, kWave));
-    __shared__ double s_max[kBlock / kWave];
+    __shared__ double s_max[BLOCK / kWave];
     if ((threadIdx.x & (kWave - 1)) == 0) s_max[threadIdx.x / kWave] = tmax;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double m = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
-        if (m > 0.0) {
+        double m = s_max[0];
+#pragma unroll
+        for (int w = 1; w < BLOCK / kWave; ++w) m = fmax(m, s_max[w]);
+        if (m > 0.0 && !(DIAG & 4)) {
             unsigned long long b;
             __builtin_memcpy(&b, &m, 8);
+            atomicMax(maxbits, b);
+        }
+    }
+}
+
+// ---- two-buffer load pipeline helpers (used by the writer-wave variant) ------------------------------------
+template <typename T, int VEC, int UZ> struct Batch {
+    Lanes<T, VEC> u[UZ], v[UZ];
+};
+
+// always UZ x 2 loads: levels past z1 re-read the last level and are ignored by consume_batch.  A FIXED number of
+// memory instructions per step lets the compiler place exact vmcnt(N) waits instead of draining the queue.
+template <typename T, int VEC, int UZ>
+__device__ inline void load_batch(Batch<T, VEC, UZ> &B, const T *__restrict__ u, const T *__restrict__ v, long ncell,
+                                  long c0, int zb, int z1)
+{
+#pragma unroll
+    for (int r = 0; r < UZ; ++r) {
+        const int zz = (zb + r < z1) ? zb + r : z1 - 1;  // wave-uniform clamp
+        B.u[r] = load_cells<T, VEC, true>(u + (long)zz * ncell + c0);
+        B.v[r] = load_cells<T, VEC, true>(v + (long)zz * ncell + c0);
+    }
+}
+
+template <typename T, int VEC, int UZ>
+__device__ inline void consume_batch(const Batch<T, VEC, UZ> &B, const double *__restrict__ thickness, int zb, int z1,
+                                     T fill, double *accU, double *accV)
+{
+#pragma unroll
+    for (int r = 0; r < UZ; ++r)
+        if (zb + r < z1) {  // wave-uniform, no memory instruction inside
+            const double th = thickness[zb + r];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                accU[k] = fma(th, fixed<T>(B.u[r].x[k], fill), accU[k]);
+                accV[k] = fma(th, fixed<T>(B.v[r].x[k], fill), accV[k]);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Writer-wave form of K1.  On CDNA the vector-memory counter (vmcnt) is ONE in-order counter for loads and
+// stores, and under a saturated read stream a store's acknowledgement takes 2-4 load round trips: a wave that
+// stores and then waits for its next loads (or exits) idles for tens of microseconds (measured: +0.10..0.23 ms
+// per launch even when the stores never reach HBM).  So the roles are split inside a 5-wave workgroup:
+//   waves 0..3  compute: a pure, exactly counted two-buffer LOAD pipeline over their tiles (u, v levels and, one step
+//               before a tile ends, its arc lengths); at the end of a tile they leave eU, eV in LDS;
+//   wave 4      writer: after the workgroup barrier it reads the 4 x 64 results from LDS and issues all stores
+//               (4-slot planes, |.| planes) and keeps the running max; it never waits on a load, so its store
+//               queue drains in the background while the compute waves are already deep in the next tile.
+// The barrier is a bare s_barrier after lgkmcnt(0): it does not drain the compute waves' prefetched loads.
+// LDS is double buffered (slot = tile & 1); one barrier per tile orders both hand-off and slot reuse.
+constexpr int kCompWaves = 4;
+constexpr int kWwBlock = (kCompWaves + 1) * kWave;  // 320 threads
+
+__device__ inline void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename T, int VEC, int UZ, int DIAG = 0>
+__global__ __launch_bounds__(kWwBlock) void k_flux_ww(const T *__restrict__ u, const T *__restrict__ v, long ncell,
+                                                      unsigned ny, unsigned nx, int z0, int z1,
+                                                      const double *__restrict__ thickness,
+                                                      const double *__restrict__ arcE,
+                                                      const double *__restrict__ arcN, T fill, double scale,
+                                                      int sverdrup, double *__restrict__ iV,
+                                                      double *__restrict__ absUV, unsigned long long *maxbits)
+{
+    __shared__ double s_res[2][kCompWaves][2][VEC][kWave];  // [slot][wave][U|V][k][lane]: conflict-free columns
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    // workgroup id: XCD x (= blockIdx % 8) owns a contiguous band of workgroup ids
+    const long G = gridDim.x;
+    const long wg = (long)(blockIdx.x % kXcds) * (G / kXcds) + blockIdx.x / kXcds;
+    const long nchunk = ncell / VEC;                                  // 16-B chunks
+    constexpr long kWgChunks = (long)kCompWaves * kWave;             // chunks per workgroup tile
+    const long T_all = (nchunk + kWgChunks - 1) / kWgChunks;         // workgroup tiles, dealt round-robin
+    const long ntile = wg < T_all ? (T_all - wg + G - 1) / G : 0;    // uniform over the workgroup
+    if (wave < kCompWaves) {
+        // ------------------------------------------------------------------ compute waves
+        int nb = (z1 - z0 + UZ - 1) / UZ;  // batches per tile, padded to an even number >= 2
+        nb += nb & 1;
+        if (nb < 2) nb = 2;
+        const int npair = nb / 2;
+        auto cell_of = [&](long t) -> long {  // lanes past the end shadow the last chunk (duplicate loads)
+            long ch = (t * G + wg) * kWgChunks + (long)wave * kWave + lane;
+            if (ch > nchunk - 1) ch = nchunk - 1;
+            return ch * VEC;
+        };
+        if (ntile > 0) {
+            Batch<T, VEC, UZ> A, B;
+            double accU[VEC], accV[VEC], aE[VEC], aN[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) accU[k] = accV[k] = 0.0;
+            long c0 = cell_of(0);
+            load_batch<T, VEC, UZ>(A, u, v, ncell, c0, z0, z1);
+            for (long tile = 0; tile < ntile; ++tile) {
+                int zb = z0;
+#pragma unroll 1
+                for (int p = 0; p + 1 < npair; ++p) {
+                    load_batch<T, VEC, UZ>(B, u, v, ncell, c0, zb + UZ, z1);
+                    consume_batch<T, VEC, UZ>(A, thickness, zb, z1, fill, accU, accV);
+                    zb += UZ;
+                    load_batch<T, VEC, UZ>(A, u, v, ncell, c0, zb + UZ, z1);
+                    consume_batch<T, VEC, UZ>(B, thickness, zb, z1, fill, accU, accV);
+                    zb += UZ;
+                }
+                // last pair: the tile's arc lengths ride one step ahead of the next tile's first batch
+                load_batch<T, VEC, UZ>(B, u, v, ncell, c0, zb + UZ, z1);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    aE[k] = arcE[c0 + k];
+                    aN[k] = arcN[c0 + k];
+                }
+                consume_batch<T, VEC, UZ>(A, thickness, zb, z1, fill, accU, accV);
+                zb += UZ;
+                const long cn = cell_of(tile + 1 < ntile ? tile + 1 : tile);  // after the last tile: dropped
+                load_batch<T, VEC, UZ>(A, u, v, ncell, cn, z0, z1);
+                consume_batch<T, VEC, UZ>(B, thickness, zb, z1, fill, accU, accV);
+                // edge fluxes (field.py:195-196, 225-228) -> LDS
+                const int slot = (int)(tile & 1);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    double eU = +accU[k] * aE[k];
+                    double eV = -accV[k] * aN[k];
+                    if (sverdrup) {
+                        eU *= scale;
+                        eV *= scale;
+                    }
+                    s_res[slot][wave][0][k][lane] = eU;
+                    s_res[slot][wave][1][k][lane] = eV;
+                    accU[k] = accV[k] = 0.0;
+                }
+                c0 = cn;
+                lds_barrier();
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ writer wave
+        double tmax = 0.0;
+        for (long tile = 0; tile < ntile; ++tile) {
+            lds_barrier();
+            const int slot = (int)(tile & 1);
+#pragma unroll 1
+            for (int w = 0; w < kCompWaves; ++w) {
+                const long ch = (tile * G + wg) * kWgChunks + (long)w * kWave + lane;
+                double eU[VEC], eV[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    eU[k] = s_res[slot][w][0][k][lane];
+                    eV[k] = s_res[slot][w][1][k][lane];
+                }
+                if (ch < nchunk) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) tmax = fmax(tmax, fmax(fabs(eU[k]), fabs(eV[k])));
+                    if (DIAG == 0) {
+                        store_cells<VEC>(ch * VEC, eU, eV, ncell, ny, nx, iV, absUV);
+                    } else if (DIAG == 1) {  // diagnostic: only the two signed planes
+#pragma unroll
+                        for (int k = 0; k < VEC; k += 2) {
+                            store2(iV + ncell + ch * VEC + k, eU[k], eU[k + 1], true);
+                            store2(iV + 2 * ncell + ch * VEC + k, eV[k], eV[k + 1], true);
+                        }
+                    }
+                }
+            }
+        }
+        // running max (field.py:234): one atomic per workgroup, after all of its tiles
+        for (int o = 32; o > 0; o >>= 1) tmax = fmax(tmax, __shfl_xor(tmax, o, kWave));
+        if (lane == 0 && tmax > 0.0) {
+            unsigned long long b;
+            __builtin_memcpy(&b, &tmax, 8);
             atomicMax(maxbits, b);
         }
     }
@@ -194,37 +409,76 @@ static int env_int(const char *name, int dflt)
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+// tuning knobs: environment at first use, nf_tuning_set() at run time (A/B runs inside one process)
+static int g_pipe_waves = env_int("NF_WW_BLOCKS_PER_CU", 0);  // writer-wave form: 0 = from the occupancy query
+static int g_xcd_map = env_int("NF_XCD_MAP", 1);
+static int g_variant = env_int("NF_FLUX_VARIANT", 0);
+int tuning_set(const char *name, int value)
+{
+    if (!strcmp(name, "xcd_map")) g_xcd_map = value;
+    else if (!strcmp(name, "flux_variant")) g_variant = value;
+    else if (!strcmp(name, "ww_blocks_per_cu")) g_pipe_waves = value;
+    else return NF_ERR_ARG;
+    return NF_OK;
+}
 
-template <typename T, int VEC, int UZ, bool NT>
+template <typename T, int VEC, int UZ, bool NT, int BLOCK, int CH, bool SYNC, int DIAG = 0>
 static int launch_flux_t(const FluxArgs &a, hipStream_t s)
 {
-    const long per_tile = (long)kBlock * VEC;
+    const long per_tile = (long)BLOCK * VEC * CH;
     const unsigned ntiles = (unsigned)((a.ncell + per_tile - 1) / per_tile);
-    static const int xcd_map = env_int("NF_XCD_MAP", 1);
+    const int xcd_map = g_xcd_map;
     const unsigned grid = xcd_map ? xcd_grid(ntiles) : ntiles;
-    hipLaunchKernelGGL((k_flux<T, VEC, UZ, NT>), dim3(grid), dim3(kBlock), 0, s, (const T *)a.u, (const T *)a.v,
-                       a.ncell, (unsigned)a.ny, (unsigned)a.nx, a.z0, a.z1, a.thickness, a.arcE, a.arcN,
-                       (T)a.fill, a.scale, a.sverdrup, a.iV, a.absU, a.maxbits, ntiles, xcd_map);
+    hipLaunchKernelGGL((k_flux<T, VEC, UZ, NT, BLOCK, CH, SYNC, DIAG>), dim3(grid), dim3(BLOCK), 0, s, (const T *)a.u,
+                       (const T *)a.v, a.ncell, (unsigned)a.ny, (unsigned)a.nx, a.z0, a.z1, a.thickness, a.arcE,
+                       a.arcN, (T)a.fill, a.scale, a.sverdrup, a.iV, a.absU, a.maxbits, ntiles, xcd_map);
     NF_HIP(hipGetLastError());
     return NF_OK;
 }
 
+template <typename T, int VEC, int UZ, int DIAG = 0>
+static int launch_flux_ww(const FluxArgs &a, hipStream_t s)
+{
+    static int blocks = 0, blocks_for = -1;  // per instantiation: resident workgroups on the chip, a multiple of 8
+    if (!blocks || blocks_for != g_pipe_waves) {
+        blocks_for = g_pipe_waves;
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        NF_HIP(hipGetDevice(&dev));
+        NF_HIP(hipGetDeviceProperties(&prop, dev));
+        NF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_flux_ww<T, VEC, UZ, DIAG>, kWwBlock, 0));
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 4) per_cu = 4;  // every workgroup must be resident at once (bare barriers, static split)
+        if (g_pipe_waves > 0) per_cu = g_pipe_waves;
+        blocks = ((prop.multiProcessorCount * per_cu) / kXcds) * kXcds;
+        if (blocks < kXcds) blocks = kXcds;
+    }
+    hipLaunchKernelGGL((k_flux_ww<T, VEC, UZ, DIAG>), dim3((unsigned)blocks), dim3(kWwBlock), 0, s, (const T *)a.u,
+                       (const T *)a.v, a.ncell, (unsigned)a.ny, (unsigned)a.nx, a.z0, a.z1, a.thickness, a.arcE, a.arcN,
+                       (T)a.fill, a.scale, a.sverdrup, a.iV, a.absU, a.maxbits);
+    NF_HIP(hipGetLastError());
+    return NF_OK;
+}
+
+// Tuning variants of the vector path (NF_FLUX_VARIANT); 0 is the default.
 template <typename T, int VEC>
 static int launch_flux_v(const FluxArgs &a, hipStream_t s)
 {
-    static const int uz = env_int("NF_FLUX_UZ", 4);
-    static const int nt = env_int("NF_FLUX_NT", 1);
-    if (VEC == 1) return launch_flux_t<T, VEC, 4, false>(a, s);
-    if (nt) {
-        if (uz == 8) return launch_flux_t<T, VEC, 8, true>(a, s);
-        if (uz == 4) return launch_flux_t<T, VEC, 4, true>(a, s);
-        if (uz == 3) return launch_flux_t<T, VEC, 3, true>(a, s);
-        return launch_flux_t<T, VEC, 5, true>(a, s);
+    const int variant = g_variant;
+    if (VEC == 1) return launch_flux_t<T, VEC, 4, false, 256, 1, false>(a, s);
+    switch (variant) {
+        // measured alternatives (tools/ab_flux.py): all within +-3 % of the default
+        case 4: return launch_flux_t<T, VEC, 4, true, 256, 2, false>(a, s);   // 2 chunks per lane
+        case 11: return launch_flux_t<T, VEC, 4, false, 256, 1, false>(a, s);  // plain (temporal) loads: -4 %
+        case 12: return launch_flux_t<T, VEC, 8, true, 256, 1, false>(a, s);   // 8 levels in flight
+        case 40: return launch_flux_ww<T, VEC, 2>(a, s);                       // writer-wave form
+        // diagnostic builds (WRONG RESULTS on purpose) that price one ingredient each
+        case 21: return launch_flux_t<T, VEC, 4, true, 256, 1, false, 1>(a, s);   // no stores
+        case 25: return launch_flux_t<T, VEC, 4, true, 256, 1, false, 5>(a, s);   // no stores, no atomic max
+        case 28: return launch_flux_t<T, VEC, 4, true, 256, 1, false, 16>(a, s);  // only the two signed planes
+        case 45: return launch_flux_ww<T, VEC, 2, 2>(a, s);                        // writer-wave, no stores
+        default: return launch_flux_t<T, VEC, 4, true, 256, 1, false>(a, s);
     }
-    if (uz == 8) return launch_flux_t<T, VEC, 8, false>(a, s);
-    if (uz == 4) return launch_flux_t<T, VEC, 4, false>(a, s);
-    if (uz == 3) return launch_flux_t<T, VEC, 3, false>(a, s);
-    return launch_flux_t<T, VEC, 5, false>(a, s);
 }
 
 int launch_flux(const FluxArgs &a, hipStream_t s)

@@ -342,3 +342,32 @@ def test_error_behaviour_matches_reference():
         f.computeFlux(5)
     with pytest.raises(NemofluxError):
         quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], g['u'], g['v'], [numpy.zeros((1, 3))])
+
+
+@pytest.mark.parametrize('variant', [4, 11, 12, 40])
+def test_flux_kernel_variants_bit_identical(variant):
+    """The tuning variants of K1 (2 chunks per lane, temporal loads, 8 levels in flight, writer-wave form) must
+    produce the same bits as the default kernel: they only reorder memory traffic, never arithmetic."""
+    import ctypes
+    from nemoflux_amd._lib import lib, check
+    dg = device_case(360, 180, 11, 2, PSI_ZT, (20., 30.))
+    tr = [transect_xyz(T_TRI)]
+    args = (dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, tr)
+    ref = quiet_field(*args)
+    try:
+        check(lib.nf_tuning_set(b'flux_variant', variant))
+        alt = quiet_field(*args)
+        for t in range(2):
+            check(lib.nf_tuning_set(b'flux_variant', 0))
+            a = ref.computeFlux(t, readback=True)
+            check(lib.nf_tuning_set(b'flux_variant', variant))
+            b = alt.computeFlux(t, readback=True)
+            assert a == b
+            assert numpy.array_equal(ref.integratedVelocity, alt.integratedVelocity)
+            assert numpy.array_equal(ref.edgeFluxesUArray, alt.edgeFluxesUArray)
+            assert numpy.array_equal(ref.edgeFluxesVArray, alt.edgeFluxesVArray)
+            assert ref.maxAbsFlux == alt.maxAbsFlux
+    finally:
+        check(lib.nf_tuning_set(b'flux_variant', 0))
+    with pytest.raises(RuntimeError):
+        check(lib.nf_tuning_set(b'no_such_knob', 1))

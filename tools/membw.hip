@@ -1,0 +1,206 @@
+// membw.hip -- HBM read-bandwidth probes used to place k_flux against what the chip delivers (tuning aid, not product).
+//   seq : every workgroup streams a contiguous span (persistent grid-stride over 4 KiB tiles), 16 B/lane, nt loads
+//   slab: the k_flux access pattern (a wave reads 1 KiB from each of NS slabs at the same offset), no stores
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+__global__ void k_fill(unsigned long long *p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned long long x = i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+        x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32;
+        p[i] = (x & 0x800FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;   // +-[1,2)
+    }
+}
+
+template <bool NT, int U>
+__global__ __launch_bounds__(256) void k_seq(const dvec2 *__restrict__ p, size_t n16, double *out)
+{
+    double acc = 0;
+    size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        dvec2 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = NT ? __builtin_nontemporal_load(p + i + k * stride) : p[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < U; ++k) acc += v[k].x + v[k].y;
+    }
+    if (acc == 1.2345e300) out[0] = acc;
+}
+
+// tile-contiguous: block b reads tiles b, b+grid, ... each tile = U*4KiB contiguous
+template <bool NT, int U>
+__global__ __launch_bounds__(256) void k_tile(const dvec2 *__restrict__ p, size_t n16, double *out)
+{
+    double acc = 0;
+    size_t ntile = n16 / (256 * U);
+    for (size_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const dvec2 *q = p + t * 256 * U + threadIdx.x;
+        dvec2 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = NT ? __builtin_nontemporal_load(q + k * 256) : q[k * 256];
+#pragma unroll
+        for (int k = 0; k < U; ++k) acc += v[k].x + v[k].y;
+    }
+    if (acc == 1.2345e300) out[0] = acc;
+}
+
+template <int UZ>
+__global__ __launch_bounds__(256) void k_slab(const dvec2 *__restrict__ p, size_t slab16, int ns, double *out, unsigned ntiles)
+{
+    unsigned b = blockIdx.x, grid = gridDim.x;
+    unsigned tile = (b % 8) * (grid / 8) + b / 8;
+    if (tile >= ntiles) return;
+    size_t c = (size_t)tile * 256 + threadIdx.x;
+    double acc = 0;
+    const dvec2 *q = p + c;
+    for (int z = 0; z + UZ <= ns; z += UZ) {
+        dvec2 v[UZ];
+#pragma unroll
+        for (int k = 0; k < UZ; ++k) v[k] = __builtin_nontemporal_load(q + (size_t)k * slab16);
+#pragma unroll
+        for (int k = 0; k < UZ; ++k) acc += v[k].x + v[k].y;
+        q += (size_t)UZ * slab16;
+    }
+    if (acc == 1.2345e300) out[0] = acc;
+}
+
+// k_flux rebuilt step by step: MODE 0 = two arrays, plain sum; 1 = + fma with thickness[z] (scalar loads);
+// 2 = + missing-value select; 3 = + epilogue (6 dense stores per lane)
+template <int UZ, int MODE>
+__global__ __launch_bounds__(256) void k_slab2(const dvec2 *__restrict__ u, const dvec2 *__restrict__ v, size_t slab16, int nz,
+                                               const double *__restrict__ th, double fill, double *__restrict__ outp,
+                                               double *out, unsigned ntiles)
+{
+    unsigned b = blockIdx.x, grid = gridDim.x;
+    unsigned tile = (b % 8) * (grid / 8) + b / 8;
+    if (tile >= ntiles) return;
+    size_t c = (size_t)tile * 256 + threadIdx.x;
+    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    const dvec2 *qu = u + c, *qv = v + c;
+    for (int z = 0; z + UZ <= nz; z += UZ) {
+        dvec2 x[UZ], y[UZ];
+#pragma unroll
+        for (int k = 0; k < UZ; ++k) {
+            x[k] = __builtin_nontemporal_load(qu + (size_t)k * slab16);
+            y[k] = __builtin_nontemporal_load(qv + (size_t)k * slab16);
+        }
+#pragma unroll
+        for (int k = 0; k < UZ; ++k) {
+            if (MODE == 0) { a0 += x[k].x; a1 += x[k].y; b0 += y[k].x; b1 += y[k].y; }
+            else {
+                double t = th[z + k];
+                double x0 = x[k].x, x1 = x[k].y, y0 = y[k].x, y1 = y[k].y;
+                if (MODE >= 2) {
+                    x0 = (x0 != x0 || x0 == fill) ? 0.0 : x0; x1 = (x1 != x1 || x1 == fill) ? 0.0 : x1;
+                    y0 = (y0 != y0 || y0 == fill) ? 0.0 : y0; y1 = (y1 != y1 || y1 == fill) ? 0.0 : y1;
+                }
+                a0 = fma(t, x0, a0); a1 = fma(t, x1, a1); b0 = fma(t, y0, b0); b1 = fma(t, y1, b1);
+            }
+        }
+        qu += (size_t)UZ * slab16; qv += (size_t)UZ * slab16;
+    }
+    if (MODE == 3) {
+        dvec2 *o = (dvec2 *)outp + c;
+        dvec2 r0 = {a0, a1}, r1 = {b0, b1};
+        o[0] = r0; o[slab16] = r1; o[2 * slab16] = r1; o[3 * slab16] = r0; o[4 * slab16] = r0; o[5 * slab16] = r1;
+    } else if (MODE == 4) {   // nontemporal stores
+        dvec2 *o = (dvec2 *)outp + c;
+        dvec2 r0 = {a0, a1}, r1 = {b0, b1};
+        __builtin_nontemporal_store(r0, o); __builtin_nontemporal_store(r1, o + slab16); __builtin_nontemporal_store(r1, o + 2 * slab16);
+        __builtin_nontemporal_store(r0, o + 3 * slab16); __builtin_nontemporal_store(r0, o + 4 * slab16); __builtin_nontemporal_store(r1, o + 5 * slab16);
+    } else if (MODE >= 8 && MODE <= 11) {   // cache-policy bits on the stores
+        dvec2 *o = (dvec2 *)outp + c;
+        dvec2 r0 = {a0, a1}, r1 = {b0, b1};
+#define ST(ptr, val, bits) asm volatile("global_store_dwordx4 %0, %1, off " bits :: "v"(ptr), "v"(val) : "memory")
+        if (MODE == 8) { ST(o, r0, "sc1"); ST(o + slab16, r1, "sc1"); ST(o + 2 * slab16, r1, "sc1"); ST(o + 3 * slab16, r0, "sc1"); ST(o + 4 * slab16, r0, "sc1"); ST(o + 5 * slab16, r1, "sc1"); }
+        if (MODE == 9) { ST(o, r0, "sc0 sc1"); ST(o + slab16, r1, "sc0 sc1"); ST(o + 2 * slab16, r1, "sc0 sc1"); ST(o + 3 * slab16, r0, "sc0 sc1"); ST(o + 4 * slab16, r0, "sc0 sc1"); ST(o + 5 * slab16, r1, "sc0 sc1"); }
+        if (MODE == 10) { ST(o, r0, "nt sc1"); ST(o + slab16, r1, "nt sc1"); ST(o + 2 * slab16, r1, "nt sc1"); ST(o + 3 * slab16, r0, "nt sc1"); ST(o + 4 * slab16, r0, "nt sc1"); ST(o + 5 * slab16, r1, "nt sc1"); }
+        if (MODE == 11) { ST(o, r0, "sc0"); ST(o + slab16, r1, "sc0"); ST(o + 2 * slab16, r1, "sc0"); ST(o + 3 * slab16, r0, "sc0"); ST(o + 4 * slab16, r0, "sc0"); ST(o + 5 * slab16, r1, "sc0"); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (MODE == 5) {   // one plane only
+        dvec2 *o = (dvec2 *)outp + c;
+        dvec2 r0 = {a0 + b0, a1 + b1};
+        o[0] = r0;
+    } else if (MODE == 6) {   // six stores into a small (L2-resident) window
+        dvec2 *o = (dvec2 *)outp + (c & 0xffff);
+        dvec2 r0 = {a0, a1}, r1 = {b0, b1};
+        o[0] = r0; o[0x10000] = r1; o[0x20000] = r1; o[0x30000] = r0; o[0x40000] = r0; o[0x50000] = r1;
+    } else if (MODE == 7) {   // six planes, AoS-interleaved: 96 contiguous bytes per lane
+        dvec2 *o = (dvec2 *)outp + c * 6;
+        dvec2 r0 = {a0, a1}, r1 = {b0, b1};
+        o[0] = r0; o[1] = r1; o[2] = r1; o[3] = r0; o[4] = r0; o[5] = r1;
+    } else if (a0 + a1 + b0 + b1 == 1.2345e300) out[0] = a0;
+}
+
+__global__ __launch_bounds__(256) void k_expand(const dvec2 *__restrict__ in, dvec2 *__restrict__ o, size_t slab16)
+{   // read 2 planes, write 4 planes (pure streaming)
+    size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= slab16) return;
+    dvec2 a = __builtin_nontemporal_load(in + c), b = __builtin_nontemporal_load(in + slab16 + c);
+    o[c] = b; o[slab16 + c] = a; o[2 * slab16 + c] = a; o[3 * slab16 + c] = b;
+}
+
+int main()
+{
+    const size_t ncell = 3600ul * 1800ul;
+    const int ns = 150;
+    const size_t bytes = ncell * 8 * ns;   // 7.776 GB
+    const size_t n16 = bytes / 16, slab16 = ncell * 8 / 16;
+    dvec2 *p; double *out;
+    CK(hipMalloc(&p, bytes)); CK(hipMalloc(&out, 8));
+    CK(hipMemset(p, 0, bytes));
+    if (getenv("MEMBW_RANDOM")) {   // random doubles: zero-filled buffers draw less power and clock higher
+        hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, (unsigned long long *)p, bytes / 8);
+        CK(hipDeviceSynchronize());
+        printf("random data\n");
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](const char *name, auto launch) {
+        for (int w = 0; w < 2; ++w) launch();
+        CK(hipEventRecord(e0));
+        const int R = 10;
+        for (int r = 0; r < R; ++r) launch();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-28s %8.4f ms  %8.1f GB/s\n", name, ms / R, bytes / (ms / R * 1e-3) / 1e9);
+    };
+    for (int g : {2048, 4096, 8192}) {
+        char nm[64];
+        snprintf(nm, 64, "seq nt U4 grid%d", g); timeit(nm, [&] { hipLaunchKernelGGL((k_seq<true, 4>), dim3(g), dim3(256), 0, 0, p, n16, out); });
+        snprintf(nm, 64, "seq nt U8 grid%d", g); timeit(nm, [&] { hipLaunchKernelGGL((k_seq<true, 8>), dim3(g), dim3(256), 0, 0, p, n16, out); });
+        snprintf(nm, 64, "seq    U8 grid%d", g); timeit(nm, [&] { hipLaunchKernelGGL((k_seq<false, 8>), dim3(g), dim3(256), 0, 0, p, n16, out); });
+        snprintf(nm, 64, "tile nt U8 grid%d", g); timeit(nm, [&] { hipLaunchKernelGGL((k_tile<true, 8>), dim3(g), dim3(256), 0, 0, p, n16, out); });
+    }
+    timeit("tile nt U8 grid=ntile", [&] { hipLaunchKernelGGL((k_tile<true, 8>), dim3((unsigned)(n16 / 2048)), dim3(256), 0, 0, p, n16, out); });
+    timeit("seq nt U1 one-shot", [&] { hipLaunchKernelGGL((k_seq<true, 1>), dim3((unsigned)(n16 / 256)), dim3(256), 0, 0, p, n16, out); });
+    unsigned ntiles = (unsigned)(slab16 / 256), grid = ((ntiles + 7) / 8) * 8;
+    timeit("slab pattern UZ5 (150 slabs)", [&] { hipLaunchKernelGGL((k_slab<5>), dim3(grid), dim3(256), 0, 0, p, slab16, ns, out, ntiles); });
+    timeit("slab pattern UZ10", [&] { hipLaunchKernelGGL((k_slab<10>), dim3(grid), dim3(256), 0, 0, p, slab16, ns, out, ntiles); });
+    {
+        const dvec2 *u = p, *v = p + slab16 * 75;
+        double *th, *outp; CK(hipMalloc(&th, 75 * 8)); CK(hipMalloc(&outp, ncell * 8 * 6));
+        std::vector<double> h(75, 1.0 / 75); CK(hipMemcpy(th, h.data(), 75 * 8, hipMemcpyHostToDevice));
+        timeit("2 arrays sum UZ5", [&] { hipLaunchKernelGGL((k_slab2<5, 0>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("2 arrays fma UZ5", [&] { hipLaunchKernelGGL((k_slab2<5, 1>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("2 arrays fma+fix UZ5", [&] { hipLaunchKernelGGL((k_slab2<5, 2>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("2 arrays fma+fix+stores UZ5", [&] { hipLaunchKernelGGL((k_slab2<5, 3>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("  + nt stores", [&] { hipLaunchKernelGGL((k_slab2<5, 4>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("  + sc1 stores", [&] { hipLaunchKernelGGL((k_slab2<5, 8>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("  + sc0 sc1 stores", [&] { hipLaunchKernelGGL((k_slab2<5, 9>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("  + nt sc1 stores", [&] { hipLaunchKernelGGL((k_slab2<5, 10>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("  + sc0 stores", [&] { hipLaunchKernelGGL((k_slab2<5, 11>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("  + one plane only", [&] { hipLaunchKernelGGL((k_slab2<5, 5>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("  + 6 stores, L2-resident window", [&] { hipLaunchKernelGGL((k_slab2<5, 6>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("  + 6 stores, 96 B per lane", [&] { hipLaunchKernelGGL((k_slab2<5, 7>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("expand kernel: read 2, write 4 planes", [&] { hipLaunchKernelGGL(k_expand, dim3((unsigned)((slab16 + 255) / 256)), dim3(256), 0, 0, (const dvec2 *)outp, (dvec2 *)outp + 2 * slab16, slab16); });
+        timeit("2 arrays fma+fix UZ4(rem)", [&] { hipLaunchKernelGGL((k_slab2<4, 2>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+        timeit("2 arrays fma+fix UZ3", [&] { hipLaunchKernelGGL((k_slab2<3, 2>), dim3(grid), dim3(256), 0, 0, u, v, slab16, 75, th, 1e20, outp, out, ntiles); });
+    }
+    return 0;
+}
