@@ -103,6 +103,23 @@ int mnt_polylineintegral_getIntegralDev(PolylineIntegral_t **self, const double 
 int mnt_polylineintegral_getNumberOfWeights(PolylineIntegral_t **self, size_t *n);
 int mnt_polylineintegral_getWeights(PolylineIntegral_t **self, int64_t *cell_edge, double *weight, int *seg);
 
+/* mint.VectorInterp: the arrows on the target line                field.py:90-95, 119-120 */
+typedef struct VectorInterp_t VectorInterp_t;
+int mnt_vectorinterp_new(VectorInterp_t **self);
+int mnt_vectorinterp_del(VectorInterp_t **self);
+/* .setGrid(grid)                                field.py:91 */
+int mnt_vectorinterp_setGrid(VectorInterp_t **self, Grid_t *grid);
+/* .buildLocator(numCellsPerBucket=128, periodX=360.)   field.py:92 */
+int mnt_vectorinterp_buildLocator(VectorInterp_t **self, int numCellsPerBucket, double periodX, int enableFolding);
+/* .findPoints(targetPoints (n,3) host, tol2=1.e-12)    field.py:93; *numNotFound (may be NULL) counts points outside */
+int mnt_vectorinterp_findPoints(VectorInterp_t **self, size_t numPoints, const double targetPoints[], double tol2,
+                                size_t *numNotFound);
+/* .getFaceVectors(data (ncell,4) host, placement=0) -> vectors (n,3) host   field.py:94-95,119 */
+int mnt_vectorinterp_getFaceVectors(VectorInterp_t **self, const double data[], int placement, double vectors[]);
+/* extensions: data resident in HBM (layout 0 = (ncell,4), 1 = the engine's [4][ncell] planes); located cells */
+int mnt_vectorinterp_getFaceVectorsDev(VectorInterp_t **self, const double *data_dev, int layout, double vectors[]);
+int mnt_vectorinterp_getCells(VectorInterp_t **self, long long *cell_ids, double *pcoords /* (n,2) */);
+
 /* ------------------------------------------------------------------ Level 2: Field-shaped engine */
 typedef struct nf_field nf_field;
 

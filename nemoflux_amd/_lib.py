@@ -70,6 +70,16 @@ _sig('mnt_polylineintegral_getIntegralDev', [_pp, ctypes.c_void_p, ctypes.c_int,
 _sig('mnt_polylineintegral_getNumberOfWeights', [_pp, ctypes.POINTER(ctypes.c_size_t)])
 _sig('mnt_polylineintegral_getWeights', [_pp, c_int64_p, c_double_p, c_int_p])
 
+_sig('mnt_vectorinterp_new', [_pp])
+_sig('mnt_vectorinterp_del', [_pp])
+_sig('mnt_vectorinterp_setGrid', [_pp, _h])
+_sig('mnt_vectorinterp_buildLocator', [_pp, ctypes.c_int, ctypes.c_double, ctypes.c_int])
+_sig('mnt_vectorinterp_findPoints', [_pp, ctypes.c_size_t, c_double_p, ctypes.c_double,
+                                     ctypes.POINTER(ctypes.c_size_t)])
+_sig('mnt_vectorinterp_getFaceVectors', [_pp, c_double_p, ctypes.c_int, c_double_p])
+_sig('mnt_vectorinterp_getFaceVectorsDev', [_pp, ctypes.c_void_p, ctypes.c_int, c_double_p])
+_sig('mnt_vectorinterp_getCells', [_pp, ctypes.POINTER(ctypes.c_longlong), c_double_p])
+
 _sig('nf_field_new', [_pp])
 _sig('nf_field_del', [_pp])
 _sig('nf_field_set_stream', [_pp, ctypes.c_void_p])

@@ -4,6 +4,7 @@
 // wrapper (horizgrid.py:23-24,30,43; field.py:45-48,102); Level 2 is the Field-shaped engine
 // (field.py:15-234).  Host-side orchestration only: every number is produced by the HIP kernels of
 // nf_geom.hip / nf_flux.hip / nf_weights.hip / nf_integral.hip / nf_datagen.hip.  There is no CPU path.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -369,6 +370,160 @@ int mnt_polylineintegral_getWeights(PolylineIntegral_t **self, int64_t *cell_edg
     if ((*self)->ws.nrec == 0) return NF_OK;
     NF_NEED_DEVICE();
     return weights_to_host((*self)->ws, cell_edge, weight, seg);
+}
+
+}  // extern "C"
+
+// ----------------------------------------------------------------------------------------------- VectorInterp
+struct VectorInterp_t {
+    Grid_t *grid = nullptr;
+    bool locator = false;
+    double periodX = 0.0;
+    long npts = 0;
+    double *d_targets = nullptr, *d_pcoords = nullptr, *d_vectors = nullptr, *d_stage = nullptr;
+    long *d_cell = nullptr;
+    unsigned long long *d_best = nullptr;
+    long stage_cells = 0;
+};
+
+static void vi_free_points(VectorInterp_t *v)
+{
+    dev_free(v->d_targets);
+    dev_free(v->d_pcoords);
+    dev_free(v->d_vectors);
+    dev_free(v->d_cell);
+    dev_free(v->d_best);
+    v->npts = 0;
+}
+
+extern "C" {
+
+int mnt_vectorinterp_new(VectorInterp_t **self)
+{
+    *self = new VectorInterp_t();
+    return NF_OK;
+}
+int mnt_vectorinterp_del(VectorInterp_t **self)
+{
+    if (self && *self) {
+        vi_free_points(*self);
+        dev_free((*self)->d_stage);
+        delete *self;
+        *self = nullptr;
+    }
+    return NF_OK;
+}
+int mnt_vectorinterp_setGrid(VectorInterp_t **self, Grid_t *grid)
+{
+    NF_REQUIRE(self && *self && grid, NF_ERR_ARG, "mnt_vectorinterp_setGrid: null argument");
+    NF_REQUIRE(grid->ncell > 0 && grid->d_xy, NF_ERR_STATE, "mnt_vectorinterp_setGrid: grid not built");
+    (*self)->grid = grid;
+    return NF_OK;
+}
+int mnt_vectorinterp_buildLocator(VectorInterp_t **self, int numCellsPerBucket, double periodX, int enableFolding)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_vectorinterp_buildLocator: null argument");
+    NF_REQUIRE((*self)->grid, NF_ERR_STATE, "mnt_vectorinterp_buildLocator: setGrid first");
+    NF_REQUIRE(numCellsPerBucket > 0 && periodX >= 0.0, NF_ERR_ARG, "mnt_vectorinterp_buildLocator: bad arguments");
+    NF_REQUIRE(!enableFolding, NF_ERR_ARG, "mnt_vectorinterp_buildLocator: enableFolding is not supported");
+    (*self)->periodX = periodX;
+    (*self)->locator = true;
+    return NF_OK;
+}
+int mnt_vectorinterp_findPoints(VectorInterp_t **self, size_t numPoints, const double targetPoints[], double tol2,
+                                size_t *numNotFound)
+{
+    NF_REQUIRE(self && *self && (targetPoints || numPoints == 0), NF_ERR_ARG, "mnt_vectorinterp_findPoints: null argument");
+    VectorInterp_t *v = *self;
+    NF_REQUIRE(v->grid && v->locator, NF_ERR_STATE, "mnt_vectorinterp_findPoints: setGrid/buildLocator first");
+    NF_REQUIRE(tol2 >= 0.0, NF_ERR_ARG, "mnt_vectorinterp_findPoints: negative tolerance");
+    NF_NEED_DEVICE();
+    vi_free_points(v);
+    v->npts = (long)numPoints;
+    if (numNotFound) *numNotFound = 0;
+    if (numPoints == 0) return NF_OK;
+    NF_TRY(dev_alloc(&v->d_targets, numPoints * 3));
+    NF_TRY(dev_alloc(&v->d_pcoords, numPoints * 2));
+    NF_TRY(dev_alloc(&v->d_vectors, numPoints * 3));
+    NF_TRY(dev_alloc(&v->d_cell, numPoints));
+    NF_TRY(dev_alloc(&v->d_best, numPoints));
+    NF_HIP(hipMemcpy(v->d_targets, targetPoints, sizeof(double) * 3 * numPoints, hipMemcpyHostToDevice));
+    {   // order the points by y for the locator's range search (index bookkeeping only)
+        std::vector<long> order(numPoints);
+        for (size_t i = 0; i < numPoints; ++i) order[i] = (long)i;
+        std::stable_sort(order.begin(), order.end(),
+                         [&](long a, long b) { return targetPoints[3 * a + 1] < targetPoints[3 * b + 1]; });
+        std::vector<double> sorted(3 * numPoints);
+        for (size_t q = 0; q < numPoints; ++q)
+            for (int k = 0; k < 3; ++k) sorted[3 * q + k] = targetPoints[3 * order[q] + k];
+        double *d_sorted = nullptr;
+        long *d_order = nullptr;
+        NF_TRY(dev_alloc(&d_sorted, numPoints * 3));
+        NF_TRY(dev_alloc(&d_order, numPoints));
+        hipError_t e1 = hipMemcpy(d_sorted, sorted.data(), sizeof(double) * 3 * numPoints, hipMemcpyHostToDevice);
+        hipError_t e2 = hipMemcpy(d_order, order.data(), sizeof(long) * numPoints, hipMemcpyHostToDevice);
+        int rc = (e1 == hipSuccess && e2 == hipSuccess)
+                     ? launch_find_points(v->grid->d_xy, v->grid->ncell, v->d_targets, d_sorted, d_order, v->npts,
+                                          v->periodX, tol2, v->d_best, v->d_cell, v->d_pcoords, nullptr)
+                     : NF_ERR_HIP;
+        hipError_t e3 = hipDeviceSynchronize();
+        dev_free(d_sorted);
+        dev_free(d_order);
+        NF_HIP(e1);
+        NF_HIP(e2);
+        NF_TRY(rc);
+        NF_HIP(e3);
+    }
+    if (numNotFound) {
+        std::vector<long> cells(numPoints);
+        NF_HIP(hipMemcpy(cells.data(), v->d_cell, sizeof(long) * numPoints, hipMemcpyDeviceToHost));
+        size_t n = 0;
+        for (long c : cells) n += (c < 0);
+        *numNotFound = n;
+    } else {
+        NF_HIP(hipDeviceSynchronize());
+    }
+    return NF_OK;
+}
+/* layout: 0 = (ncell,4) AoS, 1 = [4][ncell] planes (the engine's resident layout) */
+int mnt_vectorinterp_getFaceVectorsDev(VectorInterp_t **self, const double *data_dev, int layout, double vectors[])
+{
+    NF_REQUIRE(self && *self && data_dev, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null argument");
+    VectorInterp_t *v = *self;
+    NF_REQUIRE(v->grid, NF_ERR_STATE, "mnt_vectorinterp_getFaceVectors: setGrid first");
+    if (v->npts == 0) return NF_OK;
+    NF_REQUIRE(vectors, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null output");
+    NF_NEED_DEVICE();
+    NF_TRY(launch_face_vectors(v->grid->d_xy, v->d_cell, v->d_pcoords, v->npts, data_dev, v->grid->ncell, layout,
+                               v->d_vectors, nullptr));
+    NF_HIP(hipMemcpy(vectors, v->d_vectors, sizeof(double) * 3 * v->npts, hipMemcpyDeviceToHost));
+    return NF_OK;
+}
+int mnt_vectorinterp_getFaceVectors(VectorInterp_t **self, const double data[], int placement, double vectors[])
+{
+    NF_REQUIRE(self && *self && data, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null argument");
+    VectorInterp_t *v = *self;
+    NF_REQUIRE(v->grid, NF_ERR_STATE, "mnt_vectorinterp_getFaceVectors: setGrid first");
+    NF_REQUIRE(placement == MNT_CELL_BY_CELL_DATA, NF_ERR_ARG,
+               "mnt_vectorinterp_getFaceVectors: only CELL_BY_CELL_DATA (placement=0) is supported (field.py:94-95)");
+    NF_NEED_DEVICE();
+    if (v->stage_cells != v->grid->ncell) {
+        dev_free(v->d_stage);
+        NF_TRY(dev_alloc(&v->d_stage, (size_t)v->grid->ncell * 4));
+        v->stage_cells = v->grid->ncell;
+    }
+    NF_HIP(hipMemcpy(v->d_stage, data, sizeof(double) * 4 * (size_t)v->grid->ncell, hipMemcpyHostToDevice));
+    return mnt_vectorinterp_getFaceVectorsDev(self, v->d_stage, 0, vectors);
+}
+int mnt_vectorinterp_getCells(VectorInterp_t **self, long long *cell_ids, double *pcoords)
+{
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_vectorinterp_getCells: null argument");
+    VectorInterp_t *v = *self;
+    if (v->npts == 0) return NF_OK;
+    NF_NEED_DEVICE();
+    if (cell_ids) NF_HIP(hipMemcpy(cell_ids, v->d_cell, sizeof(long) * v->npts, hipMemcpyDeviceToHost));
+    if (pcoords) NF_HIP(hipMemcpy(pcoords, v->d_pcoords, sizeof(double) * 2 * v->npts, hipMemcpyDeviceToHost));
+    return NF_OK;
 }
 
 }  // extern "C"

@@ -242,8 +242,15 @@ class Field(object):
                     vectorPoints.append(begPoint + u * j * vdx)
                     self.uVectors.append(u)
         self.vectorPoints = numpy.array(vectorPoints) if vectorPoints else numpy.zeros((0, 3))
-        # mint.VectorInterp (field.py:90-95) is SURVEY.md 8f rank 2 ("next"): arrows are not computed yet
+        # compute the vector at the target line (field.py:89-95), from the resident planes (no host round trip)
         self.vectorValues = numpy.zeros((self.vectorPoints.shape[0], 3), numpy.float64)
+        self.vinterp = None
+        if self._readback:   # batch drivers (readback=False) never look at the arrows
+            self.vinterp = mint.VectorInterp()
+            self.vinterp.setGrid(self.gr.getMintGrid())
+            self.vinterp.buildLocator(numCellsPerBucket=128, periodX=periodX)
+            self.vinterp.findPoints(self.vectorPoints, tol2=1.e-12)
+            self._update_vectors()
 
     # ------------------------------------------------------------------------------------------
     def _host_zeros(self, shape):
@@ -317,10 +324,16 @@ class Field(object):
             self.maxAbsFlux = max(self.maxAbsFlux, m.value)  # field.py:234
         return self._row
 
+    def _update_vectors(self):
+        if self.vectorValues.shape[0] and self.vinterp is not None:
+            p = ctypes.c_void_p()
+            check(lib.nf_field_device_ptr(ctypes.byref(self._h), 0, ctypes.byref(p)))
+            self.vinterp.getFaceVectors(p.value, out=self.vectorValues, _layout=1)   # in place (fluxviz.py:301)
+
     def update(self):
         """field.py:112-120: recompute the current time step; host arrays are refreshed in place."""
         self._compute(self.timeIndex, readback=True)
-        # self.vectorValues[:] = vinterp.getFaceVectors(...)  (field.py:119-120) -- "next" row 8f-2
+        self._update_vectors()   # field.py:119-120
 
     def computeFlux(self, tIndex, readback=False):
         """BASELINE north_star's computeFlux(tIndex): set the time index, run the step on the GPU and return

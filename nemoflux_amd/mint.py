@@ -5,6 +5,8 @@
     mint.PolylineIntegral().setGrid / buildLocator /
         computeWeights / getIntegral                            field.py:45-48,102; fluxplot.py:56
     mint.CELL_BY_CELL_DATA                                      field.py:102
+    mint.VectorInterp().setGrid / buildLocator / findPoints /
+        getFaceVectors                                          field.py:90-95,119-120
 
 `import nemoflux_amd.mint as mint` in place of `import mint` is the whole integration.
 Same names, argument meaning and error behaviour; all numbers come from HIP kernels (no CPU fallback).
@@ -133,3 +135,63 @@ class PolylineIntegral(object):
         check(lib.mnt_polylineintegral_getWeights(ctypes.byref(self.obj), ce.ctypes.data_as(_lib.c_int64_p),
                                                   _lib.dptr(w), sg.ctypes.data_as(_lib.c_int_p)))
         return ce, w, sg
+
+
+class VectorInterp(object):
+    """mint.VectorInterp: vectors at target points from cell-by-cell edge data (W2 / face interpolation)."""
+
+    def __init__(self):
+        self.obj = ctypes.c_void_p()
+        self.grid = None
+        self.numTargetPoints = 0
+        self.numNotFound = 0
+        check(lib.mnt_vectorinterp_new(ctypes.byref(self.obj)))
+
+    def __del__(self):
+        if self.obj:
+            lib.mnt_vectorinterp_del(ctypes.byref(self.obj))
+
+    def setGrid(self, grid):
+        self.grid = grid
+        check(lib.mnt_vectorinterp_setGrid(ctypes.byref(self.obj), grid.obj))
+
+    def buildLocator(self, numCellsPerBucket=128, periodX=360., enableFolding=False):
+        check(lib.mnt_vectorinterp_buildLocator(ctypes.byref(self.obj), int(numCellsPerBucket), float(periodX),
+                                                1 if enableFolding else 0))
+
+    def findPoints(self, targetPoints, tol2=1.e-12):
+        """targetPoints: (n, 3); returns the number of points that fall outside every cell."""
+        tp = numpy.ascontiguousarray(targetPoints, dtype=numpy.float64)
+        if tp.size and (tp.ndim != 2 or tp.shape[1] != 3):
+            raise RuntimeError('ERROR: targetPoints must have shape (numPoints, 3)')
+        self.numTargetPoints = tp.shape[0] if tp.size else 0
+        nf = ctypes.c_size_t()
+        check(lib.mnt_vectorinterp_findPoints(ctypes.byref(self.obj), self.numTargetPoints,
+                                              _lib.dptr(tp) if tp.size else None, float(tol2), ctypes.byref(nf)))
+        self.numNotFound = nf.value
+        return nf.value
+
+    def getFaceVectors(self, data, placement=CELL_BY_CELL_DATA, out=None, _layout=0):
+        """(n, 3) vectors; data: (ncell, 4) host array, or HBM-resident (torch CUDA tensor / DeviceBuffer / int)."""
+        res = numpy.zeros((self.numTargetPoints, 3), numpy.float64) if out is None else out
+        if self.numTargetPoints == 0:
+            return res
+        p = _lib.device_pointer(data)
+        if p is not None:
+            check(lib.mnt_vectorinterp_getFaceVectorsDev(ctypes.byref(self.obj), p, int(_layout), _lib.dptr(res)))
+        else:
+            d = numpy.ascontiguousarray(data, dtype=numpy.float64)
+            if d.size != self.grid.getNumberOfCells() * 4:
+                raise RuntimeError('ERROR: data must hold 4 edge values per cell')
+            check(lib.mnt_vectorinterp_getFaceVectors(ctypes.byref(self.obj), _lib.dptr(d), int(placement),
+                                                      _lib.dptr(res)))
+        return res
+
+    def getCells(self):
+        """(cell id or -1, (xi, eta)) of every target point."""
+        ids = numpy.zeros(self.numTargetPoints, numpy.int64)
+        pc = numpy.zeros((self.numTargetPoints, 2), numpy.float64)
+        if self.numTargetPoints:
+            check(lib.mnt_vectorinterp_getCells(ctypes.byref(self.obj), ids.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)),
+                                                _lib.dptr(pc)))
+        return ids, pc

@@ -339,3 +339,57 @@ double nfo_step(const void *u, const void *v, int is_f32, long nz, long ny, long
     nfo_edge_flux(uInt, vInt, arc, ny, nx, sverdrup, iV, eU, eV, max_abs);
     return nfo_get_integral(iV, nw, cell_edge, weight, seg, 0, NULL);
 }
+
+/* ---- VectorInterp: mint.VectorInterp.findPoints + getFaceVectors (field.py:90-95,119-120) -----------------
+ * python-mint (absent) again: "parity unpinned".  Restated from the W2 (face / Piola) interpolation the reference
+ * asks for: for a target point inside cell c with bilinear parameters (xi, eta),
+ *      V = [ (d3 (1-xi) + d1 xi) r_xi  -  (d0 (1-eta) + d2 eta) r_eta ] / J ,   J = r_xi x r_eta
+ * with d0..d3 the cell's edge data (S,E,N,W; all oriented in +xi: counterclock = False) and r_xi, r_eta the tangent
+ * vectors of the bilinear map.  With nemoflux's data (d1 = +U arc, d2 = -V arc: field.py:195-196) this is the
+ * vertically integrated velocity per unit length in grid units; the only pin in the reference is README.md:36
+ * ("the velocity is uniform and points down in the y direction" for psi = x).  A point is located in the cell with
+ * the LOWEST id whose parameters lie in [-tol, 1+tol]^2 (tol = sqrt(tol2)), trying x, x-periodX, x+periodX;
+ * points outside every cell get the zero vector and cell id -1. */
+void nfo_vector_interp(const double *points, long ncell, const double *targets, long npts, double periodX, double tol2,
+                       const double *data /* (ncell,4) */, double *vectors /* (npts,3) */, long *cell_ids /* npts or NULL */)
+{
+    const double tol = sqrt(tol2);
+    const int nshift = periodX > 0.0 ? 3 : 1;
+    for (long p = 0; p < npts; ++p) {
+        vectors[3 * p] = vectors[3 * p + 1] = vectors[3 * p + 2] = 0.0;
+        if (cell_ids) cell_ids[p] = -1;
+        int found = 0;
+        for (long c = 0; c < ncell && !found; ++c) {
+            double v[8];
+            double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+            for (int i = 0; i < 4; ++i) {
+                v[2 * i] = points[(c * 4 + i) * 3];
+                v[2 * i + 1] = points[(c * 4 + i) * 3 + 1];
+                if (v[2 * i] < xmin) xmin = v[2 * i];
+                if (v[2 * i] > xmax) xmax = v[2 * i];
+                if (v[2 * i + 1] < ymin) ymin = v[2 * i + 1];
+                if (v[2 * i + 1] > ymax) ymax = v[2 * i + 1];
+            }
+            const double slack = 1.e-6 * (fabs(xmin) + fabs(xmax) + fabs(ymin) + fabs(ymax) + 1.0);
+            for (int k = 0; k < nshift && !found; ++k) {
+                const double px = targets[3 * p] + (nshift == 3 ? k - 1 : 0) * periodX, py = targets[3 * p + 1];
+                if (px < xmin - slack || px > xmax + slack || py < ymin - slack || py > ymax + slack) continue;
+                double xi, eta;
+                inv_bilinear(v, px, py, &xi, &eta);
+                if (!(xi >= -tol && xi <= 1.0 + tol && eta >= -tol && eta <= 1.0 + tol)) continue;
+                const double rxx = (1.0 - eta) * (v[2] - v[0]) + eta * (v[4] - v[6]);
+                const double rxy = (1.0 - eta) * (v[3] - v[1]) + eta * (v[5] - v[7]);
+                const double rex = (1.0 - xi) * (v[6] - v[0]) + xi * (v[4] - v[2]);
+                const double rey = (1.0 - xi) * (v[7] - v[1]) + xi * (v[5] - v[3]);
+                const double jac = rxx * rey - rxy * rex;
+                const double *d = data + 4 * c;
+                const double fx = d[3] * (1.0 - xi) + d[1] * xi;    /* flux in +xi  (west .. east) */
+                const double fe = d[0] * (1.0 - eta) + d[2] * eta;  /* stream-function difference along xi (south .. north) */
+                vectors[3 * p] = (fx * rxx - fe * rex) / jac;
+                vectors[3 * p + 1] = (fx * rxy - fe * rey) / jac;
+                if (cell_ids) cell_ids[p] = c;
+                found = 1;
+            }
+        }
+    }
+}

@@ -56,6 +56,8 @@ def lib():
                                ctypes.c_long, dp, ctypes.c_double, dp, ctypes.c_int, dp, dp, dp, dp, dp, dp,
                                ctypes.c_long, ctypes.POINTER(ctypes.c_int64), dp, ctypes.POINTER(ctypes.c_int)]
         L.nfo_step.restype = ctypes.c_double
+        L.nfo_vector_interp.argtypes = [dp, ctypes.c_long, dp, ctypes.c_long, ctypes.c_double, ctypes.c_double, dp, dp,
+                                        ctypes.POINTER(ctypes.c_long)]
         _lib = L
     return _lib
 
@@ -159,6 +161,16 @@ def get_integral(weights, data, with_segments=False):
                                  _dp(weights.weight), weights.seg.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
                                  weights.nseg, _dp(segt))
     return (tot, segt[:weights.nseg]) if with_segments else tot
+
+
+def vector_interp(points, targets, data, periodX=360., tol2=1.e-12):
+    """mint.VectorInterp.findPoints + getFaceVectors (field.py:90-95); returns (vectors (npts,3), cell ids)."""
+    pts, tg, d = _c64(points), _c64(targets).reshape(-1, 3), _c64(data).reshape(-1, 4)
+    vec = numpy.zeros((tg.shape[0], 3), numpy.float64)
+    ids = numpy.zeros(tg.shape[0], numpy.int64)
+    lib().nfo_vector_interp(_dp(pts), pts.shape[0], _dp(tg), tg.shape[0], float(periodX), float(tol2), _dp(d), _dp(vec),
+                            ids.ctypes.data_as(ctypes.POINTER(ctypes.c_long)))
+    return vec, ids
 
 
 # ---------------------------------------------------------------- numpy restatements, as written

@@ -371,3 +371,47 @@ def test_flux_kernel_variants_bit_identical(variant):
         check(lib.nf_tuning_set(b'flux_variant', 0))
     with pytest.raises(RuntimeError):
         check(lib.nf_tuning_set(b'no_such_knob', 1))
+
+
+def test_vector_interp_vs_oracle_and_readme(oracle, cases):
+    """mint.VectorInterp stand-in (field.py:90-95,119-120).  python-mint is absent -> parity unpinned beyond
+    README.md:36: for psi = x 'the velocity is uniform and points down in the y direction'."""
+    from nemoflux_amd import mint
+    g = load_golden('c1_x')
+    m = [c for c in cases if c['name'] == 'c1_x'][0]
+    fld = quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], g['u'], g['v'],
+                      [transect_xyz(m['transects']['readme']['points'])])
+    assert fld.vectorPoints.shape[0] > 20 and fld.vectorValues.shape == fld.vectorPoints.shape
+    inner = numpy.abs(fld.vectorPoints[:, 1]) < 79.0          # away from the pole rows
+    assert numpy.allclose(fld.vectorValues[inner], [0.0, -1.0, 0.0], rtol=0, atol=1e-13)
+    addr = fld.vectorValues.ctypes.data
+    fld.update()
+    assert fld.vectorValues.ctypes.data == addr                # refreshed in place (fluxviz.py:301)
+    # general data, rotated grid: same algorithm as the oracle, no transcendental -> tight tolerance
+    gr = load_golden('rot36_zt')
+    pts = oracle.assemble_points(gr['bounds_lon'], gr['bounds_lat'])
+    grid = mint.Grid()
+    grid.setPoints(pts)
+    rng = numpy.random.default_rng(11)
+    targets = numpy.zeros((400, 3))
+    targets[:, 0] = rng.uniform(-260, 300, 400)
+    targets[:, 1] = rng.uniform(-88, 88, 400)
+    targets[:5, :2] = [(-180, -90), (0, 0), (10, 10), (180, 90), (170, -80)]    # nodes / corners
+    data = rng.standard_normal((pts.shape[0], 4))
+    for periodX in (360., 0.):
+        vi = mint.VectorInterp()
+        vi.setGrid(grid)
+        vi.buildLocator(numCellsPerBucket=128, periodX=periodX)
+        nnot = vi.findPoints(targets, tol2=1.e-12)
+        vec = vi.getFaceVectors(data, placement=0)
+        ovec, oids = oracle.vector_interp(pts, targets, data, periodX=periodX, tol2=1.e-12)
+        ids, pc = vi.getCells()
+        assert numpy.array_equal(ids, oids)
+        assert nnot == int((oids < 0).sum())
+        scale = numpy.abs(ovec).max()
+        assert numpy.abs(vec - ovec).max() <= 1e-11 * scale
+        assert numpy.all(vec[oids < 0] == 0)
+    vi = mint.VectorInterp()
+    vi.setGrid(grid)
+    vi.buildLocator()
+    assert vi.findPoints(numpy.zeros((0, 3))) == 0 and vi.getFaceVectors(data).shape == (0, 3)

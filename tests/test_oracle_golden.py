@@ -178,3 +178,27 @@ def test_station_files_parsed_like_reference():
         got = LatLonReader(path).getLonLats()
         os.unlink(path)
         assert numpy.array_equal(got, numpy.array(ll))
+
+
+def test_vector_interp_restatement_physics(oracle):
+    """README.md:36: for psi = x 'the velocity is uniform and points down in the y direction' -- the only statement in
+    the reference that pins mint.VectorInterp.getFaceVectors (sign and orientation) for nemoflux's edge data."""
+    g = load_golden('c1_x')
+    pts = oracle.assemble_points(g['bounds_lon'], g['bounds_lat'])
+    tg = numpy.array([[-175., -65., 0.], [3.3, 12.2, 0.], [100., 40., 0.], [500., 0., 0.], [-185., 10., 0.], [0., 95., 0.]])
+    vec, ids = oracle.vector_interp(pts, tg, g['integratedVelocity'][0])
+    assert numpy.allclose(vec[:5], [0., -1., 0.], rtol=0, atol=1e-14)     # 10 (A m^2/s per 10-degree edge) / 10 degrees
+    assert ids[5] == -1 and numpy.all(vec[5] == 0)                        # outside the grid -> zero vector
+    # psi = cos(2 pi y/360) + sin(2 pi x/360): (u, v) = (dpsi/dy, -dpsi/dx) per degree; bilinear cells -> O(h) agreement
+    g2 = load_golden('cossin360')
+    p2 = oracle.assemble_points(g2['bounds_lon'], g2['bounds_lat'])
+    dg = oracle.DataGen(360, 180, 1, 1)
+    u, v = dg.computeUV("cos(2*pi*y/360) + sin(2*pi*x/360)")
+    st = oracle.EdgeFluxState(180, 360)
+    oracle.edge_flux(st, oracle.np_read_field(u[0], dg.thickness), oracle.np_read_field(v[0], dg.thickness),
+                     g2['arcLengths'])
+    tg2 = numpy.array([[-95.3, 5.2, 0.], [35.7, -25.1, 0.], [125.5, 45.5, 0.]])
+    v2, _ = oracle.vector_interp(p2, tg2, st.integratedVelocity)
+    k = 2 * numpy.pi / 360
+    exact = numpy.stack([-k * numpy.sin(k * tg2[:, 1]), -k * numpy.cos(k * tg2[:, 0])], axis=1)
+    assert numpy.allclose(v2[:, :2], exact, rtol=0, atol=0.02 * numpy.abs(exact).max())
