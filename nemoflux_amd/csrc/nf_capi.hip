@@ -560,7 +560,19 @@ struct nf_field {
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // pairs
+    // hipGraph of one compute_all pass (launch-bound small grids: 4 launches per time step)
+    hipGraphExec_t graph_exec = nullptr;
+    double *graph_rows = nullptr;
+    long graph_version = -1, version = 0;  // version is bumped by every call that changes what a pass launches
 };
+
+static void field_drop_graph(nf_field *f)
+{
+    if (f->graph_exec) (void)hipGraphExecDestroy(f->graph_exec);
+    f->graph_exec = nullptr;
+    f->graph_rows = nullptr;
+    f->graph_version = -1;
+}
 
 static int field_free_geometry(nf_field *f)
 {
@@ -674,6 +686,7 @@ int nf_field_del(nf_field **self)
         dev_free(f->d_scratch);
         dev_free(f->d_row);
         for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
+        field_drop_graph(f);
         delete f;
         *self = nullptr;
     }
@@ -683,6 +696,7 @@ int nf_field_set_stream(nf_field **self, void *hip_stream)
 {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_stream: null field");
     (*self)->stream = (hipStream_t)hip_stream;
+    ++(*self)->version;
     return NF_OK;
 }
 
@@ -736,6 +750,7 @@ int nf_field_set_bounds(nf_field **self, const void *bounds_lon, const void *bou
     f->grid_view.d_xy = f->d_xy;
     f->grid_view.owns_xy = false;
     f->weights_built = false;
+    ++f->version;
     return NF_OK;
 }
 
@@ -749,6 +764,7 @@ int nf_field_set_thickness(nf_field **self, const double *thickness, long nz)
     NF_TRY(dev_alloc(&f->d_thick, (size_t)nz));
     NF_HIP(hipMemcpy(f->d_thick, thickness, sizeof(double) * nz, hipMemcpyHostToDevice));
     f->nz = nz;
+    ++f->version;
     return NF_OK;
 }
 
@@ -768,6 +784,7 @@ int nf_field_set_uv(nf_field **self, const void *u, const void *v, long nt, int 
     if (f->d_stage_u) (void)hipFree(f->d_stage_u);
     if (f->d_stage_v) (void)hipFree(f->d_stage_v);
     f->d_stage_u = f->d_stage_v = nullptr;
+    ++f->version;
     return NF_OK;
 }
 
@@ -775,6 +792,7 @@ int nf_field_set_sverdrup(nf_field **self, int sverdrup)
 {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_sverdrup: null field");
     (*self)->sverdrup = sverdrup ? 1 : 0;
+    ++(*self)->version;
     return NF_OK;
 }
 
@@ -784,6 +802,7 @@ int nf_field_set_slab_range(nf_field **self, long s_begin, long s_end)
     NF_REQUIRE(s_begin >= 0 && s_end >= s_begin, NF_ERR_ARG, "nf_field_set_slab_range: need 0 <= begin <= end");
     (*self)->s_begin = s_begin;
     (*self)->s_end = s_end;
+    ++(*self)->version;
     return NF_OK;
 }
 
@@ -822,6 +841,7 @@ int nf_field_build_weights(nf_field **self, int numCellsPerBucket, double period
     NF_TRY(dev_alloc(&f->d_row, (size_t)field_row_length(f)));
     NF_HIP(hipMemcpy(f->d_tr_off, f->tr_off.data(), sizeof(int) * f->tr_off.size(), hipMemcpyHostToDevice));
     f->weights_built = true;
+    ++f->version;
     return NF_OK;
 }
 
@@ -885,6 +905,36 @@ int nf_field_compute_all_async(nf_field **self, double *rows_dev)
     nf_field *f = *self;
     NF_REQUIRE(f->weights_built, NF_ERR_STATE, "nf_field_compute_all_async: build_weights first");
     const int rowlen = field_row_length(f);
+    // Replay a captured graph of the whole pass when nothing changed since it was captured.  Capture needs a real
+    // (non-null) stream, resident fields, and no per-launch timing events.
+    static const bool use_graph = !(getenv("NF_GRAPH") && atoi(getenv("NF_GRAPH")) == 0);
+    const bool can_graph = use_graph && f->stream != nullptr && f->uv_on_device && !f->timing;
+    if (can_graph && f->graph_exec && f->graph_rows == rows_dev && f->graph_version == f->version + tuning_version()) {
+        NF_HIP(hipGraphLaunch(f->graph_exec, f->stream));
+        return NF_OK;
+    }
+    if (can_graph) {
+        field_drop_graph(f);
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int rc = NF_OK;
+            for (long t = 0; t < f->nt && rc == NF_OK; ++t) rc = field_step_async(f, t, rows_dev + (size_t)t * rowlen);
+            hipError_t e = hipStreamEndCapture(f->stream, &graph);
+            if (rc == NF_OK && e == hipSuccess && graph &&
+                hipGraphInstantiate(&f->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                (void)hipGraphDestroy(graph);
+                f->graph_rows = rows_dev;
+                f->graph_version = f->version + tuning_version();
+                NF_HIP(hipGraphLaunch(f->graph_exec, f->stream));
+                return NF_OK;
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+            f->graph_exec = nullptr;
+            (void)hipGetLastError();  // fall through to direct launches (they report any real error)
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     for (long t = 0; t < f->nt; ++t) NF_TRY(field_step_async(f, t, rows_dev + (size_t)t * rowlen));
     return NF_OK;
 }
@@ -993,6 +1043,7 @@ int nf_field_timing(nf_field **self, int enable)
     for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
     f->ev.clear();
     f->timing = enable != 0;
+    ++f->version;
     return NF_OK;
 }
 int nf_field_timing_read(nf_field **self, long *launches, double *total_ms)

@@ -66,6 +66,7 @@ struct FluxArgs {
 };
 int launch_flux(const FluxArgs &a, hipStream_t s);
 int tuning_set(const char *name, int value);
+long tuning_version();
 int launch_planes_to_aos(const double *planes, long ncell, double *aos, hipStream_t s);
 
 // K2: batched polyline weights.

@@ -413,8 +413,11 @@ static int env_int(const char *name, int dflt)
 static int g_pipe_waves = env_int("NF_WW_BLOCKS_PER_CU", 0);  // writer-wave form: 0 = from the occupancy query
 static int g_xcd_map = env_int("NF_XCD_MAP", 1);
 static int g_variant = env_int("NF_FLUX_VARIANT", 0);
+static long g_tuning_version = 0;
+long tuning_version() { return g_tuning_version; }
 int tuning_set(const char *name, int value)
 {
+    ++g_tuning_version;  // captured graphs bake the variant in
     if (!strcmp(name, "xcd_map")) g_xcd_map = value;
     else if (!strcmp(name, "flux_variant")) g_variant = value;
     else if (!strcmp(name, "ww_blocks_per_cu")) g_pipe_waves = value;

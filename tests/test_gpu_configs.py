@@ -415,3 +415,64 @@ def test_vector_interp_vs_oracle_and_readme(oracle, cases):
     vi.setGrid(grid)
     vi.buildLocator()
     assert vi.findPoints(numpy.zeros((0, 3))) == 0 and vi.getFaceVectors(data).shape == (0, 3)
+
+
+def test_fluxplot_batch_driver(tmp_path, capsys):
+    """nemoflux/fluxplot.py:51-59 as one batched pass: the table equals the reference's step-by-step loop."""
+    from nemoflux_amd import fluxplot, mint
+    from nemoflux_amd.datagen import main as datagen_main
+    from nemoflux_amd.field import Field
+    from nemoflux_amd.fluxexact import exactFlux
+    prefix = str(tmp_path) + '/'
+    datagen_main(streamFunction=PSI_ZT, prefix=prefix, nx=72, ny=36, nz=4, nt=5)
+    lines = "[(-100,-80),(100,-80),(0,80)],[(-100,-80),(100,-80),(0,80),(-100,-80)]"
+    out = prefix + 'series.csv'
+    totals = fluxplot.main(tFile=prefix + 'T.npz', uFile=prefix + 'U.npz', vFile=prefix + 'V.npz', lonLatPoints=lines,
+                           output=out)
+    assert totals.shape == (5, 2)
+    ex = numpy.array(exactFlux(PSI_ZT, eval(T_OPEN), 4, 5))
+    assert numpy.abs(totals[:, 0] - ex).max() <= 1e-12 * numpy.abs(ex).max()
+    assert numpy.abs(totals[:, 1]).max() <= 1e-12 * numpy.abs(ex).max()
+    rows = open(out).read().strip().split('\n')
+    assert rows[0].startswith('# water flow [A m^2/s]') and rows[1] == 'time,line0,line1' and len(rows) == 7
+    # the reference's own loop (update + getIntegral per step) gives the same numbers
+    pts, _ = fluxplot.readTargets(lines)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        fld = Field(prefix + 'T.npz', prefix + 'U.npz', prefix + 'V.npz', pts)
+    for itime in range(fld.nt):
+        fld.update()
+        step = [pli.getIntegral(fld.integratedVelocity, mint.CELL_BY_CELL_DATA) for pli in fld.plis]
+        assert step == list(totals[itime])
+        fld.timeIndex = (fld.timeIndex + 1) % fld.nt
+    # README.md:32 style (a single polyline without the outer list) is accepted
+    single, names = fluxplot.readTargets("(-180,-70),(-160,-10),(-35,40)")
+    assert len(single) == 1 and single[0].shape == (3, 3)
+
+
+def test_hipgraph_replay_equals_direct_launches():
+    """computeAll on a non-null stream captures the whole pass (4 launches per time step) into a hipGraph and replays
+    it; results are bit-identical to direct launches, and a change of configuration re-captures."""
+    import torch
+    from nemoflux_amd.dist import slab_range
+    dg = device_case(72, 36, 5, 8, PSI_ZT)
+    tr = [transect_xyz(T_OPEN), transect_xyz(T_TRI)]
+    args = (dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, tr)
+    direct = quiet_field(*args, readback=False)                       # null stream: direct launches
+    dtot, dseg = direct.computeAll()
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        g = quiet_field(*args, readback=False, stream=st.cuda_stream)
+        out = torch.zeros((8, g._rowlen), dtype=torch.float64, device='cuda')
+        for rep in range(3):                                          # capture, then two replays
+            gtot, gseg = g.computeAll(out=out)
+            assert numpy.array_equal(gtot, dtot) and numpy.array_equal(gseg, dseg)
+        # ownership change -> new graph
+        import ctypes
+        from nemoflux_amd._lib import lib, check
+        sr = slab_range(8, 5, 0, 2)
+        check(lib.nf_field_set_slab_range(ctypes.byref(g._h), sr[0], sr[1]))
+        half, _ = g.computeAll(out=out)
+        assert numpy.all(half[4:] == 0) and numpy.array_equal(half[:4], dtot[:4])
+    torch.cuda.synchronize()
