@@ -33,6 +33,9 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'NF_FORCE_DEVICE' in os.environ:      # rehearsal of N ranks on a one-GPU box (with NF_DIST_BACKEND=gloo)
+        local = int(os.environ['NF_FORCE_DEVICE'])
+    backend = backend or os.environ.get('NF_DIST_BACKEND')
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'

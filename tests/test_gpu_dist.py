@@ -1,0 +1,82 @@
+"""GPU parity, part 3: the N>1 path with the REAL engine.  Two processes share the one GPU of the test box (RCCL needs
+one GPU per rank, so the collective runs over gloo on host tensors here); each integrates its (t,z) slab range on
+the GPU, one all_reduce combines the rows, and rank 0 compares with the single-rank result.  The RCCL/xGMI path itself is
+exercised by the driver's multi-GPU bench."""
+import os
+import socket
+import sys
+
+import numpy
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+PSI = "(1+10*z)*(t+1)*(cos(2*pi*y/360) + sin(2*pi*x/360))"
+TRANSECTS = [[(-100., -80., 0.), (100., -80., 0.), (0., 80., 0.)],
+             [(-100., -80., 0.), (100., -80., 0.), (0., 80., 0.), (-100., -80., 0.)],
+             [(-170., 10., 0.), (-20., -55., 0.), (135., 62., 0.)]]
+NX, NY, NZ, NT = 180, 90, 7, 5     # 35 slabs over 2 ranks: rank 0 ends in the middle of time step 2
+
+
+def _rows(rank, world, local_window):
+    import contextlib
+    import io
+    from nemoflux_amd import dist as nfdist
+    from nemoflux_amd._lib import DeviceArray
+    from nemoflux_amd.datagen import DataGen
+    from nemoflux_amd.field import Field
+    dg = DataGen()
+    dg.setSizes(NX, NY, NZ, NT)
+    dg.setBoundingBox(-180., 180., -90., 90., 0., 1.)
+    dg.build()
+    dg.applyStreamFunction(PSI)
+    sr = nfdist.slab_range(NT, NZ, rank, world)
+    if local_window:   # hold only the touched time steps, address them through the virtual global base
+        t0, t1 = nfdist.time_steps_touched(sr, NZ)
+        u, v = dg.computeUVFromPotential(t0, t1)
+        ug = DeviceArray(nfdist.virtual_base(u, t0 * NZ, NY * NX), (NT, NZ, NY, NX), 'float64', u)
+        vg = DeviceArray(nfdist.virtual_base(v, t0 * NZ, NY * NX), (NT, NZ, NY, NX), 'float64', v)
+    else:
+        ug, vg = dg.computeUVFromPotential()
+    with contextlib.redirect_stdout(io.StringIO()):
+        fld = Field.fromArrays(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, ug, vg,
+                               [numpy.array(t) for t in TRANSECTS], slab_range=sr, readback=False)
+    out = torch.zeros((NT, fld._rowlen), dtype=torch.float64, device='cuda')
+    fld.computeAll(out=out)
+    return out
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0')
+    import torch.distributed as dist
+    from nemoflux_amd import dist as nfdist
+    nfdist.init_from_env(backend='gloo')
+    rows = _rows(rank, world, local_window=True).cpu()
+    nfdist.reduce_rows(rows)
+    if rank == 0:
+        numpy.save(out_path, rows.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_gloo(tmp_path):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'rows.npy')
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = numpy.load(out)
+    full = _rows(0, 1, local_window=False).cpu().numpy()
+    assert got.shape == full.shape
+    assert numpy.allclose(got, full, rtol=1e-13, atol=1e-13 * numpy.abs(full).max())
+    from nemoflux_amd.fluxexact import exactFlux
+    nseg = sum(len(t) - 1 for t in TRANSECTS)
+    ex = numpy.array(exactFlux(PSI, TRANSECTS[0], NZ, NT))
+    assert numpy.abs(got[:, nseg + 0] - ex).max() <= 1e-12 * numpy.abs(ex).max()
+    assert numpy.abs(got[:, nseg + 1]).max() <= 1e-12 * numpy.abs(ex).max()
