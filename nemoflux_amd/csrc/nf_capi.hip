@@ -335,7 +335,7 @@ int mnt_polylineintegral_getIntegralDev(PolylineIntegral_t **self, const double 
     NF_REQUIRE(placement == MNT_CELL_BY_CELL_DATA, NF_ERR_ARG,
                "mnt_polylineintegral_getIntegral: only CELL_BY_CELL_DATA is supported (field.py:102)");
     NF_NEED_DEVICE();
-    NF_TRY(launch_integral(p->ws, data_dev, p->grid->ncell, 0, p->d_tr_off, 1, p->d_scratch, p->d_row, nullptr));
+    NF_TRY(launch_integral(p->ws, data_dev, p->grid->ncell, 0, 0, p->d_tr_off, 1, p->d_scratch, p->d_row, nullptr));
     std::vector<double> row((size_t)p->nseg + 1);
     NF_HIP(hipMemcpy(row.data(), p->d_row, sizeof(double) * row.size(), hipMemcpyDeviceToHost));
     *result = row[p->nseg];
@@ -659,8 +659,8 @@ static int field_step_async(nf_field *f, long t, double *row_dev)
     }
     if (row_dev && rowlen > 0) {
         NF_REQUIRE(f->weights_built, NF_ERR_STATE, "compute: build_weights first");
-        NF_TRY(launch_integral(f->ws, f->d_iV, f->ncell, 1, f->d_tr_off, (int)f->polylines.size(), f->d_scratch,
-                               row_dev, f->stream));
+        NF_TRY(launch_integral(f->ws, f->d_iV, f->ncell, 2, f->nx, f->d_tr_off, (int)f->polylines.size(),
+                               f->d_scratch, row_dev, f->stream));
     }
     return NF_OK;
 }

@@ -89,9 +89,10 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
 // K3: gather + wavefront segmented reduction -> per-segment sums, then per-transect sums.
 // row: (nseg + ntransect) doubles in HBM; tr_offsets_dev: (ntransect+1) segment offsets.
 // scratch: at least ws.nrec doubles.
-// data: (ncell,4) AoS (planes = 0) or the resident [4][ncell] planes (planes = 1).
-int launch_integral(const WeightSet &ws, const double *data, long ncell, int planes, const int *tr_offsets_dev,
-                    int ntransect, double *scratch, double *row, hipStream_t s);
+// data: (ncell,4) AoS (planes = 0), [4][ncell] planes (planes = 1), or the engine's own planes read through their two
+// signed members only (planes = 2; needs nx for the neighbour indexing).
+int launch_integral(const WeightSet &ws, const double *data, long ncell, int planes, long nx,
+                    const int *tr_offsets_dev, int ntransect, double *scratch, double *row, hipStream_t s);
 
 // VectorInterp (field.py:90-95,119-120)
 // targets_dev: caller order (n,3); sorted_dev: the same points sorted by y; order_dev: caller index of sorted point q

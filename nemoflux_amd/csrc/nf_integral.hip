@@ -20,7 +20,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_segscan(const int *__restrict
                                                            const double *__restrict__ w4,
                                                            const int *__restrict__ seg, long n,
                                                            const double *__restrict__ data, long ncell,
-                                                           int planes, double *__restrict__ runsum)
+                                                           int planes, unsigned nx, double *__restrict__ runsum)
 {
     const long k = (long)blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
@@ -31,7 +31,17 @@ __global__ __launch_bounds__(kBlock) void k_gather_segscan(const int *__restrict
         const double2 *pw = reinterpret_cast<const double2 *>(w4 + 4 * k);
         const double2 wa = pw[0], wb = pw[1];
         double d0, d1, d2, d3;
-        if (planes) {
+        if (planes == 2) {
+            // the engine's own planes: the south and west slots are copies of the neighbours' north and east values
+            // (field.py:219-223), so only the two signed planes are touched: eU[c-1], eU[c] share a sector and
+            // eV[c-nx] is the eV[c] of the record one row below -- about half the sectors of four separate planes
+            const unsigned j = (unsigned)(c / nx), i = (unsigned)(c - (long)j * nx);
+            const double *eU = data + ncell, *eV = data + 2 * ncell;
+            d1 = eU[c];
+            d2 = eV[c];
+            d0 = j > 0 ? eV[c - nx] : 0.0;               // row 0's south slot is never written (field.py:219)
+            d3 = eU[i > 0 ? c - 1 : c - 1 + nx];         // column 0: periodic copy of column nx-1 (field.py:223)
+        } else if (planes) {
             d0 = data[c];
             d1 = data[ncell + c];
             d2 = data[2 * ncell + c];
@@ -90,12 +100,12 @@ __global__ __launch_bounds__(kBlock) void k_finalize_tr(const int *__restrict__ 
     if (lane == 0) row[nseg + p] = part;
 }
 
-int launch_integral(const WeightSet &ws, const double *data, long ncell, int planes, const int *tr_offsets_dev,
-                    int ntransect, double *scratch, double *row, hipStream_t s)
+int launch_integral(const WeightSet &ws, const double *data, long ncell, int planes, long nx,
+                    const int *tr_offsets_dev, int ntransect, double *scratch, double *row, hipStream_t s)
 {
     if (ws.nrec > 0) {
         hipLaunchKernelGGL(k_gather_segscan, dim3((unsigned)((ws.nrec + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                           ws.cell, ws.w4, ws.seg, ws.nrec, data, ncell, planes, scratch);
+                           ws.cell, ws.w4, ws.seg, ws.nrec, data, ncell, planes, (unsigned)(nx > 0 ? nx : 1), scratch);
     }
     if (ws.nseg > 0) {
         const unsigned nb = (unsigned)(((long)ws.nseg * kWave + kBlock - 1) / kBlock);
