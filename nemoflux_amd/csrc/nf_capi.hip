@@ -547,6 +547,7 @@ struct nf_field {
     // resident per-step outputs
     double *d_iV = nullptr;   // [4][ncell]
     double *d_abs = nullptr;  // [2][ncell]
+    double *d_aos = nullptr;  // (ncell,4) re-pack buffer for read_step, allocated on first use
     unsigned long long *d_maxbits = nullptr;
     // transects
     std::vector<std::vector<double>> polylines;
@@ -583,6 +584,7 @@ static int field_free_geometry(nf_field *f)
     dev_free(f->d_box);
     dev_free(f->d_iV);
     dev_free(f->d_abs);
+    dev_free(f->d_aos);
     dev_free(f->d_maxbits);
     return NF_OK;
 }
@@ -946,16 +948,10 @@ int nf_field_read_step(nf_field **self, double *iV_host, double *eU_host, double
     NF_REQUIRE(f->d_iV, NF_ERR_STATE, "nf_field_read_step: set_bounds first");
     NF_NEED_DEVICE();
     const size_t n = (size_t)f->ncell;
-    if (iV_host) {
-        double *d_aos = nullptr;
-        NF_TRY(dev_alloc(&d_aos, n * 4));
-        int rc = launch_planes_to_aos(f->d_iV, f->ncell, d_aos, f->stream);
-        hipError_t e = hipMemcpyAsync(iV_host, d_aos, sizeof(double) * n * 4, hipMemcpyDeviceToHost, f->stream);
-        hipError_t e2 = hipStreamSynchronize(f->stream);
-        dev_free(d_aos);
-        NF_TRY(rc);
-        NF_HIP(e);
-        NF_HIP(e2);
+    if (iV_host) {  // re-pack the planes into the reference's (ncell,4) layout, then one D2H into the caller's array
+        if (!f->d_aos) NF_TRY(dev_alloc(&f->d_aos, n * 4));
+        NF_TRY(launch_planes_to_aos(f->d_iV, f->ncell, f->d_aos, f->stream));
+        NF_HIP(hipMemcpyAsync(iV_host, f->d_aos, sizeof(double) * n * 4, hipMemcpyDeviceToHost, f->stream));
     }
     if (eU_host) NF_HIP(hipMemcpyAsync(eU_host, f->d_abs, sizeof(double) * n, hipMemcpyDeviceToHost, f->stream));
     if (eV_host) NF_HIP(hipMemcpyAsync(eV_host, f->d_abs + n, sizeof(double) * n, hipMemcpyDeviceToHost, f->stream));

@@ -73,6 +73,23 @@ class _TimeObj(object):
         return f'{timeIndex}' if self.timeValues is None else f'{self.timeValues[timeIndex]}'
 
 
+class _PinnedBlock(object):
+    """Owner of one pinned host allocation; freed when the last numpy view of it is gone (VTK may outlive the Field)."""
+
+    def __init__(self, nbytes):
+        p = ctypes.c_void_p()
+        check(lib.nf_host_alloc(ctypes.byref(p), max(int(nbytes), 8)))
+        self.ptr = p.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib.nf_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
 class _Transect(object):
     """Entry of Field.plis: quacks like mint.PolylineIntegral.getIntegral (fluxplot.py:56).
 
@@ -213,7 +230,6 @@ class Field(object):
         self._arc = None
 
         # --- host mirrors of the per-step arrays (field.py:59-63); pinned, updated in place
-        self._pinned = []
         self.edgeFluxesUArray = self._host_zeros((numCells,))
         self.edgeFluxesVArray = self._host_zeros((numCells,))
         self.integratedVelocity = self._host_zeros((numCells, 4))
@@ -254,11 +270,12 @@ class Field(object):
 
     # ------------------------------------------------------------------------------------------
     def _host_zeros(self, shape):
+        """Pinned host array (fast D2H target); the allocation lives as long as any view of the array."""
         n = int(numpy.prod(shape))
-        p = ctypes.c_void_p()
-        check(lib.nf_host_alloc(ctypes.byref(p), max(n, 1) * 8))
-        self._pinned.append(p.value)
-        a = numpy.ctypeslib.as_array((ctypes.c_double * max(n, 1)).from_address(p.value))[:n].reshape(shape)
+        block = _PinnedBlock(max(n, 1) * 8)
+        buf = (ctypes.c_double * max(n, 1)).from_address(block.ptr)
+        buf._owner = block  # the ctypes object is the numpy array's base: it keeps the block alive
+        a = numpy.ctypeslib.as_array(buf)[:n].reshape(shape)
         a[...] = 0.0
         return a
 
@@ -266,9 +283,6 @@ class Field(object):
         try:
             if getattr(self, '_h', None):
                 lib.nf_field_del(ctypes.byref(self._h))
-            for p in getattr(self, '_pinned', []):
-                lib.nf_host_free(p)
-            self._pinned = []
         except Exception:
             pass
 

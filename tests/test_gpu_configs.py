@@ -476,3 +476,19 @@ def test_hipgraph_replay_equals_direct_launches():
         half, _ = g.computeAll(out=out)
         assert numpy.all(half[4:] == 0) and numpy.array_equal(half[:4], dtot[:4])
     torch.cuda.synchronize()
+
+
+def test_host_arrays_outlive_the_field():
+    """VTK keeps raw pointers into Field's arrays (fluxviz.py:148,160,168): the pinned buffers must stay valid for as
+    long as a view of them exists, even after the Field is gone; repeated construction must not leak."""
+    import gc
+    g = load_golden('def36_zt')
+    keep = []
+    for rep in range(20):
+        f = quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], g['u'], g['v'], [transect_xyz(T_OPEN)])
+        keep = [f.integratedVelocity, f.edgeFluxesUArray]
+        ref = f.integratedVelocity.copy()
+        del f
+        gc.collect()
+        assert numpy.array_equal(keep[0], ref)      # still readable, same content
+        keep[0][0, 0] = 1.0                         # and writable
