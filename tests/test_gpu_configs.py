@@ -492,3 +492,53 @@ def test_host_arrays_outlive_the_field():
         gc.collect()
         assert numpy.array_equal(keep[0], ref)      # still readable, same content
         keep[0][0, 0] = 1.0                         # and writable
+
+
+def test_real_orca025_subset_geometry_f32_land_sverdrup(oracle):
+    """The README's real-data example (README.md:108: data/sa, -s, S3_sa.txt; pictures/sa.png) with what survives of
+    it: the REAL curvilinear ORCA025 geometry (float32 bounds, 75 uneven levels from data/sa/T.nc) and the real
+    station file; U.nc/V.nc are missing from the reference (.MISSING_LARGE_BLOBS), so float32 velocities with a land
+    mask (_FillValue 1e20 and NaN) are drawn from a seeded generator.  GPU vs oracle, Sverdrup units."""
+    import json
+    b = load_golden('sa_T_bounds')
+    with open(os.path.join(GOLDEN, 'stations.json')) as f:
+        ll = numpy.array(json.load(f)['sa/S3_sa.txt'])
+    xyz = numpy.zeros((ll.shape[0], 3))
+    xyz[:, :2] = ll
+    ny, nx, nz, nt = 100, 100, 75, 3
+    rng = numpy.random.default_rng(42)
+    u = (0.3 * rng.standard_normal((nt, nz, ny, nx))).astype(numpy.float32)
+    v = (0.3 * rng.standard_normal((nt, nz, ny, nx))).astype(numpy.float32)
+    land = rng.random((ny, nx)) < 0.2
+    u[:, :, land] = numpy.float32(1.e20)
+    v[:, :, land] = numpy.nan
+    u[:, 40:, :, :] = numpy.where(rng.random((ny, nx)) < 0.3, numpy.float32(1.e20), u[:, 40:, :, :])   # bathymetry
+    fld = quiet_field(b['bounds_lon'], b['bounds_lat'], b['deptht_bounds'], u, v, [xyz], sverdrup=True,
+                      fill_value=1.e20, periodX=360.)
+    assert (fld.nt, fld.nz, fld.ny, fld.nx) == (nt, nz, ny, nx)
+    assert abs(fld.lonmin - 12.625) < 1e-6 and abs(fld.latmax - (-20.662027)) < 1e-5
+    pts = oracle.assemble_points(b['bounds_lon'], b['bounds_lat'])
+    assert numpy.array_equal(fld.gr.getPoints(), pts)
+    th = (b['deptht_bounds'][:, 1] - b['deptht_bounds'][:, 0]).astype(numpy.float64)
+    assert numpy.array_equal(fld.thickness, th)
+    ow = oracle.polyline_weights(pts, xyz)
+    st = oracle.EdgeFluxState(ny, nx)
+    for t in range(nt):
+        fld.timeIndex = t
+        fld.update()
+        oracle.edge_flux(st, oracle.vertical_integral(u[t], th, 1.e20), oracle.vertical_integral(v[t], th, 1.e20),
+                         fld.arcLengths, True)
+        assert numpy.array_equal(fld.integratedVelocity, st.integratedVelocity)
+        assert numpy.array_equal(fld.edgeFluxesVArray, st.edgeFluxesV)
+        assert fld.maxAbsFlux == st.maxAbsFlux.value
+        want = oracle.get_integral(ow, st.integratedVelocity)
+        got = fld.plis[0].getIntegral(fld.integratedVelocity)
+        assert abs(got - want) <= 1e-12 * numpy.abs(ow.weight * st.integratedVelocity.reshape(-1)[ow.cell_edge]).sum()
+        assert fld.getFluxText().endswith('(Sv) ')
+    ce, w, sg = fld.getWeights()
+    gd = dict(zip(zip(sg.tolist(), ce.tolist()), w.tolist()))
+    od = ow.as_dict()
+    assert set(gd) == set(od) and max(abs(gd[k] - od[k]) for k in od) <= 1e-12
+    # the arrows exist on the target line and sit inside the grid
+    ids, _ = fld.vinterp.getCells()
+    assert fld.vectorPoints.shape[0] > 50 and (ids >= 0).all()
