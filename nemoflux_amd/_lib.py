@@ -114,9 +114,6 @@ _sig('nf_datagen_bounds', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctyp
 _sig('nf_datagen_uv', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_long] * 6 + [ctypes.c_double] * 6 +
      [ctypes.c_int, ctypes.c_int, ctypes.c_void_p])
 
-# every symbol include/nemoflux_amd.h declares (tests/test_abi.py checks the header against this list)
-EXPORTS = [n for n in dir(lib) if False]  # filled lazily by tests from the header itself
-
 
 class NemofluxError(RuntimeError):
     """A non-zero return code of the C ABI (the reference raises RuntimeError: field.py:135,154)."""

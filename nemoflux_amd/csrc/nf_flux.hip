@@ -204,7 +204,10 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
                     }
                     tmax = fmax(tmax, fmax(fabs(eU[k]), fabs(eV[k])));
                 }
-                if (DIAG & 16) {  // only the two signed planes (the rest comes from k_expand_planes)
+                if (DIAG & 32) {  // diagnostic: ONE interleaved (eU,eV) stream, 32 B per lane
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) store2(iV + 2 * (c0 + k), eU[k], eV[k], true);
+                } else if (DIAG & 16) {  // only the two signed planes (the rest comes from k_expand_planes)
 #pragma unroll
                     for (int k = 0; k < VEC; k += 2) {
                         store2(iV + ncell + c0 + k, eU[k], eU[k + 1], true);
@@ -479,6 +482,7 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
         case 21: return launch_flux_t<T, VEC, 4, true, 256, 1, false, 1>(a, s);   // no stores
         case 25: return launch_flux_t<T, VEC, 4, true, 256, 1, false, 5>(a, s);   // no stores, no atomic max
         case 28: return launch_flux_t<T, VEC, 4, true, 256, 1, false, 16>(a, s);  // only the two signed planes
+        case 29: return launch_flux_t<T, VEC, 4, true, 256, 1, false, 32>(a, s);  // one interleaved (eU,eV) stream
         case 45: return launch_flux_ww<T, VEC, 2, 2>(a, s);                        // writer-wave, no stores
         default: return launch_flux_t<T, VEC, 4, true, 256, 1, false>(a, s);
     }

@@ -242,7 +242,7 @@ class Field(object):
         self._lonlat = None
         # arrow seed points along the target lines (field.py:71-87)
         vectorPoints = []
-        self.uVectors = []
+        uVectors = []
         for lonlatpts in self._polylines:
             for i in range(len(lonlatpts) - 1):
                 begPoint = numpy.array(lonlatpts[i])
@@ -254,10 +254,12 @@ class Field(object):
                 u /= distance
                 nvpts = max(2, int(distance / self.dx))
                 vdx = distance / float(nvpts - 1)
-                for j in range(nvpts):
-                    vectorPoints.append(begPoint + u * j * vdx)
-                    self.uVectors.append(u)
-        self.vectorPoints = numpy.array(vectorPoints) if vectorPoints else numpy.zeros((0, 3))
+                # begPoint + u*j*vdx for j in range(nvpts) (field.py:84-86), vectorised over j
+                vectorPoints.append(begPoint + (u * numpy.arange(nvpts)[:, None]) * vdx)
+                uVectors.append(numpy.broadcast_to(u, (nvpts, 3)))
+        self.uVectors = numpy.concatenate(uVectors) if uVectors else numpy.zeros((0, 3))
+        vectorPoints = numpy.concatenate(vectorPoints) if vectorPoints else []
+        self.vectorPoints = numpy.ascontiguousarray(vectorPoints) if len(vectorPoints) else numpy.zeros((0, 3))
         # compute the vector at the target line (field.py:89-95), from the resident planes (no host round trip)
         self.vectorValues = numpy.zeros((self.vectorPoints.shape[0], 3), numpy.float64)
         self.vinterp = None
