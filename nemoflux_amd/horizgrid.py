@@ -58,3 +58,19 @@ class HorizGrid(object):
     def dump(self, fileName):
         """Dump the grid data to a VTK file (horizgrid.py:38-43)."""
         self.grid.dump(fileName)
+
+
+def main(*, tFile):
+    """Create the grid and dump it next to the T file as legacy VTK (horizgrid.py:45-52)."""
+    import re
+    gr = HorizGrid(tFile)
+    vtkFile = re.sub(r'\.(nc|npz)$', '.vtk', str(tFile))
+    gr.dump(vtkFile)
+    return vtkFile
+
+
+if __name__ == '__main__':
+    import argparse
+    ap = argparse.ArgumentParser(description='Create grid')
+    ap.add_argument('-t', '--tFile', required=True, help='file containing t grid data (NetCDF via xarray, or .npz)')
+    main(**vars(ap.parse_args()))

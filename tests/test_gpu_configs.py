@@ -296,7 +296,11 @@ def test_grid_dump_horizgrid_and_npz_files(tmp_path):
     hg = HorizGrid(prefix + 'T.npz')
     assert hg.getNumCells() == 648 and hg.getPoints().shape == (648, 4, 3)
     assert list(hg.getPoint(0, 0)) == [-180.0, -90.0, 0.0] and list(hg.getPoint(647, 2)) == [180.0, 90.0, 0.0]
+    from nemoflux_amd.horizgrid import main as horizgrid_main
+    assert horizgrid_main(tFile=prefix + 'T.npz') == prefix + 'T.vtk'      # horizgrid.py:45-52
+    txt0 = open(prefix + 'T.vtk').read()
     hg.dump(prefix + 'T.vtk')
+    assert open(prefix + 'T.vtk').read() == txt0
     txt = open(prefix + 'T.vtk').read().split('\n')
     assert txt[3] == 'DATASET UNSTRUCTURED_GRID' and txt[4] == 'POINTS 2592 double' and 'CELL_TYPES 648' in txt
     pts = [(-180., -70., 0.), (-160., -10., 0.), (-35., 40., 0.), (20., -50., 0.), (60., 50., 0.), (180., 40., 0.)]
