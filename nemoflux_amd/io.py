@@ -1,24 +1,55 @@
 """File access for the Field/HorizGrid constructors (nemoflux/field.py:22-25,34-35).
 
-The reference reads NetCDF through xarray.  This image has neither xarray nor netCDF4, so:
-  * NetCDF files are read through xarray IF it is importable (same variable names: bounds_lat,
-    bounds_lon, deptht_bounds, uo, vo; _FillValue decoded by hand), and
+The reference reads NetCDF through xarray.  This image has neither xarray nor netCDF4 in its main interpreter, so:
   * `.npz` bundles with the same variable names are always accepted (nemoflux_amd.datagen.DataGen.save
-    writes them): <prefix>T.npz, <prefix>U.npz, <prefix>V.npz.
+    writes them): <prefix>T.npz, <prefix>U.npz, <prefix>V.npz;
+  * NetCDF files are read through xarray IF it is importable (same variable names: bounds_lat,
+    bounds_lon, deptht_bounds, uo, vo; _FillValue kept, not decoded);
+  * otherwise a NetCDF-4/HDF5 file is converted once by tools/nc2npz.py under any interpreter that has h5py
+    (probed: the running one, /opt/conda/bin/python3.9, python3) -- a compatibility path through the file system.
 NetCDF/HDF5 ingest straight to HBM is SURVEY.md 8f rank 3 ("next").
 """
+import os
+import subprocess
+import sys
+import tempfile
+
 import numpy
+
+_NC2NPZ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'nc2npz.py')
+_H5_PYTHONS = [sys.executable, '/opt/conda/bin/python3.9', 'python3']
+
+
+def _convert_with_h5py(path):
+    """Child-process conversion; returns the dict of arrays or None if no interpreter with h5py is found."""
+    if not os.path.exists(_NC2NPZ):
+        return None
+    for py in _H5_PYTHONS:
+        with tempfile.TemporaryDirectory() as tmp:
+            dst = os.path.join(tmp, 'converted.npz')
+            try:
+                r = subprocess.run([py, _NC2NPZ, path, dst], capture_output=True, timeout=3600)
+            except (OSError, subprocess.TimeoutExpired):
+                continue
+            if r.returncode == 0 and os.path.exists(dst):
+                return dict(numpy.load(dst, allow_pickle=False))
+    return None
 
 
 def _open(path):
     path = str(path)
     if path.endswith('.npz'):
         return dict(numpy.load(path, allow_pickle=False))
+    if not os.path.exists(path):
+        raise RuntimeError(f'ERROR: cannot read {path}: no such file')
     try:
         import xarray
     except ImportError as e:
-        raise RuntimeError(f'ERROR: cannot read {path}: xarray/netCDF4 are not installed; '
-                           'use the .npz bundles written by nemoflux_amd.datagen') from e
+        d = _convert_with_h5py(path)
+        if d is not None:
+            return d
+        raise RuntimeError(f'ERROR: cannot read {path}: neither xarray/netCDF4 nor an interpreter with h5py is '
+                           'available; use the .npz bundles written by nemoflux_amd.datagen') from e
     out = {}
     with xarray.open_dataset(path, mask_and_scale=False) as nc:
         for k in nc.variables:

@@ -109,3 +109,25 @@ def test_get_sizes_and_flux_text_format():
         f.getSizes((1, 2, 3, 4, 5))
     txt = ''.join(f"{v:4.3g}, " for v in (360.0, -0.318)) + "(Sv) "
     assert _re.sub(r',\s*\(', ' (', txt) == ' 360, -0.318 (Sv) '
+
+
+def test_netcdf4_ingest_of_the_reference_t_file():
+    """nemoflux_amd.io reads the reference's real NetCDF-4 T file (data/sa/T.nc) when some interpreter with h5py exists
+    (this image: /opt/conda/bin/python3.9) and agrees with the committed fixture.  Skipped where the reference tree or
+    h5py is absent (the GPU box has no /root/reference)."""
+    from conftest import load_golden
+    from nemoflux_amd import io
+    src = '/root/reference/data/sa/T.nc'
+    if not os.path.exists(src):
+        pytest.skip('reference tree not present')
+    try:
+        d = io.open_tfile(src)
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    g = load_golden('sa_T_bounds')
+    for k in ('bounds_lon', 'bounds_lat', 'deptht_bounds'):
+        assert d[k].dtype == numpy.float32 and numpy.array_equal(d[k], g[k])
+    with pytest.raises(RuntimeError, match='no such file'):
+        io.open_tfile('/nonexistent/T.nc')
+    with pytest.raises(RuntimeError, match='could not read uo'):
+        io.open_uvfile(src, 'uo')      # field.py:154: the T file holds no velocity
