@@ -233,17 +233,20 @@ def cpu_baseline(dg, u, v, nz, ny, nx, xyz0, args):
         best = min(best, time.perf_counter() - t0)
         reps += 1
     units = float(nz) * ny * nx
-    # the plain-C port, one thread, same step
-    t0 = time.perf_counter()
-    Uc = o.vertical_integral(uh, th)
-    Vc = o.vertical_integral(vh, th)
-    o.edge_flux(o.EdgeFluxState(ny, nx), Uc, Vc, arc)
-    t_c = time.perf_counter() - t0
+    # the plain-C port (OpenMP over columns; OMP_NUM_THREADS or all host cores), same step
+    t_c = 1e30
+    for _ in range(2):
+        t0 = time.perf_counter()
+        Uc = o.vertical_integral(uh, th)
+        Vc = o.vertical_integral(vh, th)
+        o.edge_flux(o.EdgeFluxState(ny, nx), Uc, Vc, arc)
+        t_c = min(t_c, time.perf_counter() - t0)
+    omp = os.environ.get('OMP_NUM_THREADS', str(os.cpu_count()))
     return {'value': units / best, 'unit': 'integrals/s', 'cores': int(threads), 'kind': 'port',
             'sample': f'1 of {args.nt} time steps of the bench workload ({nx}x{ny}x{nz}, {args.dtype}), best of {reps} '
                       f'reps of the numpy restatement of field.py:157-234 (+oracle A7, README transect): '
                       f'{best:.3f} s/step; one-off arc lengths {t_arc:.2f} s, oracle weights {t_w:.2f} s; '
-                      f'single-thread C port of the same step: {units / t_c:.3e} integrals/s; flux {tot:.6g}'}
+                      f'C port of the same step with OpenMP ({omp} threads): {units / t_c:.3e} integrals/s; flux {tot:.6g}'}
 
 
 if __name__ == '__main__':

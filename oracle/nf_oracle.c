@@ -86,9 +86,13 @@ void nfo_vertical_integral(const void *f, int is_f32, long nz, long ncell, const
     const double *fd = (const double *)f;
     const float *ff = (const float *)f;
     const float fillf = (float)fill;
+    /* columns are independent: with -fopenmp (and OMP_NUM_THREADS > 1) they are split over the host cores; every
+     * column still runs the same sequential fma chain over z, so the result does not depend on the thread count */
+#pragma omp parallel for schedule(static)
     for (long c = 0; c < ncell; ++c) out[c] = 0.0;
     for (long z = 0; z < nz; ++z) {
         double th = thickness[z];
+#pragma omp parallel for schedule(static)
         for (long c = 0; c < ncell; ++c) {
             double x;
             if (is_f32) {

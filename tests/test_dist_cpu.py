@@ -86,3 +86,21 @@ def test_two_rank_gloo_reduce_matches_single(name, oracle, cases, tmp_path):
     assert numpy.allclose(got, full, rtol=1e-13, atol=1e-13 * numpy.abs(full).max())
     # nz = 3, nt = 2 cut in two: rank 0 owns (t0: z0..2), rank 1 owns (t1: z0..2) for rot36 -> also try uneven
     assert got.shape == (m['nt'], len(m['transects']))
+
+
+def test_bench_transects_are_seeded_and_clear_of_column_zero():
+    """bench.py's batch (config C5): deterministic, node-snapped, |lat| <= 80, inside the lon box and clear of column 0
+    (whose west slot is the periodic copy of column nx-1, field.py:223 -- psi of the bench is not x-periodic)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.make_transects(3600, 1800, -180., 180., -90., 90., 64)
+    b = bench.make_transects(3600, 1800, -180., 180., -90., 90., 64)
+    assert a == b and len(a) == 65 and a[0][0] == (-180., -80.)
+    dx = 0.1
+    for k, poly in enumerate(a[1:]):
+        xy = numpy.array(poly)
+        assert 8 <= len(poly) <= 65
+        assert xy[:, 0].min() >= -180. + dx - 1e-9 and xy[:, 0].max() <= 180. + 1e-9
+        assert numpy.abs(xy[:, 1]).max() <= 80. + 1e-9
+        assert numpy.allclose(numpy.round((xy[:, 0] + 180.) / dx) * dx - 180., xy[:, 0], atol=1e-9)   # on nodes
+        assert (poly[0] == poly[-1]) == (k % 2 == 1)                                              # half are closed
