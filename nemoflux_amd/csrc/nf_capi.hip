@@ -63,6 +63,9 @@ static void dev_free(T *&p)
 
 using namespace nf;
 
+// 1 = compute_all may put all time steps of a small grid into one launch per kernel ("batch_steps" tuning knob)
+static int g_batch_steps = (getenv("NF_BATCH_STEPS") && atoi(getenv("NF_BATCH_STEPS")) == 0) ? 0 : 1;
+
 // =============================================================================================== plumbing
 extern "C" {
 
@@ -135,6 +138,10 @@ int nf_memset(void *dev, int value, size_t bytes)
 int nf_tuning_set(const char *name, int value)
 {
     NF_REQUIRE(name, NF_ERR_ARG, "nf_tuning_set: null name");
+    if (!strcmp(name, "batch_steps")) {
+        g_batch_steps = value;
+        return NF_OK;
+    }
     int rc = tuning_set(name, value);
     NF_REQUIRE(rc == NF_OK, NF_ERR_ARG, std::string("nf_tuning_set: unknown knob ") + name);
     return NF_OK;
@@ -548,6 +555,10 @@ struct nf_field {
     double *d_iV = nullptr;   // [4][ncell]
     double *d_abs = nullptr;  // [2][ncell]
     double *d_aos = nullptr;  // (ncell,4) re-pack buffer for read_step, allocated on first use
+    // multi-step launches for small grids (compute_all): per-step planes, scratch and z ranges
+    double *d_iVb = nullptr, *d_absb = nullptr, *d_scratchb = nullptr;
+    int *d_zr = nullptr;
+    long batch_steps = 0, batch_version = -1;
     unsigned long long *d_maxbits = nullptr;
     // transects
     std::vector<std::vector<double>> polylines;
@@ -585,6 +596,12 @@ static int field_free_geometry(nf_field *f)
     dev_free(f->d_iV);
     dev_free(f->d_abs);
     dev_free(f->d_aos);
+    dev_free(f->d_iVb);
+    dev_free(f->d_absb);
+    dev_free(f->d_scratchb);
+    dev_free(f->d_zr);
+    f->batch_steps = 0;
+    f->batch_version = -1;
     dev_free(f->d_maxbits);
     return NF_OK;
 }
@@ -664,6 +681,83 @@ static int field_step_async(nf_field *f, long t, double *row_dev)
         NF_TRY(launch_integral(f->ws, f->d_iV, f->ncell, 2, f->nx, f->d_tr_off, (int)f->polylines.size(),
                                f->d_scratch, row_dev, f->stream));
     }
+    return NF_OK;
+}
+
+// All nt steps in FOUR launches (flux kernel with blockIdx.y = step, then the three reduction kernels): small grids
+// are launch-bound (4 launches of a few microseconds per step otherwise).  Needs HBM-resident fields and per-step
+// planes (nt x 48 B per cell), so it is used while nt*ncell stays under kBatchCellSteps.
+constexpr long kBatchCellSteps = 32l << 20;
+
+static bool field_can_batch(const nf_field *f)
+{
+    return g_batch_steps && f->uv_on_device && !f->timing && f->nt >= 2 && f->nt < 65536 && f->nt * f->ncell <= kBatchCellSteps &&
+           f->weights_built;
+}
+
+static int field_all_steps_batched(nf_field *f, double *rows_dev)
+{
+    const int rowlen = field_row_length(f);
+    const size_t n = (size_t)f->ncell;
+    if (f->batch_steps != f->nt) {
+        dev_free(f->d_iVb);
+        dev_free(f->d_absb);
+        dev_free(f->d_zr);
+        NF_TRY(dev_alloc(&f->d_iVb, n * 4 * f->nt));
+        NF_TRY(dev_alloc(&f->d_absb, n * 2 * f->nt));
+        NF_TRY(dev_alloc(&f->d_zr, (size_t)2 * f->nt));
+        // south slots of row 0 are never written (field.py:219): every step's planes start as zeros
+        NF_HIP(hipMemsetAsync(f->d_iVb, 0, sizeof(double) * n * 4 * f->nt, f->stream));
+        f->batch_steps = f->nt;
+        f->batch_version = -1;
+    }
+    if (f->batch_version != f->version) {  // scratch follows the weight set, z ranges follow the slab ownership
+        dev_free(f->d_scratchb);
+        NF_TRY(dev_alloc(&f->d_scratchb, (size_t)f->ws.nrec * f->nt));
+        std::vector<int> zr((size_t)2 * f->nt);
+        const long s_end = f->s_end < 0 ? f->nt * f->nz : f->s_end;
+        for (long t = 0; t < f->nt; ++t) {
+            long lo = t * f->nz, hi = (t + 1) * f->nz;
+            if (lo < f->s_begin) lo = f->s_begin;
+            if (hi > s_end) hi = s_end;
+            if (hi < lo) hi = lo;
+            zr[2 * t] = (int)(lo - t * f->nz);
+            zr[2 * t + 1] = (int)(hi - t * f->nz);
+        }
+        NF_HIP(hipMemcpy(f->d_zr, zr.data(), sizeof(int) * zr.size(), hipMemcpyHostToDevice));
+        f->batch_version = f->version;
+    }
+    FluxArgs a{};
+    a.u = f->u;
+    a.v = f->v;
+    a.dtype = f->uv_dtype;
+    a.ncell = f->ncell;
+    a.ny = f->ny;
+    a.nx = f->nx;
+    a.z0 = 0;
+    a.z1 = (int)f->nz;
+    a.thickness = f->d_thick;
+    a.arcE = f->d_arcE;
+    a.arcN = f->d_arcN;
+    a.fill = f->fill;
+    a.scale = kEarthRadiusSv / 1.e6;
+    a.sverdrup = f->sverdrup;
+    a.iV = f->d_iVb;
+    a.absU = f->d_absb;
+    a.absV = f->d_absb + f->ncell;
+    a.maxbits = f->d_maxbits;
+    a.batch.nsteps = (int)f->nt;
+    a.batch.in_stride = f->nz * f->ncell;
+    a.batch.zr = f->d_zr;
+    NF_TRY(launch_flux(a, f->stream));
+    if (rowlen > 0)
+        NF_TRY(launch_integral(f->ws, f->d_iVb, f->ncell, 2, f->nx, f->d_tr_off, (int)f->polylines.size(), f->d_scratchb,
+                               rows_dev, f->stream, (int)f->nt, (long)(4 * n), rowlen));
+    // the resident single-step arrays keep their meaning: they hold the LAST step (what read_step returns)
+    NF_HIP(hipMemcpyAsync(f->d_iV, f->d_iVb + (size_t)(f->nt - 1) * 4 * n, sizeof(double) * 4 * n,
+                          hipMemcpyDeviceToDevice, f->stream));
+    NF_HIP(hipMemcpyAsync(f->d_abs, f->d_absb + (size_t)(f->nt - 1) * 2 * n, sizeof(double) * 2 * n,
+                          hipMemcpyDeviceToDevice, f->stream));
     return NF_OK;
 }
 
@@ -907,6 +1001,7 @@ int nf_field_compute_all_async(nf_field **self, double *rows_dev)
     nf_field *f = *self;
     NF_REQUIRE(f->weights_built, NF_ERR_STATE, "nf_field_compute_all_async: build_weights first");
     const int rowlen = field_row_length(f);
+    if (field_can_batch(f)) return field_all_steps_batched(f, rows_dev);
     // Replay a captured graph of the whole pass when nothing changed since it was captured.  Capture needs a real
     // (non-null) stream, resident fields, and no per-launch timing events.
     static const bool use_graph = !(getenv("NF_GRAPH") && atoi(getenv("NF_GRAPH")) == 0);

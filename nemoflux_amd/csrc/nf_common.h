@@ -50,6 +50,14 @@ int launch_corner_table_from_points(const double *points, long ncell, double *xy
 int launch_points_from_corner_table(const double *xy, long ncell, double *points, hipStream_t s);
 double box_key_to_double(unsigned long long k);
 
+// several time steps in one launch (launch-bound small grids): step tb reads u,v + tb*in_stride, integrates levels
+// [zr[2tb], zr[2tb+1]) and writes planes iV + tb*4*ncell, abs + tb*2*ncell.  zr == nullptr: one step (z0, z1).
+struct StepBatch {
+    int nsteps = 0;
+    long in_stride = 0;       // elements of the field dtype between consecutive time steps
+    const int *zr = nullptr;  // device, 2*nsteps
+};
+
 // K1: vertical integral of one time step's slabs [z0,z1) + edge fluxes (the bandwidth-bound kernel).
 struct FluxArgs {
     const void *u, *v;        // base of the time step: (nz, ncell)
@@ -63,6 +71,7 @@ struct FluxArgs {
     int sverdrup;
     double *iV, *absU, *absV; // resident outputs
     unsigned long long *maxbits;  // running max as the bits of a non-negative double
+    StepBatch batch;
 };
 int launch_flux(const FluxArgs &a, hipStream_t s);
 int tuning_set(const char *name, int value);
@@ -91,8 +100,10 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
 // scratch: at least ws.nrec doubles.
 // data: (ncell,4) AoS (planes = 0), [4][ncell] planes (planes = 1), or the engine's own planes read through their two
 // signed members only (planes = 2; needs nx for the neighbour indexing).
+// nsteps > 1: step tb gathers from data + tb*data_stride and writes row + tb*row_stride (scratch: nsteps*ws.nrec).
 int launch_integral(const WeightSet &ws, const double *data, long ncell, int planes, long nx,
-                    const int *tr_offsets_dev, int ntransect, double *scratch, double *row, hipStream_t s);
+                    const int *tr_offsets_dev, int ntransect, double *scratch, double *row, hipStream_t s,
+                    int nsteps = 1, long data_stride = 0, long row_stride = 0);
 
 // VectorInterp (field.py:90-95,119-120)
 // targets_dev: caller order (n,3); sorted_dev: the same points sorted by y; order_dev: caller index of sorted point q

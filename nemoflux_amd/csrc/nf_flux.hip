@@ -126,9 +126,18 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
                                                 const double *__restrict__ arcE, const double *__restrict__ arcN,
                                                 T fill, double scale, int sverdrup, double *__restrict__ iV,
                                                 double *__restrict__ absUV, unsigned long long *maxbits,
-                                                unsigned ntiles, int xcd_map)
+                                                unsigned ntiles, int xcd_map, StepBatch sb)
 {
     const unsigned tile = xcd_map ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
+    if (sb.zr) {  // several time steps in one launch (small grids are launch-bound): blockIdx.y is the step
+        const long tb = blockIdx.y;
+        u += tb * sb.in_stride;
+        v += tb * sb.in_stride;
+        iV += tb * 4 * ncell;
+        absUV += tb * 2 * ncell;
+        z0 = sb.zr[2 * tb];
+        z1 = sb.zr[2 * tb + 1];  // z1 == z0: the rank owns nothing of this step and stores zeros
+    }
     double tmax = 0.0;
     if (tile < ntiles) {  // workgroup-uniform
         const long base = (long)tile * BLOCK * VEC * CH + (long)threadIdx.x * VEC;
@@ -435,9 +444,10 @@ static int launch_flux_t(const FluxArgs &a, hipStream_t s)
     const unsigned ntiles = (unsigned)((a.ncell + per_tile - 1) / per_tile);
     const int xcd_map = g_xcd_map;
     const unsigned grid = xcd_map ? xcd_grid(ntiles) : ntiles;
-    hipLaunchKernelGGL((k_flux<T, VEC, UZ, NT, BLOCK, CH, SYNC, DIAG>), dim3(grid), dim3(BLOCK), 0, s, (const T *)a.u,
-                       (const T *)a.v, a.ncell, (unsigned)a.ny, (unsigned)a.nx, a.z0, a.z1, a.thickness, a.arcE,
-                       a.arcN, (T)a.fill, a.scale, a.sverdrup, a.iV, a.absU, a.maxbits, ntiles, xcd_map);
+    hipLaunchKernelGGL((k_flux<T, VEC, UZ, NT, BLOCK, CH, SYNC, DIAG>), dim3(grid, (unsigned)(a.batch.zr ? a.batch.nsteps : 1)),
+                       dim3(BLOCK), 0, s, (const T *)a.u, (const T *)a.v, a.ncell, (unsigned)a.ny, (unsigned)a.nx, a.z0,
+                       a.z1, a.thickness, a.arcE, a.arcN, (T)a.fill, a.scale, a.sverdrup, a.iV, a.absU, a.maxbits, ntiles,
+                       xcd_map, a.batch);
     NF_HIP(hipGetLastError());
     return NF_OK;
 }
@@ -470,7 +480,7 @@ static int launch_flux_ww(const FluxArgs &a, hipStream_t s)
 template <typename T, int VEC>
 static int launch_flux_v(const FluxArgs &a, hipStream_t s)
 {
-    const int variant = g_variant;
+    const int variant = a.batch.zr ? 0 : g_variant;  // the multi-step launch exists for the default kernel only
     if (VEC == 1) return launch_flux_t<T, VEC, 4, false, 256, 1, false>(a, s);
     switch (variant) {
         // measured alternatives (tools/ab_flux.py): all within +-3 % of the default
@@ -491,7 +501,8 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
 int launch_flux(const FluxArgs &a, hipStream_t s)
 {
     NF_REQUIRE(a.ncell > 0 && a.ncell == a.ny * a.nx && a.ncell < (1l << 31), NF_ERR_ARG, "flux: bad grid sizes");
-    NF_REQUIRE(a.z1 > a.z0 && a.z0 >= 0, NF_ERR_ARG, "flux: empty z range");
+    NF_REQUIRE(a.batch.zr || (a.z1 > a.z0 && a.z0 >= 0), NF_ERR_ARG, "flux: empty z range");
+    NF_REQUIRE(!a.batch.zr || (a.batch.nsteps > 0 && a.batch.nsteps < 65536), NF_ERR_ARG, "flux: bad step batch");
     NF_REQUIRE(a.absV == a.absU + a.ncell, NF_ERR_ARG, "flux: abs planes must be contiguous");
     const bool al16 = ((uintptr_t)a.u % 16 == 0) && ((uintptr_t)a.v % 16 == 0);
     if (a.dtype == NF_F64) {

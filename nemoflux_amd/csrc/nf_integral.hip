@@ -20,8 +20,11 @@ __global__ __launch_bounds__(kBlock) void k_gather_segscan(const int *__restrict
                                                            const double *__restrict__ w4,
                                                            const int *__restrict__ seg, long n,
                                                            const double *__restrict__ data, long ncell,
-                                                           int planes, unsigned nx, double *__restrict__ runsum)
+                                                           int planes, unsigned nx, double *__restrict__ runsum,
+                                                           long data_stride)
 {
+    data += (long)blockIdx.y * data_stride;  // blockIdx.y = time step of a multi-step launch
+    runsum += (long)blockIdx.y * n;
     const long k = (long)blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1);
     double val = 0.0;
@@ -68,8 +71,10 @@ __global__ __launch_bounds__(kBlock) void k_gather_segscan(const int *__restrict
 // spans) with a lane-strided sum and a butterfly
 __global__ __launch_bounds__(kBlock) void k_finalize_seg(const double *__restrict__ runsum,
                                                          const int *__restrict__ seg_start, int nseg,
-                                                         double *__restrict__ row)
+                                                         double *__restrict__ row, long nrec, long row_stride)
 {
+    runsum += (long)blockIdx.y * nrec;
+    row += (long)blockIdx.y * row_stride;
     const int s = (blockIdx.x * kBlock + threadIdx.x) / kWave;
     const int lane = threadIdx.x & (kWave - 1);
     if (s >= nseg) return;
@@ -89,8 +94,9 @@ __global__ __launch_bounds__(kBlock) void k_finalize_seg(const double *__restric
 
 // one wavefront per transect: sum of its segments
 __global__ __launch_bounds__(kBlock) void k_finalize_tr(const int *__restrict__ tr_off, int ntransect, int nseg,
-                                                        double *__restrict__ row)
+                                                        double *__restrict__ row, long row_stride)
 {
+    row += (long)blockIdx.y * row_stride;
     const int p = (blockIdx.x * kBlock + threadIdx.x) / kWave;
     const int lane = threadIdx.x & (kWave - 1);
     if (p >= ntransect) return;
@@ -101,19 +107,24 @@ __global__ __launch_bounds__(kBlock) void k_finalize_tr(const int *__restrict__ 
 }
 
 int launch_integral(const WeightSet &ws, const double *data, long ncell, int planes, long nx,
-                    const int *tr_offsets_dev, int ntransect, double *scratch, double *row, hipStream_t s)
+                    const int *tr_offsets_dev, int ntransect, double *scratch, double *row, hipStream_t s, int nsteps,
+                    long data_stride, long row_stride)
 {
+    const unsigned ny = (unsigned)(nsteps > 1 ? nsteps : 1);
     if (ws.nrec > 0) {
-        hipLaunchKernelGGL(k_gather_segscan, dim3((unsigned)((ws.nrec + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                           ws.cell, ws.w4, ws.seg, ws.nrec, data, ncell, planes, (unsigned)(nx > 0 ? nx : 1), scratch);
+        hipLaunchKernelGGL(k_gather_segscan, dim3((unsigned)((ws.nrec + kBlock - 1) / kBlock), ny), dim3(kBlock), 0, s,
+                           ws.cell, ws.w4, ws.seg, ws.nrec, data, ncell, planes, (unsigned)(nx > 0 ? nx : 1), scratch,
+                           data_stride);
     }
     if (ws.nseg > 0) {
         const unsigned nb = (unsigned)(((long)ws.nseg * kWave + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_finalize_seg, dim3(nb), dim3(kBlock), 0, s, scratch, ws.seg_start, ws.nseg, row);
+        hipLaunchKernelGGL(k_finalize_seg, dim3(nb, ny), dim3(kBlock), 0, s, scratch, ws.seg_start, ws.nseg, row,
+                           ws.nrec, row_stride);
     }
     if (ntransect > 0) {
         const unsigned nb = (unsigned)(((long)ntransect * kWave + kBlock - 1) / kBlock);
-        hipLaunchKernelGGL(k_finalize_tr, dim3(nb), dim3(kBlock), 0, s, tr_offsets_dev, ntransect, ws.nseg, row);
+        hipLaunchKernelGGL(k_finalize_tr, dim3(nb, ny), dim3(kBlock), 0, s, tr_offsets_dev, ntransect, ws.nseg, row,
+                           row_stride);
     }
     NF_HIP(hipGetLastError());
     return NF_OK;

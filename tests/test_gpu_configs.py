@@ -457,11 +457,22 @@ def test_fluxplot_batch_driver(tmp_path, capsys):
 def test_hipgraph_replay_equals_direct_launches():
     """computeAll on a non-null stream captures the whole pass (4 launches per time step) into a hipGraph and replays
     it; results are bit-identical to direct launches, and a change of configuration re-captures."""
+    import ctypes
     import torch
+    from nemoflux_amd._lib import lib, check
     from nemoflux_amd.dist import slab_range
     dg = device_case(72, 36, 5, 8, PSI_ZT)
     tr = [transect_xyz(T_OPEN), transect_xyz(T_TRI)]
     args = (dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, tr)
+    check(lib.nf_tuning_set(b'batch_steps', 0))                       # this test is about the per-step launch path
+    try:
+        _graph_body(args, dg, slab_range)
+    finally:
+        check(lib.nf_tuning_set(b'batch_steps', 1))
+
+
+def _graph_body(args, dg, slab_range):
+    import torch
     direct = quiet_field(*args, readback=False)                       # null stream: direct launches
     dtot, dseg = direct.computeAll()
     st = torch.cuda.Stream()
@@ -546,3 +557,39 @@ def test_real_orca025_subset_geometry_f32_land_sverdrup(oracle):
     # the arrows exist on the target line and sit inside the grid
     ids, _ = fld.vinterp.getCells()
     assert fld.vectorPoints.shape[0] > 50 and (ids >= 0).all()
+
+
+@pytest.mark.parametrize('real', ['float64', 'float32'])
+def test_all_steps_in_one_launch_equals_step_by_step(real):
+    """Small grids are launch-bound: computeAll puts every time step into one launch per kernel (blockIdx.y = step).
+    Same kernels, same arithmetic: rows and resident arrays are bit-identical to the step-by-step path, also under
+    slab ownership (a rank that owns part of a step, or nothing of it)."""
+    import ctypes
+    from nemoflux_amd._lib import lib, check
+    from nemoflux_amd.dist import slab_range
+    dg = device_case(90, 45, 6, 7, PSI_ZT, (20., 30.), real=real)
+    tr = [transect_xyz(T_OPEN), transect_xyz(T_TRI)]
+    args = (dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, tr)
+    for sr in (None, slab_range(7, 6, 1, 3), slab_range(7, 6, 0, 4)):
+        f = quiet_field(*args, slab_range=sr)
+        check(lib.nf_tuning_set(b'batch_steps', 0))
+        try:
+            stot, sseg = f.computeAll()
+            f.update()   # read back the resident arrays: they hold the step timeIndex = 0 after update
+        finally:
+            check(lib.nf_tuning_set(b'batch_steps', 1))
+        btot, bseg = f.computeAll()
+        assert numpy.array_equal(btot, stot) and numpy.array_equal(bseg, sseg)
+        # after a batched pass the resident arrays hold the LAST step, like after a step-by-step pass
+        m = ctypes.c_double()
+        iv = numpy.zeros((90 * 45, 4))
+        check(lib.nf_field_read_step(ctypes.byref(f._h), iv.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), None, None,
+                                     ctypes.byref(m)))
+        f.timeIndex = 6
+        f.update()
+        assert numpy.array_equal(iv, f.integratedVelocity)
+        # steps this rank does not touch are exact zeros
+        if sr is not None:
+            for t in range(7):
+                if sr[1] <= t * 6 or sr[0] >= (t + 1) * 6:
+                    assert numpy.all(btot[t] == 0) and numpy.all(bseg[t] == 0)

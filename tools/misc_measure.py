@@ -26,14 +26,16 @@ def quiet(*a, **k):
 # ---- 1. C2: launch-bound small grid
 dg = gen(360, 180, 10, 20, (20., 30.))
 units = 360 * 180 * 10 * 20
-for label, stream in (('direct launches (null stream)', None), ('hipGraph replay', torch.cuda.Stream())):
+import ctypes
+from nemoflux_amd._lib import lib, check
+for label, stream, batch in (('per-step launches (80 per pass)', None, 0), ('per-step launches in a hipGraph', torch.cuda.Stream(), 0),
+                             ('all steps per launch (4 per pass)', None, 1)):
+    check(lib.nf_tuning_set(b'batch_steps', batch))
     ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
     with ctx:
         f = quiet(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, [TRI], readback=False,
                   stream=None if stream is None else stream.cuda_stream)
         out = torch.zeros((20, f._rowlen), dtype=torch.float64, device='cuda')
-        import ctypes
-        from nemoflux_amd._lib import lib, check
         for _ in range(3):
             check(lib.nf_field_compute_all_async(ctypes.byref(f._h), ctypes.c_void_p(out.data_ptr())))
         torch.cuda.synchronize()
@@ -43,7 +45,8 @@ for label, stream in (('direct launches (null stream)', None), ('hipGraph replay
             check(lib.nf_field_compute_all_async(ctypes.byref(f._h), ctypes.c_void_p(out.data_ptr())))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / R
-    print(f'C2 360x180x10x20 {label:32s}: {dt*1e3:.3f} ms per 20-step pass = {units/dt:.3e} integrals/s')
+    print(f'C2 360x180x10x20 {label:34s}: {dt*1e3:.3f} ms per 20-step pass = {units/dt:.3e} integrals/s')
+check(lib.nf_tuning_set(b'batch_steps', 1))
 
 # ---- 2. host-resident fields (PCIe-inclusive)
 nx, ny, nz, nt = 1440, 1021, 75, 2
