@@ -686,12 +686,16 @@ static int field_step_async(nf_field *f, long t, double *row_dev)
 
 // All nt steps in FOUR launches (flux kernel with blockIdx.y = step, then the three reduction kernels): small grids
 // are launch-bound (4 launches of a few microseconds per step otherwise).  Needs HBM-resident fields and per-step
-// planes (nt x 48 B per cell), so it is used while nt*ncell stays under kBatchCellSteps.
-constexpr long kBatchCellSteps = 32l << 20;
+// planes (nt x 48 B per cell), so it is used while nt*ncell stays under 32 M cell-steps (NF_BATCH_CELLSTEPS).
+static long batch_cell_steps()
+{
+    static const long v = getenv("NF_BATCH_CELLSTEPS") ? atol(getenv("NF_BATCH_CELLSTEPS")) : (32l << 20);
+    return v;
+}
 
 static bool field_can_batch(const nf_field *f)
 {
-    return g_batch_steps && f->uv_on_device && !f->timing && f->nt >= 2 && f->nt < 65536 && f->nt * f->ncell <= kBatchCellSteps &&
+    return g_batch_steps && f->uv_on_device && f->nt >= 2 && f->nt < 65536 && f->nt * f->ncell <= batch_cell_steps() &&
            f->weights_built;
 }
 
@@ -749,7 +753,18 @@ static int field_all_steps_batched(nf_field *f, double *rows_dev)
     a.batch.nsteps = (int)f->nt;
     a.batch.in_stride = f->nz * f->ncell;
     a.batch.zr = f->d_zr;
-    NF_TRY(launch_flux(a, f->stream));
+    if (f->timing) {  // one event pair around the one flux launch of the pass
+        hipEvent_t e0, e1;
+        NF_HIP(hipEventCreate(&e0));
+        NF_HIP(hipEventCreate(&e1));
+        NF_HIP(hipEventRecord(e0, f->stream));
+        NF_TRY(launch_flux(a, f->stream));
+        NF_HIP(hipEventRecord(e1, f->stream));
+        f->ev.push_back(e0);
+        f->ev.push_back(e1);
+    } else {
+        NF_TRY(launch_flux(a, f->stream));
+    }
     if (rowlen > 0)
         NF_TRY(launch_integral(f->ws, f->d_iVb, f->ncell, 2, f->nx, f->d_tr_off, (int)f->polylines.size(), f->d_scratchb,
                                rows_dev, f->stream, (int)f->nt, (long)(4 * n), rowlen));
