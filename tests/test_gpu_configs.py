@@ -593,3 +593,66 @@ def test_all_steps_in_one_launch_equals_step_by_step(real):
             for t in range(7):
                 if sr[1] <= t * 6 or sr[0] >= (t + 1) * 6:
                     assert numpy.all(btot[t] == 0) and numpy.all(bseg[t] == 0)
+
+
+@pytest.mark.parametrize('grid_kind', ['regular', 'rotated', 'regional', 'orca025'])
+def test_weights_randomised_against_oracle(grid_kind, oracle):
+    """Seeded random polylines -- generic, node-snapped (segments along grid lines and through nodes), crossing the
+    +-180 seam, partly outside the grid -- on four geometries: GPU weights == oracle weights entry by entry, and the
+    coverage property holds (planar lon/lat are bilinear per cell, so segments that lie inside the grid integrate the
+    lon/lat "edge data" to their own end-point differences)."""
+    from nemoflux_amd import mint
+    if grid_kind == 'orca025':
+        b = load_golden('sa_T_bounds')
+        blon, blat = b['bounds_lon'].astype(numpy.float64), b['bounds_lat'].astype(numpy.float64)
+        box, periodX = (12.7, 37.5, -41.7, -20.8), 0.
+    else:
+        o = oracle.DataGen(72, 36, 1, 1)
+        if grid_kind == 'rotated':
+            o.rotatePole((20., 30.))
+        blon, blat = o.bounds_lon, o.bounds_lat
+        box, periodX = (-180., 180., -85., 85.), 360.
+        if grid_kind == 'regional':
+            blon, blat = numpy.ascontiguousarray(blon[6:30, 10:50]), numpy.ascontiguousarray(blat[6:30, 10:50])
+            box, periodX = (-130., 70., -60., 60.), 0.
+    pts = oracle.assemble_points(blon, blat)
+    grid = mint.Grid()
+    grid.setPoints(pts)
+    lonlat = [pts[:, :, 0], pts[:, :, 1]]
+    data = [numpy.stack([f[:, 1] - f[:, 0], f[:, 2] - f[:, 1], f[:, 2] - f[:, 3], f[:, 3] - f[:, 0]], axis=1) for f in lonlat]
+    rng = numpy.random.default_rng({'regular': 1, 'rotated': 2, 'regional': 3, 'orca025': 4}[grid_kind])
+    nodes_x, nodes_y = numpy.unique(pts[:, :, 0]), numpy.unique(pts[:, :, 1])
+    for trial in range(12):
+        n = int(rng.integers(2, 9))
+        x = rng.uniform(box[0] - 8, box[1] + 8, n)
+        y = rng.uniform(box[2], box[3], n)
+        if trial % 3 == 1 and grid_kind != 'rotated':     # snap to nodes: segments along grid lines / through nodes
+            x = nodes_x[rng.integers(0, nodes_x.size, n)]
+            y = nodes_y[rng.integers(0, nodes_y.size, n)]
+            if trial % 2:
+                x[1::2] = x[0::2][:x[1::2].size]              # vertical pieces on a grid line
+        if trial % 3 == 2 and periodX > 0:
+            x = x + rng.choice([-360., 0., 360.])          # the whole line shifted by a period
+        xyz = numpy.zeros((n, 3))
+        xyz[:, 0], xyz[:, 1] = x, y
+        pli = mint.PolylineIntegral()
+        pli.setGrid(grid)
+        pli.buildLocator(numCellsPerBucket=128, periodX=periodX, enableFolding=False)
+        pli.computeWeights(xyz, counterclock=False)
+        ce, w, sg = pli.getWeights()
+        ow = oracle.polyline_weights(pts, xyz, periodX=periodX)
+        assert ce.size == ow.weight.size, (grid_kind, trial)
+        gd = {}
+        for a, b_, c in zip(sg.tolist(), ce.tolist(), w.tolist()):
+            gd[(a, b_)] = gd.get((a, b_), 0.0) + c
+        od = ow.as_dict()
+        assert set(gd) == set(od)
+        if od:
+            assert max(abs(gd[k] - od[k]) for k in od) <= 1e-12
+        if grid_kind in ('regular', 'regional', 'orca025'):
+            inside = numpy.all((x >= box[0]) & (x <= box[1])) if periodX == 0 else True
+            if inside and grid_kind != 'regional' or (grid_kind == 'regional' and numpy.all((x > -128) & (x < 68))):
+                for k in (0, 1):
+                    segs, tot = pli.getSegmentIntegrals(data[k])
+                    want = numpy.diff(xyz[:, k])
+                    assert numpy.allclose(segs, want, rtol=0, atol=1e-9), (grid_kind, trial, k)

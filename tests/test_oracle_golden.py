@@ -202,3 +202,33 @@ def test_vector_interp_restatement_physics(oracle):
     k = 2 * numpy.pi / 360
     exact = numpy.stack([-k * numpy.sin(k * tg2[:, 1]), -k * numpy.cos(k * tg2[:, 0])], axis=1)
     assert numpy.allclose(v2[:, :2], exact, rtol=0, atol=0.02 * numpy.abs(exact).max())
+
+
+@pytest.mark.parametrize('kind', ['regular', 'regional'])
+def test_oracle_weights_coverage_random(kind, oracle):
+    """Property that pins the A6 restatement beyond the README answers: planar lon and lat are bilinear in every cell,
+    so with their edge differences as data every target segment that lies inside the grid must integrate to its own
+    end-point difference -- each point of the line counted exactly once, also along shared edges and through nodes."""
+    o = oracle.DataGen(72, 36, 1, 1)
+    blon, blat, periodX, box = o.bounds_lon, o.bounds_lat, 360., (-188., 188., -88., 88.)
+    if kind == 'regional':
+        blon, blat = numpy.ascontiguousarray(blon[6:30, 10:50]), numpy.ascontiguousarray(blat[6:30, 10:50])
+        periodX, box = 0., (-129., 69., -59., 59.)
+    pts = oracle.assemble_points(blon, blat)
+    data = [numpy.stack([f[:, 1] - f[:, 0], f[:, 2] - f[:, 1], f[:, 2] - f[:, 3], f[:, 3] - f[:, 0]], axis=1)
+            for f in (pts[:, :, 0], pts[:, :, 1])]
+    nodes_x, nodes_y = numpy.unique(pts[:, :, 0]), numpy.unique(pts[:, :, 1])
+    rng = numpy.random.default_rng(5 if kind == 'regular' else 6)
+    for trial in range(25):
+        n = int(rng.integers(2, 8))
+        x, y = rng.uniform(box[0], box[1], n), rng.uniform(box[2], box[3], n)
+        if trial % 2:
+            x, y = nodes_x[rng.integers(0, nodes_x.size, n)], nodes_y[rng.integers(0, nodes_y.size, n)]
+            if trial % 4 == 1:
+                y[1::2] = y[0::2][:y[1::2].size]      # horizontal pieces on a grid line
+        xyz = numpy.zeros((n, 3))
+        xyz[:, 0], xyz[:, 1] = x, y
+        w = oracle.polyline_weights(pts, xyz, periodX=periodX)
+        for k in (0, 1):
+            tot, segs = oracle.get_integral(w, data[k], True)
+            assert numpy.allclose(segs, numpy.diff(xyz[:, k]), rtol=0, atol=1e-10), (kind, trial, k)

@@ -12,9 +12,12 @@ ap.add_argument('--rounds', type=int, default=7)
 ap.add_argument('--nt', type=int, default=4)
 ap.add_argument('--dtype', default='float64')
 ap.add_argument('--random', type=int, default=1)
+ap.add_argument('--nx', type=int, default=3600)
+ap.add_argument('--ny', type=int, default=1800)
+ap.add_argument('--nz', type=int, default=75)
 ap.add_argument('--knobs', default='', help='semicolon list of knob settings per run, e.g. ww_blocks_per_cu=4,pipe_round_robin=1')
 a = ap.parse_args()
-nx, ny, nz = 3600, 1800, 75
+nx, ny, nz = a.nx, a.ny, a.nz
 dg = DataGen(real=a.dtype); dg.setSizes(nx, ny, nz, a.nt); dg.setBoundingBox(-180, 180, -90, 90, 0, 1); dg.build()
 dg.applyStreamFunction(STREAM_FUNCTIONS[5])
 if a.random:
