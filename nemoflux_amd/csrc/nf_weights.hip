@@ -14,9 +14,10 @@
 //
 // Mapping to the hardware.  One wavefront owns 64 consecutive cells.  Their corner table rows (64 x 64 B =
 // 4 KiB contiguous) are read coalesced and staged in LDS, then each lane keeps its own 4 corners in
-// registers for the whole kernel.  The segment list is wave-uniform (scalar loads); a wave-level bounding
-// box test (the "locator": numCellsPerBucket -> one 64-cell wave tile) rejects almost every (tile, segment)
-// pair with a uniform branch.  Hits are compacted with ballot/popcount into a deterministic order
+// registers for the whole kernel.  The locator has three levels: the 256 lanes of a workgroup clip 256 segment
+// images at a time against the workgroup's box (exact segment-vs-box test) and compact the survivors into an
+// LDS list; each wave then checks the survivors against its own 64-cell box (numCellsPerBucket -> the wave tile)
+// with a uniform branch, and each lane against its cell.  Hits are compacted with ballot/popcount into a deterministic order
 // (tile, segment, shift, lane): pass 1 counts per wave, a single-workgroup scan turns counts into offsets,
 // pass 2 recomputes and writes records.  Records are then stably radix-sorted (rocPRIM) by the 64-bit key
 // (global segment id, ta quantised to 2^-40), the multiplicity is resolved per record against its
@@ -167,11 +168,73 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
     int count = 0;
     const int base = (FILL && wave_id * kWave < ncell) ? wave_off[wave_id] : 0;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int s = 0; s < nseg; ++s) {
-        const double p0x = segs[4 * s], p0y = segs[4 * s + 1];
-        const double dx = segs[4 * s + 2], dy = segs[4 * s + 3];
-        if (dx == 0.0 && dy == 0.0) continue;
-        for (int k = 0; k < nshift; ++k) {
+    // Locator, level 1 (workgroup): the 256 lanes test 256 segment images at a time against the workgroup's box
+    // with an exact segment-vs-box clip and compact the survivors, in image order, into an LDS list; level 2 (wave)
+    // and level 3 (cell) then only look at those.  A workgroup is a 256-cell strip of one grid row, so almost every
+    // image is rejected here: tens of candidates instead of nseg*nshift loop trips per wave.
+    __shared__ int s_hits[kBlock];
+    __shared__ int s_wcount[kBlock / kWave];
+    __shared__ double s_box[4][kBlock / kWave];
+    if (lane == 0) {
+        s_box[0][tid / kWave] = wxmin;
+        s_box[1][tid / kWave] = wxmax;
+        s_box[2][tid / kWave] = wymin;
+        s_box[3][tid / kWave] = wymax;
+    }
+    __syncthreads();
+    double bxmin = s_box[0][0], bxmax = s_box[1][0], bymin = s_box[2][0], bymax = s_box[3][0];
+#pragma unroll
+    for (int w = 1; w < kBlock / kWave; ++w) {
+        bxmin = fmin(bxmin, s_box[0][w]);
+        bxmax = fmax(bxmax, s_box[1][w]);
+        bymin = fmin(bymin, s_box[2][w]);
+        bymax = fmax(bymax, s_box[3][w]);
+    }
+    const int nimg = nseg * nshift;
+    for (int chunk = 0; chunk < nimg; chunk += kBlock) {
+        const int img = chunk + tid;
+        bool cand = false;
+        if (img < nimg) {
+            const int s = img / nshift, k = img - s * nshift;
+            const double dx = segs[4 * s + 2], dy = segs[4 * s + 3];
+            if (!(dx == 0.0 && dy == 0.0)) {
+                const double qx = segs[4 * s] + (nshift == 3 ? k - 1 : 0) * periodX, qy = segs[4 * s + 1];
+                // Liang-Barsky clip of q + t d, t in [0,1], against the (slack-expanded) box; conservative
+                double t0 = 0.0, t1 = 1.0;
+                cand = true;
+                if (dx == 0.0) cand = qx >= bxmin && qx <= bxmax;
+                else {
+                    double ta = (bxmin - qx) / dx, tb = (bxmax - qx) / dx;
+                    if (ta > tb) { const double tt = ta; ta = tb; tb = tt; }
+                    t0 = fmax(t0, ta);
+                    t1 = fmin(t1, tb);
+                }
+                if (dy == 0.0) cand = cand && qy >= bymin && qy <= bymax;
+                else {
+                    double ta = (bymin - qy) / dy, tb = (bymax - qy) / dy;
+                    if (ta > tb) { const double tt = ta; ta = tb; tb = tt; }
+                    t0 = fmax(t0, ta);
+                    t1 = fmin(t1, tb);
+                }
+                cand = cand && t0 <= t1 + 1.e-9;
+            }
+        }
+        const unsigned long long cmask = __ballot(cand);
+        if (lane == 0) s_wcount[tid / kWave] = __popcll(cmask);
+        __syncthreads();
+        int before = 0, nhit = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) {
+            if (w < tid / kWave) before += s_wcount[w];
+            nhit += s_wcount[w];
+        }
+        if (cand) s_hits[before + __popcll(cmask & lt_mask)] = img;
+        __syncthreads();
+        for (int h = 0; h < nhit; ++h) {  // workgroup-uniform trip count, image order preserved
+            const int im = s_hits[h];
+            const int s = im / nshift, k = im - s * nshift;
+            const double p0x = segs[4 * s], p0y = segs[4 * s + 1];
+            const double dx = segs[4 * s + 2], dy = segs[4 * s + 3];
             const int shift = nshift == 3 ? k - 1 : 0;
             const double qx = p0x + shift * periodX, qy = p0y;
             const double sxmin = qx < qx + dx ? qx : qx + dx, sxmax = qx < qx + dx ? qx + dx : qx;
@@ -207,6 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
             }
             count += __popcll(mask);
         }
+        __syncthreads();  // s_hits is reused by the next chunk
     }
     if (!FILL && lane == 0 && wave_id * kWave < ncell) wave_cnt[wave_id] = count;
 }
