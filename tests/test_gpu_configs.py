@@ -656,3 +656,32 @@ def test_weights_randomised_against_oracle(grid_kind, oracle):
                     segs, tot = pli.getSegmentIntegrals(data[k])
                     want = numpy.diff(xyz[:, k])
                     assert numpy.allclose(segs, want, rtol=0, atol=1e-9), (grid_kind, trial, k)
+
+
+@pytest.mark.parametrize('rotated', [False, True])
+def test_path_independence_random_psi_gpu(rotated, oracle):
+    """GPU counterpart of test_oracle_path_independence_random_psi: random node field, edge data = node differences,
+    flux between two nodes = psi(end) - psi(start) for any intermediate points (on the un-rotated grid, where target
+    coordinates and nodes coincide; on the rotated grid: closed loops integrate to zero)."""
+    from nemoflux_amd import mint
+    from test_oracle_golden import _random_stream_function_case
+    o, pts, psi, data, rng = _random_stream_function_case(oracle, rotated, 33)
+    grid = mint.Grid()
+    grid.setPoints(pts)
+    x_nodes, y_nodes = o.xx[0], o.yy[:, 0]
+    for trial in range(10):
+        mid = [(float(a), float(b)) for a, b in zip(rng.uniform(-170, 170, 4), rng.uniform(-60, 60, 4))]
+        if rotated:
+            xy = numpy.array(mid + [mid[0]])
+            want = 0.0
+        else:
+            ia, ja, ib, jb = rng.integers(0, 49), rng.integers(2, 23), rng.integers(0, 49), rng.integers(2, 23)
+            xy = numpy.array([(x_nodes[ia], y_nodes[ja])] + mid + [(x_nodes[ib], y_nodes[jb])])
+            want = psi[jb, ib] - psi[ja, ia]
+        xyz = numpy.zeros((len(xy), 3))
+        xyz[:, :2] = xy
+        pli = mint.PolylineIntegral()
+        pli.setGrid(grid)
+        pli.buildLocator(numCellsPerBucket=128, periodX=360., enableFolding=False)
+        pli.computeWeights(xyz, counterclock=False)
+        assert abs(pli.getIntegral(data) - want) <= 1e-11, (rotated, trial)

@@ -80,3 +80,28 @@ def test_two_ranks_one_gpu_gloo(tmp_path):
     ex = numpy.array(exactFlux(PSI, TRANSECTS[0], NZ, NT))
     assert numpy.abs(got[:, nseg + 0] - ex).max() <= 1e-12 * numpy.abs(ex).max()
     assert numpy.abs(got[:, nseg + 1]).max() <= 1e-12 * numpy.abs(ex).max()
+
+
+def test_bench_contract_small_workload():
+    """bench.py prints exactly one JSON line with the contract's keys (tiny workload, CPU leg included)."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--nx', '144',
+                          '--ny', '72', '--nz', '9', '--nt', '3', '--batch', '6'], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['vs_baseline'] is None and d['dtype'] == 'f64' and d['data'] == 'synthetic' and 'workload' in d['config']
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['achieved'] > 0
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1 and c['unit'] == d['unit']
+    assert d['accuracy']['max_abs_err_vs_fluxexact'] <= 1e-11 * max(1.0, d['accuracy']['max_abs_exact'])
+    assert abs(d['value'] - 144 * 72 * 9 * 3 * 2 / (d['ms_per_step'] * 2e-3)) <= 1e-6 * d['value']

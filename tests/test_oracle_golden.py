@@ -232,3 +232,39 @@ def test_oracle_weights_coverage_random(kind, oracle):
         for k in (0, 1):
             tot, segs = oracle.get_integral(w, data[k], True)
             assert numpy.allclose(segs, numpy.diff(xyz[:, k]), rtol=0, atol=1e-10), (kind, trial, k)
+
+
+def _random_stream_function_case(oracle, rotated, seed):
+    """Random node values psi on the (ny+1) x (nx+1) mesh (x-periodic), as cell-by-cell edge differences."""
+    nx, ny = 48, 24
+    o = oracle.DataGen(nx, ny, 1, 1)
+    if rotated:
+        o.rotatePole((20., 30.))
+    pts = oracle.assemble_points(o.bounds_lon, o.bounds_lat)
+    rng = numpy.random.default_rng(seed)
+    psi = rng.standard_normal((ny + 1, nx + 1))
+    psi[:, -1] = psi[:, 0]
+    p0, p1, p2, p3 = psi[:-1, :-1], psi[:-1, 1:], psi[1:, 1:], psi[1:, :-1]
+    data = numpy.stack([p1 - p0, p2 - p1, p2 - p3, p3 - p0], axis=-1).reshape(-1, 4)
+    return o, pts, psi, data, rng
+
+
+def test_oracle_path_independence_random_psi(oracle):
+    """Any node field psi is reproduced exactly by the bilinear cell interpolants, so for edge data = node differences
+    the flux across ANY polyline between two nodes is psi(end) - psi(start): this exercises the xi*eta cross term of
+    the weights, the 1/n sharing along edges, nodes hit exactly and the periodic seam (README.md:45,58 generalised)."""
+    o, pts, psi, data, rng = _random_stream_function_case(oracle, False, 21)
+    x_nodes, y_nodes = o.xx[0], o.yy[:, 0]
+    for trial in range(20):
+        ia, ja, ib, jb = rng.integers(0, 49), rng.integers(2, 23), rng.integers(0, 49), rng.integers(2, 23)
+        mid = [(float(a), float(b)) for a, b in zip(rng.uniform(-180, 180, 3), rng.uniform(-75, 75, 3))]
+        if trial % 2:   # intermediate points on nodes too
+            mid = [(float(x_nodes[rng.integers(0, 49)]), float(y_nodes[rng.integers(2, 23)])) for _ in range(3)]
+        xy = numpy.array([(x_nodes[ia], y_nodes[ja])] + mid + [(x_nodes[ib], y_nodes[jb])])
+        if trial % 5 == 4:
+            xy[:, 0] += 360.0    # same line one period to the east
+        xyz = numpy.zeros((len(xy), 3))
+        xyz[:, :2] = xy
+        w = oracle.polyline_weights(pts, xyz)
+        got = oracle.get_integral(w, data)
+        assert abs(got - (psi[jb, ib] - psi[ja, ia])) <= 1e-11, trial
