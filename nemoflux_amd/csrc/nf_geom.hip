@@ -77,10 +77,13 @@ __global__ __launch_bounds__(kBlock) void k_geometry(const T *__restrict__ blon,
             // geo.py:15-21 with radius = geo.EARTH_RADIUS = 1.0
             double lam = lon[v] * kDeg2Rad;
             double the = lat[v] * kDeg2Rad;
-            double rho = 1.0 * cos(the);
-            X[v] = rho * cos(lam);
-            Y[v] = rho * sin(lam);
-            Z[v] = 1.0 * sin(the);
+            double sl, cl, st, ct;  // sincos shares the argument reduction; same values as sin() and cos()
+            sincos(lam, &sl, &cl);
+            sincos(the, &st, &ct);
+            double rho = 1.0 * ct;
+            X[v] = rho * cl;
+            Y[v] = rho * sl;
+            Z[v] = 1.0 * st;
             lomin = fmin(lomin, lon[v]);
             lomax = fmax(lomax, lon[v]);
             lamin = fmin(lamin, lat[v]);
