@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below; see docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, 'libnemoflux_amd.so')
+_SO = os.environ.get('NEMOFLUX_AMD_LIB', os.path.join(_HERE, 'libnemoflux_amd.so'))  # override: sanitizer builds
 
 if not os.path.exists(_SO):
     raise ImportError(
