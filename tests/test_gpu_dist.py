@@ -105,3 +105,11 @@ def test_bench_contract_small_workload():
     assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1 and c['unit'] == d['unit']
     assert d['accuracy']['max_abs_err_vs_fluxexact'] <= 1e-11 * max(1.0, d['accuracy']['max_abs_exact'])
     assert abs(d['value'] - 144 * 72 * 9 * 3 * 2 / (d['ms_per_step'] * 2e-3)) <= 1e-6 * d['value']
+
+
+def test_readme_examples_script():
+    """examples/readme_examples.py: every worked example of the reference's README within 1e-9 of its answer
+    (the rotated closed loop carries the reference's own ~1e-11 arc-length conditioning error)."""
+    import runpy
+    mod = runpy.run_path(os.path.join(ROOT, 'examples', 'readme_examples.py'))
+    assert mod['main']() <= 1e-9
