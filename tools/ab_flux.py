@@ -12,6 +12,7 @@ ap.add_argument('--rounds', type=int, default=7)
 ap.add_argument('--nt', type=int, default=4)
 ap.add_argument('--dtype', default='float64')
 ap.add_argument('--random', type=int, default=1)
+ap.add_argument('--voff', type=int, default=0, help='extra byte offset of v relative to its allocation (16-B multiple)')
 ap.add_argument('--nx', type=int, default=3600)
 ap.add_argument('--ny', type=int, default=1800)
 ap.add_argument('--nz', type=int, default=75)
@@ -23,7 +24,11 @@ dg.applyStreamFunction(STREAM_FUNCTIONS[5])
 if a.random:
     dt = torch.float64 if a.dtype == 'float64' else torch.float32
     u = torch.empty((a.nt, nz, ny, nx), dtype=dt, device='cuda').normal_()
-    v = torch.empty((a.nt, nz, ny, nx), dtype=dt, device='cuda').normal_()
+    nelem = a.nt * nz * ny * nx
+    esz = 8 if a.dtype == 'float64' else 4
+    vbuf = torch.empty(nelem + a.voff // esz + 16, dtype=dt, device='cuda').normal_()
+    v = vbuf[a.voff // esz: a.voff // esz + nelem].view(a.nt, nz, ny, nx)
+    print('u ptr %x v ptr %x diff mod 2MiB %d' % (u.data_ptr(), v.data_ptr(), (v.data_ptr() - u.data_ptr()) % (2 << 20)))
 else:
     u, v = dg.computeUVFromPotential()
 with contextlib.redirect_stdout(io.StringIO()):
