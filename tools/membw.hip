@@ -1,3 +1,4 @@
+// build: hipcc -O3 --offload-arch=gfx950 -o tools/membw tools/membw.hip ; run: MEMBW_RANDOM=1 ./tools/membw
 // membw.hip -- HBM read-bandwidth probes used to place k_flux against what the chip delivers (tuning aid, not product).
 //   seq : every workgroup streams a contiguous span (persistent grid-stride over 4 KiB tiles), 16 B/lane, nt loads
 //   slab: the k_flux access pattern (a wave reads 1 KiB from each of NS slabs at the same offset), no stores
