@@ -9,5 +9,6 @@ fallback.  See DESIGN.md and INTEGRATION.md.
 """
 from . import _lib  # noqa: F401  (fails loudly if the HIP extension is missing)
 from . import mint  # noqa: F401
+from ._lib import DeviceArray, DeviceBuffer, NemofluxError  # noqa: F401
 
-__all__ = ['mint']
+__all__ = ['mint', 'DeviceArray', 'DeviceBuffer', 'NemofluxError']

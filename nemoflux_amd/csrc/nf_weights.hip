@@ -297,7 +297,7 @@ __global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ in, long 
         out[k] = (int)run;
         run += in[k];
     }
-    if (tid == 1023) out[n] = (int)s_sum[1023];
+    if (tid == 1023) out[n] = s_sum[1023] > 0x7fffffffl ? -1 : (int)s_sum[1023];  // -1: too many records
 }
 
 __global__ __launch_bounds__(kBlock) void k_iota(unsigned *p, long n)
@@ -421,6 +421,7 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     int nrec_i = 0;
     NF_HIP(hipMemcpyAsync(&nrec_i, d_off.as<int>() + nwaves, sizeof(int), hipMemcpyDeviceToHost, s));
     NF_HIP(hipStreamSynchronize(s));
+    NF_REQUIRE(nrec_i >= 0, NF_ERR_ARG, "weights: more than 2^31 (segment, cell) records; split the transect set");
     const long nrec = nrec_i;
 
     NF_HIP(hipMalloc((void **)&out->seg_start, sizeof(int) * (size_t)(nseg + 1)));
