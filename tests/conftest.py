@@ -14,6 +14,10 @@ for p in (ROOT, os.path.join(ROOT, 'oracle')):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # a fresh checkout has no built artefacts (they are git-ignored): build the HIP library and the oracle once
+    if not os.path.exists(os.path.join(ROOT, 'nemoflux_amd', 'libnemoflux_amd.so')):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def load_cases():
