@@ -103,8 +103,10 @@ class DataGen(object):
         t_end = self.nt if t_end is None else t_end
         dt = torch.float64 if self.real == 'float64' else torch.float32
         shape = (t_end - t_begin, self.nz, self.ny, self.nx)
-        self.u = torch.empty(shape, dtype=dt, device='cuda')
-        self.v = torch.empty(shape, dtype=dt, device='cuda')
+        # one allocation for both fields: their relative placement in HBM (which decides how the two read streams
+        # of the flux kernel share channels) is then the same in every process instead of an accident of the allocator
+        self._uv = torch.empty((2,) + shape, dtype=dt, device='cuda')
+        self.u, self.v = self._uv[0], self._uv[1]
         code = NF_F64 if self.real == 'float64' else NF_F32
         # at most 65535 slabs per launch
         per = max(1, 60000 // self.nz)
