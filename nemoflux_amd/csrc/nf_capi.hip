@@ -886,15 +886,17 @@ int nf_field_set_uv(nf_field **self, const void *u, const void *v, long nt, int 
     NF_REQUIRE(nt > 0, NF_ERR_ARG, "nf_field_set_uv: nt must be positive");
     NF_REQUIRE(dtype == NF_F64 || dtype == NF_F32, NF_ERR_ARG, "nf_field_set_uv: dtype must be NF_F64/NF_F32");
     nf_field *f = *self;
+    if (f->uv_dtype != dtype) {  // the staging slabs of host-resident fields are sized by the dtype
+        if (f->d_stage_u) (void)hipFree(f->d_stage_u);
+        if (f->d_stage_v) (void)hipFree(f->d_stage_v);
+        f->d_stage_u = f->d_stage_v = nullptr;
+    }
     f->u = u;
     f->v = v;
     f->nt = nt;
     f->uv_dtype = dtype;
     f->uv_on_device = on_device;
     f->fill = fill_value;
-    if (f->d_stage_u) (void)hipFree(f->d_stage_u);
-    if (f->d_stage_v) (void)hipFree(f->d_stage_v);
-    f->d_stage_u = f->d_stage_v = nullptr;
     ++f->version;
     return NF_OK;
 }

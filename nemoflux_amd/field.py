@@ -183,7 +183,16 @@ class Field(object):
             raise RuntimeError("ERROR: uo/vo shapes do not match the (ny, nx) of the cell bounds")
         self.ny, self.nx = ny, nx
         pu, pv = _lib.device_pointer(uo), _lib.device_pointer(vo)
-        if pu is None:
+        self._lazy = None
+        if hasattr(uo, 'read_step') or hasattr(vo, 'read_step'):
+            # file-backed variables inflated one time step at a time (nemoflux_amd.hdf5min.LazyVariable)
+            self._lazy = (uo, vo)
+            self._lazy_dtype = numpy.dtype(uo.dtype)
+            self._uv_code, self._fill = _dtype_code(uo), float(fill_value)
+            self._lazy_step = (-1, None, None)
+            pu = pv = None
+            uv_dev = 0
+        elif pu is None:
             uo = numpy.ascontiguousarray(uo)
             vo = numpy.ascontiguousarray(vo)
             if vo.dtype != uo.dtype:
@@ -192,7 +201,8 @@ class Field(object):
             pu, pv, uv_dev = uo.ctypes.data, vo.ctypes.data, 0
         else:
             uv_dev = 1
-        check(lib.nf_field_set_uv(ctypes.byref(self._h), pu, pv, self.nt, _dtype_code(uo), uv_dev, float(fill_value)))
+        if self._lazy is None:
+            check(lib.nf_field_set_uv(ctypes.byref(self._h), pu, pv, self.nt, _dtype_code(uo), uv_dev, float(fill_value)))
         check(lib.nf_field_set_sverdrup(ctypes.byref(self._h), 1 if sverdrup else 0))
         if slab_range is not None:
             check(lib.nf_field_set_slab_range(ctypes.byref(self._h), int(slab_range[0]), int(slab_range[1])))
@@ -330,6 +340,19 @@ class Field(object):
     def _compute(self, tIndex, readback=None):
         if not (0 <= tIndex < self.nt):
             raise RuntimeError(f'ERROR: time index {tIndex} out of range [0, {self.nt})')
+        if self._lazy is not None and self._lazy_step[0] != tIndex:
+            # one time step from the file; the engine sees a virtual (nt, nz, ny, nx) base that it only
+            # dereferences at step tIndex
+            def step_of(src):   # LazyVariable, or a plain / memory-mapped array (one of the two files may be either)
+                if hasattr(src, 'read_step'):
+                    return numpy.ascontiguousarray(src.read_step(tIndex), dtype=self._lazy_dtype)
+                a = src[tIndex] if len(src.shape) == 4 else src
+                return numpy.ascontiguousarray(a, dtype=self._lazy_dtype)
+            au, av = step_of(self._lazy[0]), step_of(self._lazy[1])
+            self._lazy_step = (tIndex, au, av)
+            off = tIndex * au.nbytes
+            check(lib.nf_field_set_uv(ctypes.byref(self._h), au.ctypes.data - off, av.ctypes.data - off, self.nt,
+                                      self._uv_code, 0, self._fill))
         check(lib.nf_field_compute_flux(ctypes.byref(self._h), int(tIndex), _lib.dptr(self._row)))
         self._row_valid = True
         if self._readback if readback is None else readback:
@@ -367,6 +390,11 @@ class Field(object):
         totals and (nt, nseg) per-segment sums.  `out`: optional torch CUDA tensor (nt, row_length) to
         receive the raw rows in HBM (for the RCCL reduce of nemoflux_amd.dist)."""
         import torch
+        if self._lazy is not None:   # file-backed, one step in memory at a time
+            rows = numpy.array([self._compute(t, readback=False).copy() for t in range(self.nt)])
+            if out is not None:
+                out.copy_(torch.from_numpy(rows))
+            return rows[:, self._nseg:self._nseg + len(self.plis)], rows[:, :self._nseg]
         if out is None:
             out = torch.empty((self.nt, max(self._rowlen, 1)), dtype=torch.float64, device='cuda')
         check(lib.nf_field_compute_all_async(ctypes.byref(self._h), ctypes.c_void_p(out.data_ptr())))

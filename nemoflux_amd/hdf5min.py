@@ -1,0 +1,633 @@
+"""hdf5min -- a small read-only HDF5 / NetCDF-4 reader (numpy + zlib only), enough for the files nemoflux opens.
+
+The reference reads its T/U/V files through xarray + netCDF4 (nemoflux/field.py:22-25,34-35,149); neither is in this
+image's main interpreter.  NetCDF-4 files ARE HDF5 files, and what nemoflux needs from them is small: a handful of
+named n-d float arrays (bounds_lat, bounds_lon, deptht_bounds, uo, vo) and their `_FillValue` attribute.  This module
+parses exactly that subset of the HDF5 file format (HDF5 File Format Specification v3):
+
+  * superblock versions 0-3;
+  * object headers version 1 and version 2 (with continuation blocks);
+  * groups: old style (symbol table: v1 B-tree + local heap + SNOD nodes), new style with compact links (Link
+    messages) and with dense links (fractal heap whose root is a direct block or a one-level indirect block);
+  * datasets: IEEE float / integer datatypes of either byte order; contiguous, compact and chunked (v1 B-tree index,
+    layout message v3; layout v4 "single chunk" / "implicit" / contiguous) storage; deflate and shuffle filters;
+  * attributes stored in the object header (scalars / small arrays such as _FillValue).
+
+Contiguous little-endian data is returned as a numpy memmap of the file itself -- no copy: handing such an array to
+Field makes the engine stage each time step from the page cache straight to HBM.  Anything this reader does not
+understand raises Hdf5Error (it never guesses); nemoflux_amd.io then falls back to xarray or an h5py interpreter.
+"""
+import mmap
+import zlib
+
+import numpy
+
+SIGNATURE = b'\x89HDF\r\n\x1a\n'
+UNDEF = 0xffffffffffffffff
+
+
+class Hdf5Error(RuntimeError):
+    pass
+
+
+class Dataset(object):
+    def __init__(self, h5, name, shape, dtype, layout, filters, attrs):
+        self._h5, self.name, self.shape, self.dtype = h5, name, tuple(shape), dtype
+        self._layout, self._filters, self.attrs = layout, filters, attrs
+
+    @property
+    def fill_value(self):
+        fv = self.attrs.get('_FillValue')
+        return None if fv is None else numpy.asarray(fv).reshape(-1)[0]
+
+    def is_contiguous(self):
+        return self._layout[0] == 'contiguous' and not self._filters
+
+    def read(self):
+        """The whole array.  Contiguous unfiltered data comes back as a (read-only) view of the mapped file."""
+        kind = self._layout[0]
+        n = int(numpy.prod(self.shape)) if self.shape else 1
+        if kind == 'compact':
+            return numpy.frombuffer(self._layout[1], dtype=self.dtype, count=n).reshape(self.shape)
+        if kind == 'contiguous':
+            addr = self._layout[1]
+            if addr == UNDEF:
+                return numpy.zeros(self.shape, self.dtype.newbyteorder('='))
+            return numpy.frombuffer(self._h5._m, dtype=self.dtype, count=n, offset=self._h5._base + addr).reshape(self.shape)
+        if kind == 'chunked':
+            return self._read_chunked()
+        raise Hdf5Error(f'{self.name}: unsupported layout {kind}')
+
+    def read_leading(self, i):
+        """The slab [i] of the leading axis (one time step of uo/vo) without touching the rest of the variable:
+        a view of the mapped file for contiguous data, only the overlapping chunks are inflated otherwise."""
+        if not self.shape or not (0 <= i < self.shape[0]):
+            raise Hdf5Error(f'{self.name}: leading index {i} out of range')
+        if self._layout[0] != 'chunked':
+            return self.read()[i]
+        return self._read_chunked(lead=i)[0]
+
+    def _decode(self, raw, filter_mask, nbytes):
+        # filters are undone in reverse order of application
+        for k in range(len(self._filters) - 1, -1, -1):
+            fid, cd = self._filters[k]
+            if filter_mask & (1 << k):
+                continue
+            if fid == 1:
+                raw = zlib.decompress(raw)
+            elif fid == 2:  # shuffle: bytes of each element were de-interleaved
+                es = cd[0] if cd else self.dtype.itemsize
+                a = numpy.frombuffer(raw, numpy.uint8)
+                ne = a.size // es
+                raw = a[:ne * es].reshape(es, ne).T.tobytes() + a[ne * es:].tobytes()
+            elif fid == 3:  # fletcher32: checksum appended
+                raw = raw[:-4]
+            else:
+                raise Hdf5Error(f'{self.name}: unsupported filter id {fid}')
+        if len(raw) < nbytes:
+            raise Hdf5Error(f'{self.name}: short chunk')
+        return raw
+
+    def _read_chunked(self, lead=None):
+        _, btree, cdims, single = self._layout
+        rank = len(self.shape)
+        cshape = tuple(cdims[:rank])
+        lo = 0 if lead is None else lead          # window [lo, lo + nlead) of the leading axis
+        shape = self.shape if lead is None else (1,) + self.shape[1:]
+        out = numpy.zeros(shape, self.dtype)
+        nbytes = int(numpy.prod(cshape)) * self.dtype.itemsize
+        if getattr(self, '_chunks', None) is None:
+            self._chunks = [single] if single is not None else list(self._h5._chunk_btree(btree, rank))
+        for offs, size, mask, addr in self._chunks:
+            if addr == UNDEF:
+                continue
+            if lead is not None and not (offs[0] <= lead < offs[0] + cshape[0]):
+                continue
+            raw = self._h5._m[self._h5._base + addr: self._h5._base + addr + size]
+            raw = self._decode(raw, mask, nbytes)
+            blk = numpy.frombuffer(raw, self.dtype, count=nbytes // self.dtype.itemsize).reshape(cshape)
+            sl_out = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cshape, self.shape))
+            sl_in = tuple(slice(0, s.stop - s.start) for s in sl_out)
+            if lead is not None:
+                sl_in = (slice(lead - offs[0], lead - offs[0] + 1),) + sl_in[1:]
+                sl_out = (slice(0, 1),) + sl_out[1:]
+            out[sl_out] = blk[sl_in]
+        return out
+
+
+class LazyVariable(object):
+    """A (nt, ...) variable read one leading slab at a time (Field stages exactly one time step per compute call)."""
+
+    def __init__(self, dataset):
+        self.dataset, self.shape = dataset, dataset.shape
+        self.dtype = numpy.dtype(dataset.dtype.newbyteorder('='))
+
+    def read_step(self, t):
+        a = self.dataset.read_leading(t)
+        return numpy.ascontiguousarray(a, dtype=self.dtype)      # native byte order, C-contiguous
+
+
+class File(object):
+    def __init__(self, path):
+        self._f = open(path, 'rb')
+        try:
+            self._m = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
+        except ValueError as e:
+            raise Hdf5Error(f'{path}: empty file') from e
+        self._parse_superblock()
+        self.datasets = {}
+        self._walk_group(self._root, '', 0)
+
+    def close(self):
+        # views handed out by Dataset.read() keep the map alive; only the descriptor is closed here
+        self._f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ------------------------------------------------------------------------------------------ primitives
+    def _u(self, off, n):
+        return int.from_bytes(self._m[off:off + n], 'little')
+
+    def _addr(self, off):
+        return self._u(off, self._O)
+
+    def _len(self, off):
+        return self._u(off, self._L)
+
+    def _parse_superblock(self):
+        m = self._m
+        base = 0
+        while base < len(m) and m[base:base + 8] != SIGNATURE:  # the superblock may sit at 0, 512, 1024, ...
+            base = 512 if base == 0 else base * 2
+        if base >= len(m):
+            raise Hdf5Error('not an HDF5 file')
+        ver = m[base + 8]
+        if ver in (0, 1):
+            self._O, self._L = m[base + 13], m[base + 14]
+            p = base + 24 + (4 if ver == 1 else 0)
+            self._base = self._addr(p)
+            p += 4 * self._O                       # base, free-space, end-of-file, driver-info addresses
+            self._root = self._addr(p + self._O)   # root symbol table entry: link name offset, object header address
+        elif ver in (2, 3):
+            self._O, self._L = m[base + 9], m[base + 10]
+            p = base + 12
+            self._base = self._addr(p)
+            self._root = self._addr(p + 3 * self._O)
+        else:
+            raise Hdf5Error(f'unsupported superblock version {ver}')
+        if self._O != 8 or self._L != 8:
+            raise Hdf5Error('only 8-byte offsets and lengths are supported')
+        if self._base == UNDEF:
+            self._base = 0
+
+    # ------------------------------------------------------------------------------------------ object headers
+    def _messages(self, addr):
+        """[(type, flags, payload offset, payload size)] of the object header at file address addr."""
+        m, p = self._m, self._base + addr
+        out = []
+        if m[p:p + 4] == b'OHDR':
+            if m[p + 4] != 2:
+                raise Hdf5Error('unsupported object header version')
+            flags = m[p + 5]
+            q = p + 6
+            if flags & 0x20:
+                q += 16
+            if flags & 0x10:
+                q += 4
+            nsz = 1 << (flags & 3)
+            size0 = self._u(q, nsz)
+            q += nsz
+            blocks = [(q, size0)]
+            corder = 2 if flags & 0x04 else 0
+            while blocks:
+                q, size = blocks.pop(0)
+                end = q + size
+                while q + 4 + corder <= end:
+                    mtype, msize, mflags = m[q], self._u(q + 1, 2), m[q + 3]
+                    q += 4 + corder
+                    if q + msize > end:
+                        break
+                    if mtype == 0x10:
+                        caddr, clen = self._addr(q), self._len(q + self._O)
+                        cp = self._base + caddr
+                        if m[cp:cp + 4] != b'OCHK':
+                            raise Hdf5Error('bad object header continuation')
+                        blocks.append((cp + 4, clen - 8))     # minus signature and checksum
+                    elif mtype != 0:
+                        out.append((mtype, mflags, q, msize))
+                    q += msize
+            return out
+        if m[p] != 1:
+            raise Hdf5Error(f'unsupported object header at {addr:#x}')
+        nmsgs, hsize = self._u(p + 2, 2), self._u(p + 8, 4)
+        blocks = [(p + 16, hsize)]
+        while blocks and len(out) < nmsgs + 64:
+            q, size = blocks.pop(0)
+            end = q + size
+            while q + 8 <= end:
+                mtype, msize, mflags = self._u(q, 2), self._u(q + 2, 2), m[q + 4]
+                q += 8
+                if mtype == 0x10:
+                    blocks.append((self._base + self._addr(q), self._len(q + self._O)))
+                elif mtype != 0:
+                    out.append((mtype, mflags, q, msize))
+                q += msize
+        return out
+
+    # ------------------------------------------------------------------------------------------ message decoders
+    def _dataspace(self, q):
+        m = self._m
+        ver, rank, flags = m[q], m[q + 1], m[q + 2]
+        q += 8 if ver == 1 else 4
+        return [self._len(q + i * self._L) for i in range(rank)]
+
+    def _datatype(self, q):
+        """numpy dtype and the encoded size of the message."""
+        m = self._m
+        cls, ver = m[q] & 0x0f, m[q] >> 4
+        bits0 = m[q + 1]
+        size = self._u(q + 4, 4)
+        order = '>' if bits0 & 1 else '<'
+        if cls == 1:
+            if size not in (4, 8):
+                raise Hdf5Error('unsupported float size')
+            return numpy.dtype(order + 'f' + str(size)), 8 + 12
+        if cls == 0:
+            kind = 'i' if bits0 & 0x08 else 'u'
+            return numpy.dtype((order if size > 1 else '|') + kind + str(size)), 8 + 4
+        if cls == 3:   # fixed-length string
+            return numpy.dtype('S' + str(size)), 8
+        raise Hdf5Error(f'unsupported datatype class {cls}')
+
+    def _layout(self, q):
+        m = self._m
+        ver = m[q]
+        if ver == 3:
+            cls = m[q + 1]
+            if cls == 0:
+                n = self._u(q + 2, 2)
+                return ('compact', bytes(m[q + 4:q + 4 + n]))
+            if cls == 1:
+                return ('contiguous', self._addr(q + 2), self._len(q + 2 + self._O))
+            if cls == 2:
+                nd = m[q + 2]
+                bt = self._addr(q + 3)
+                dims = [self._u(q + 3 + self._O + 4 * i, 4) for i in range(nd)]
+                return ('chunked', bt, dims, None)
+        elif ver == 4:
+            cls = m[q + 1]
+            if cls == 0:
+                n = self._u(q + 2, 2)
+                return ('compact', bytes(m[q + 4:q + 4 + n]))
+            if cls == 1:
+                return ('contiguous', self._addr(q + 2), self._len(q + 2 + self._O))
+            if cls == 2:
+                flags, nd, enc = m[q + 2], m[q + 3], m[q + 4]
+                dims = [self._u(q + 5 + enc * i, enc) for i in range(nd)]
+                p = q + 5 + enc * nd
+                itype = m[p]
+                p += 1
+                if itype == 1:    # single chunk
+                    size, mask = None, 0
+                    if flags & 2:
+                        size, mask = self._len(p), self._u(p + self._L, 4)
+                        p += self._L + 4
+                    addr = self._addr(p)
+                    if size is None:
+                        size = int(numpy.prod(dims[:-1])) * dims[-1]
+                    return ('chunked', None, dims, ((0,) * (nd - 1), size, mask, addr))
+                raise Hdf5Error(f'unsupported chunk index type {itype} (HDF5 1.10 "latest" format)')
+        raise Hdf5Error(f'unsupported data layout message (version {ver})')
+
+    def _filters(self, q):
+        m = self._m
+        ver, n = m[q], m[q + 1]
+        q += 8 if ver == 1 else 2
+        out = []
+        for _ in range(n):
+            fid = self._u(q, 2)
+            q += 2
+            nlen = 0
+            if ver == 1 or fid >= 256:
+                nlen = self._u(q, 2)
+                q += 2
+            ncd = self._u(q + 2, 2)
+            q += 4
+            if nlen:
+                q += (nlen + 7) // 8 * 8 if ver == 1 else nlen
+            cd = [self._u(q + 4 * i, 4) for i in range(ncd)]
+            q += 4 * ncd
+            if ver == 1 and ncd % 2:
+                q += 4
+            out.append((fid, cd))
+        return out
+
+    def _attribute(self, q):
+        m = self._m
+        ver = m[q]
+        nsz, dtsz, dssz = self._u(q + 2, 2), self._u(q + 4, 2), self._u(q + 6, 2)
+        p = q + 8 + (1 if ver == 3 else 0)
+        pad = (lambda x: (x + 7) // 8 * 8) if ver == 1 else (lambda x: x)
+        name = bytes(m[p:p + nsz]).split(b'\0')[0].decode('utf-8', 'replace')
+        p += pad(nsz)
+        shape = self._dataspace(p + pad(dtsz)) if dssz >= 4 else []
+        n = int(numpy.prod(shape)) if shape else 1
+        esize = self._u(p + 4, 4)                       # element size of the attribute's datatype
+        total = (p - q) + pad(dtsz) + pad(dssz) + n * esize
+        try:
+            dt, _ = self._datatype(p)
+        except Hdf5Error:
+            return name, None, total                    # e.g. variable-length strings: skipped
+        p += pad(dtsz) + pad(dssz)
+        val = numpy.frombuffer(m[p:p + n * dt.itemsize], dt, count=n)
+        return name, (val.reshape(shape) if shape else val[0]), total
+
+    # ------------------------------------------------------------------------------------------ groups
+    def _walk_group(self, addr, prefix, depth):
+        if depth > 4:
+            return
+        msgs = self._messages(addr)
+        types = [t for t, _, _, _ in msgs]
+        if 0x01 in types and 0x03 in types and 0x08 in types:   # a dataset at the root (not expected)
+            return
+        for mtype, _, q, size in msgs:
+            if mtype == 0x11:      # old-style group: symbol table
+                for name, child in self._symbol_table(self._addr(q), self._addr(q + self._O)):
+                    self._visit(name, child, prefix, depth)
+            elif mtype == 0x06:    # compact link
+                link = self._link(q)
+                if link:
+                    self._visit(link[0], link[1], prefix, depth)
+            elif mtype == 0x02:    # link info: dense storage in a fractal heap
+                flags = self._m[q + 1]
+                p = q + 2 + (8 if flags & 1 else 0)
+                heap, btree = self._addr(p), self._addr(p + self._O)
+                if heap != UNDEF:
+                    # name-index records (type 5): hash (4), heap id (7)
+                    for name, child in self._fractal_heap_objects(heap, self._link_item, btree, 4):
+                        self._visit(name, child, prefix, depth)
+
+    def _visit(self, name, addr, prefix, depth):
+        try:
+            msgs = self._messages(addr)
+        except (Hdf5Error, IndexError):
+            return
+        info = {t: (q, s) for t, _, q, s in msgs}
+        if 0x01 in info and 0x03 in info and 0x08 in info:
+            try:
+                shape = self._dataspace(info[0x01][0])
+                dt, _ = self._datatype(info[0x03][0])
+                layout = self._layout(info[0x08][0])
+                filters = self._filters(info[0x0b][0]) if 0x0b in info else []
+            except Hdf5Error as e:
+                self.datasets[prefix + name] = e     # reported when the variable is asked for
+                return
+            attrs = {}
+            for t, _, q, s in msgs:
+                if t == 0x0c:
+                    k, v, _ = self._attribute(q)
+                    if v is not None:
+                        attrs[k] = v
+                elif t == 0x15:    # attribute info: dense attribute storage (more than 8 attributes)
+                    flags = self._m[q + 1]
+                    p0 = q + 2 + (2 if flags & 1 else 0)
+                    heap, btree = self._addr(p0), self._addr(p0 + self._O)
+                    if heap != UNDEF:
+                        # name-index records (type 8): heap id (8), flags (1), creation order (4), hash (4)
+                        for k, v in self._fractal_heap_objects(heap, self._attribute_item, btree, 0):
+                            if v is not None:
+                                attrs[k] = v
+            if '_FillValue' not in attrs:   # netCDF-4 mirrors _FillValue in the HDF5 fill-value message
+                fv = self._fill_value(info, dt)
+                if fv is not None:
+                    attrs['_FillValue'] = fv
+            self.datasets[prefix + name] = Dataset(self, prefix + name, shape, dt, layout, filters, attrs)
+        elif 0x11 in info or 0x02 in info or 0x06 in info:
+            self._walk_group(addr, prefix + name + '/', depth + 1)
+
+    def _attribute_item(self, q):
+        if self._m[q] not in (1, 2, 3):
+            return None
+        k, v, total = self._attribute(q)
+        return (k, v), total
+
+    def _link_item(self, q):
+        if self._m[q] != 1:
+            return None
+        link = self._link(q)
+        if not link:
+            return None
+        return (link[0], link[1]), link[2]
+
+    def _fill_value(self, info, dt):
+        m = self._m
+        if 0x05 in info:
+            q = info[0x05][0]
+            ver = m[q]
+            if ver in (1, 2):
+                if ver == 1 or m[q + 3]:
+                    n = self._u(q + 4, 4)
+                    if n == dt.itemsize:
+                        return numpy.frombuffer(m[q + 8:q + 8 + n], dt)[0]
+            elif ver == 3 and m[q + 1] & 0x20:
+                n = self._u(q + 2, 4)
+                if n == dt.itemsize:
+                    return numpy.frombuffer(m[q + 6:q + 6 + n], dt)[0]
+        if 0x04 in info:
+            q = info[0x04][0]
+            n = self._u(q, 4)
+            if n == dt.itemsize:
+                return numpy.frombuffer(m[q + 4:q + 4 + n], dt)[0]
+        return None
+
+    def _link(self, q):
+        m = self._m
+        if m[q] != 1:
+            return None
+        flags = m[q + 1]
+        p = q + 2
+        ltype = 0
+        if flags & 0x08:
+            ltype = m[p]
+            p += 1
+        if flags & 0x04:
+            p += 8
+        if flags & 0x10:
+            p += 1
+        nsz = 1 << (flags & 3)
+        nlen = self._u(p, nsz)
+        p += nsz
+        name = bytes(m[p:p + nlen]).decode('utf-8', 'replace')
+        p += nlen
+        if ltype != 0:
+            return None          # soft / external links are not followed
+        return name, self._addr(p), p + self._O - q
+
+    def _symbol_table(self, btree, heap):
+        m = self._m
+        hp = self._base + heap
+        if m[hp:hp + 4] != b'HEAP':
+            raise Hdf5Error('bad local heap')
+        data = self._base + self._addr(hp + 8 + 2 * self._L)
+
+        def name_at(off):
+            e = m.find(b'\0', data + off)
+            return bytes(m[data + off:e]).decode('utf-8', 'replace')
+
+        def node(a):
+            p = self._base + a
+            if m[p:p + 4] == b'SNOD':
+                n = self._u(p + 6, 2)
+                q = p + 8
+                for _ in range(n):
+                    yield name_at(self._addr(q)), self._addr(q + self._O)
+                    q += 2 * self._O + 24
+                return
+            if m[p:p + 4] != b'TREE' or m[p + 4] != 0:
+                raise Hdf5Error('bad group B-tree node')
+            n = self._u(p + 6, 2)
+            q = p + 8 + 2 * self._O
+            for i in range(n):
+                q += self._L                      # key
+                yield from node(self._addr(q))
+                q += self._O
+        yield from node(btree)
+
+    def _fractal_heap(self, addr):
+        """Geometry of a fractal heap: returns locate(offset) -> file position of the object at that heap offset, and
+        blocks() -> [(file position of the first object, end)] of its direct blocks."""
+        m, p = self._m, self._base + addr
+        if m[p:p + 4] != b'FRHP' or m[p + 4] != 0:
+            raise Hdf5Error('bad fractal heap header')
+        id_len = self._u(p + 5, 2)
+        filt_len = self._u(p + 7, 2)
+        flags = m[p + 9]
+        max_managed = self._u(p + 10, 4)
+        q = p + 14 + self._L + self._O + self._L + self._O           # next huge id, huge btree, free space, fsm addr
+        q += 8 * self._L                                             # managed space ... number of tiny objects
+        width = self._u(q, 2)
+        start_size = self._len(q + 2)
+        max_direct = self._len(q + 2 + self._L)
+        max_heap_bits = self._u(q + 2 + 2 * self._L, 2)
+        root = self._addr(q + 2 + 2 * self._L + 4)
+        nrows = self._u(q + 2 + 2 * self._L + 4 + self._O, 2)
+        if filt_len:
+            raise Hdf5Error('filtered fractal heaps are not supported')
+        off_bytes = (max_heap_bits + 7) // 8
+        hdr = 5 + self._O + off_bytes + (4 if flags & 2 else 0)      # direct block prefix
+        direct = []                                                  # (heap offset, size, file position)
+        if root != UNDEF:
+            if nrows == 0:
+                direct.append((0, start_size, self._base + root))
+            else:
+                b = self._base + root
+                if m[b:b + 4] != b'FHIB':
+                    raise Hdf5Error('bad fractal heap indirect block')
+                q0 = b + 5 + self._O + off_bytes
+                hoff = 0
+                for r in range(nrows):
+                    size = start_size * (1 << max(0, r - 1))
+                    if size > max_direct:
+                        break    # deeper indirect blocks: not needed for the handful of variables of a NEMO file
+                    for _ in range(width):
+                        a = self._addr(q0)
+                        q0 += self._O
+                        if a != UNDEF:
+                            direct.append((hoff, size, self._base + a))
+                        hoff += size
+        len_bytes = min((max(max_direct.bit_length(), 1) + 7) // 8, (max(max_managed.bit_length(), 1) + 7) // 8)
+
+        def locate(heap_id):
+            """heap_id: bytes of a managed-object heap ID -> (file position, length) or None."""
+            if (heap_id[0] >> 4) & 3 != 0:
+                return None        # huge / tiny objects: not produced for links and small attributes
+            off = int.from_bytes(heap_id[1:1 + off_bytes], 'little')
+            ln = int.from_bytes(heap_id[1 + off_bytes:1 + off_bytes + len_bytes], 'little')
+            for hoff, size, pos in direct:
+                if hoff <= off < hoff + size:
+                    return pos + (off - hoff), ln
+            return None
+
+        def blocks():
+            return [(pos + hdr, pos + size) for _, size, pos in direct if m[pos:pos + 4] == b'FHDB']
+        return locate, blocks, id_len
+
+    def _btree2_heap_ids(self, addr, id_offset, id_len):
+        """Heap IDs of the records of a version-2 B-tree whose root is a leaf (enough for tens of variables); None if
+        the tree is deeper (the caller then scans the heap blocks instead)."""
+        m = self._m
+        if addr == UNDEF:
+            return None
+        p = self._base + addr
+        if m[p:p + 4] != b'BTHD':
+            return None
+        rec_size, depth = self._u(p + 10, 2), self._u(p + 12, 2)
+        root = self._addr(p + 16)
+        nrec = self._u(p + 16 + self._O, 2)
+        if depth != 0 or root == UNDEF:
+            return None
+        b = self._base + root
+        if m[b:b + 4] != b'BTLF':
+            return None
+        return [bytes(m[b + 6 + i * rec_size + id_offset: b + 6 + i * rec_size + id_offset + id_len]) for i in range(nrec)]
+
+    def _fractal_heap_objects(self, addr, item, btree=UNDEF, id_offset=0):
+        """Objects (links / attributes) stored in a fractal heap: through the name-index B-tree when it is a single
+        leaf (exact, immune to deleted objects), else by parsing each direct block front to back."""
+        locate, blocks, id_len = self._fractal_heap(addr)
+        ids = self._btree2_heap_ids(btree, id_offset, id_len)
+        if ids is not None:
+            for hid in ids:
+                loc = locate(hid)
+                if loc is None:
+                    continue
+                it = item(loc[0])
+                if it is not None:
+                    yield it[0]
+            return
+        for q0, end in blocks():
+            while q0 + 4 < end:
+                it = item(q0)
+                if it is None:
+                    break
+                yield it[0]
+                q0 += it[1]
+
+    def _chunk_btree(self, addr, rank):
+        m = self._m
+        if addr == UNDEF:
+            return
+        p = self._base + addr
+        if m[p:p + 4] != b'TREE' or m[p + 4] != 1:
+            raise Hdf5Error('bad chunk B-tree node')
+        level, n = m[p + 5], self._u(p + 6, 2)
+        q = p + 8 + 2 * self._O
+        ksize = 8 + 8 * (rank + 1)
+        for _ in range(n):
+            size, mask = self._u(q, 4), self._u(q + 4, 4)
+            offs = tuple(self._u(q + 8 + 8 * i, 8) for i in range(rank))
+            child = self._addr(q + ksize)
+            q += ksize + self._O
+            if level == 0:
+                yield offs, size, mask, child
+            else:
+                yield from self._chunk_btree(child, rank)
+
+
+def read_variables(path, wanted=None):
+    """{name: array} (+ '_FillValue_<name>') of the top-level datasets of an HDF5 / NetCDF-4 file."""
+    out = {}
+    with File(path) as f:
+        for name, ds in f.datasets.items():
+            if wanted is not None and name not in wanted:
+                continue
+            if isinstance(ds, Hdf5Error):
+                raise ds
+            out[name] = ds.read()
+            if ds.fill_value is not None:
+                out['_FillValue_' + name] = numpy.asarray(ds.fill_value)
+    return out

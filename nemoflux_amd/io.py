@@ -3,11 +3,12 @@
 The reference reads NetCDF through xarray.  This image has neither xarray nor netCDF4 in its main interpreter, so:
   * `.npz` bundles with the same variable names are always accepted (nemoflux_amd.datagen.DataGen.save
     writes them): <prefix>T.npz, <prefix>U.npz, <prefix>V.npz;
-  * NetCDF files are read through xarray IF it is importable (same variable names: bounds_lat,
-    bounds_lon, deptht_bounds, uo, vo; _FillValue kept, not decoded);
-  * otherwise a NetCDF-4/HDF5 file is converted once by tools/nc2npz.py under any interpreter that has h5py
-    (probed: the running one, /opt/conda/bin/python3.9, python3) -- a compatibility path through the file system.
-NetCDF/HDF5 ingest straight to HBM is SURVEY.md 8f rank 3 ("next").
+  * NetCDF-4 / HDF5 files are parsed in-process by nemoflux_amd/hdf5min.py (numpy + zlib only): contiguous variables
+    come back as views of the mapped file, so the engine stages each time step from the page cache straight to HBM;
+    chunked / deflated variables (real NEMO output) are inflated one time step at a time (LazyVariable);
+  * what hdf5min does not understand falls back to xarray IF it is importable (same variable names: bounds_lat,
+    bounds_lon, deptht_bounds, uo, vo; _FillValue kept, not decoded), and last to a one-off conversion by
+    tools/nc2npz.py under any interpreter that has h5py (probed: the running one, /opt/conda/bin/python3.9, python3).
 """
 import os
 import subprocess
@@ -15,6 +16,8 @@ import sys
 import tempfile
 
 import numpy
+
+from . import hdf5min
 
 _NC2NPZ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'nc2npz.py')
 _H5_PYTHONS = [sys.executable, '/opt/conda/bin/python3.9', 'python3']
@@ -36,12 +39,40 @@ def _convert_with_h5py(path):
     return None
 
 
-def _open(path):
+def _open_hdf5(path, lazy=()):
+    """In-process NetCDF-4/HDF5 read; variables named in `lazy` are returned as hdf5min.LazyVariable."""
+    out = {}
+    f = hdf5min.File(path)
+    for name, ds in f.datasets.items():
+        if '/' in name:
+            continue
+        if isinstance(ds, hdf5min.Hdf5Error):
+            if name in ('bounds_lat', 'bounds_lon', 'deptht_bounds', 'uo', 'vo'):
+                raise ds
+            continue
+        if ds.dtype.kind not in 'fiu':
+            continue
+        if name in lazy and len(ds.shape) >= 3 and not (ds.is_contiguous() and ds.dtype.isnative):
+            out[name] = hdf5min.LazyVariable(ds)
+        else:
+            a = ds.read()
+            out[name] = a if a.dtype.isnative else a.astype(a.dtype.newbyteorder('='))
+        if ds.fill_value is not None:
+            out['_FillValue_' + name] = numpy.asarray(ds.fill_value)
+    out['_hdf5_file'] = f      # keeps the mapping alive for the views
+    return out
+
+
+def _open(path, lazy=()):
     path = str(path)
     if path.endswith('.npz'):
         return dict(numpy.load(path, allow_pickle=False))
     if not os.path.exists(path):
         raise RuntimeError(f'ERROR: cannot read {path}: no such file')
+    try:
+        return _open_hdf5(path, lazy)
+    except hdf5min.Hdf5Error:
+        pass
     try:
         import xarray
     except ImportError as e:
@@ -69,7 +100,7 @@ def open_tfile(path):
 
 
 def open_uvfile(path, name):
-    d = _open(path)
+    d = _open(path, lazy=(name,))
     if name not in d:
         raise RuntimeError(f'ERROR: could not read {name} field')  # field.py:154
     fill = d.get('_FillValue_' + name, numpy.array(numpy.nan))

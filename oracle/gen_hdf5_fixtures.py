@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Write the small HDF5 / NetCDF-4-like files that pin nemoflux_amd/hdf5min.py (test infrastructure).
+
+Needs h5py (this image: /opt/conda/bin/python3.9 oracle/gen_hdf5_fixtures.py).  Every array is a deterministic
+function of its shape (see `field`), so the tests recompute the expected values instead of storing them twice.
+The files cover the HDF5 structures netCDF-4 / XIOS / h5py produce for NEMO-like data:
+  old_style.h5      libver earliest: symbol-table groups, v1 object headers; contiguous f64, chunked+gzip+shuffle f32
+                    with ragged edge chunks (4-D like uo), big-endian f4, int32, compact storage, _FillValue attributes
+  new_compact.h5    creation-order tracking: v2 object headers, compact Link messages
+  new_dense.h5      > 8 links and > 8 attributes: fractal-heap (dense) link and attribute storage, fletcher32
+  latest.h5         libver latest: superblock v3, layout message v4 (single-chunk index; other indexes unsupported)
+"""
+import os
+import sys
+
+import h5py
+import numpy
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden', 'h5')
+
+
+def field(shape, dtype, seed):
+    n = int(numpy.prod(shape))
+    a = numpy.sin(0.37 * numpy.arange(n, dtype=numpy.float64) + seed) * (1 + seed)
+    if numpy.dtype(dtype).kind in 'iu':
+        a = numpy.floor(a * 1000)
+    return a.reshape(shape).astype(dtype)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    with h5py.File(os.path.join(OUT, 'old_style.h5'), 'w', libver='earliest') as f:
+        f.create_dataset('bounds_lon', data=field((5, 7, 4), '<f8', 1))
+        d = f.create_dataset('uo', data=field((3, 4, 9, 11), '<f4', 2), chunks=(1, 2, 4, 5), compression='gzip',
+                             compression_opts=4, shuffle=True)
+        d.attrs.create('_FillValue', numpy.float32(1.e20))
+        d.attrs['units'] = 'm/s'
+        f.create_dataset('vo', data=field((3, 4, 9, 11), '<f4', 3), chunks=(3, 4, 9, 11))     # one chunk, no filter
+        f.create_dataset('time_counter', data=field((12,), '>f4', 4))
+        f.create_dataset('index', data=field((6,), '<i4', 5))
+        f.create_dataset('tiny', data=field((3,), '<f8', 6), chunks=None)
+        g = f.create_group('sub')
+        g.create_dataset('inner', data=field((2, 2), '<f8', 7))
+    with h5py.File(os.path.join(OUT, 'new_compact.h5'), 'w', libver='earliest', track_order=True) as f:
+        f.create_dataset('bounds_lat', data=field((5, 7, 4), '<f4', 8), track_order=True)
+        d = f.create_dataset('deptht_bounds', data=field((75, 2), '<f4', 9), track_order=True)
+        d.attrs.create('_FillValue', numpy.float32(-999.0))
+    with h5py.File(os.path.join(OUT, 'new_dense.h5'), 'w', libver='earliest', track_order=True) as f:
+        for k in range(14):
+            f.create_dataset(f'var{k:02d}', data=field((4, 3), '<f8', 10 + k), track_order=True)
+        d = f.create_dataset('vo', data=field((2, 3, 8, 6), '<f4', 30), chunks=(1, 3, 8, 6), compression='gzip',
+                             fletcher32=True, track_order=True)
+        for k in range(11):
+            d.attrs[f'attr{k:02d}'] = f'value {k}'
+        d.attrs.create('_FillValue', numpy.float32(1.e20))
+    with h5py.File(os.path.join(OUT, 'latest.h5'), 'w', libver='latest') as f:
+        f.create_dataset('contig', data=field((6, 5), '<f8', 40))
+        f.create_dataset('single_chunk', data=field((6, 5), '<f4', 41), chunks=(6, 5), compression='gzip')
+        f.create_dataset('many_chunks', data=field((6, 5), '<f4', 42), chunks=(2, 5))
+    # a NEMO-like T/U/V triple built from the golden case def36_zt (reference datagen output), the way XIOS/netCDF-4
+    # writes it: float32, uo chunked + shuffled + deflated with land as _FillValue, vo contiguous with NaN land
+    g = numpy.load(os.path.join(OUT, '..', 'def36_zt.npz'))
+    u, v = g['u'].astype('<f4'), g['v'].astype('<f4')
+    u[:, :, 4:9, 10:20] = numpy.float32(1.e20)
+    v[:, :, 4:9, 10:20] = numpy.nan
+    with h5py.File(os.path.join(OUT, 'nemo_T.h5'), 'w', libver='earliest', track_order=True) as f:
+        f.create_dataset('bounds_lon', data=g['bounds_lon'].astype('<f4'), track_order=True)
+        f.create_dataset('bounds_lat', data=g['bounds_lat'].astype('<f4'), track_order=True)
+        f.create_dataset('deptht_bounds', data=g['deptht_bounds'].astype('<f4'), track_order=True)
+    with h5py.File(os.path.join(OUT, 'nemo_U.h5'), 'w', libver='earliest', track_order=True) as f:
+        d = f.create_dataset('uo', data=u, chunks=(1, 1, 9, 18), compression='gzip', shuffle=True, track_order=True)
+        d.attrs.create('_FillValue', numpy.float32(1.e20))
+        for k in range(9):
+            d.attrs[f'note{k}'] = numpy.float64(k)
+        f.create_dataset('time_counter', data=numpy.arange(3, dtype='>f8'), track_order=True)
+    with h5py.File(os.path.join(OUT, 'nemo_V.h5'), 'w', libver='earliest') as f:
+        f.create_dataset('vo', data=v)
+    print('wrote', sorted(os.listdir(OUT)))
+
+
+if __name__ == '__main__':
+    main()

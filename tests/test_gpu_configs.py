@@ -685,3 +685,32 @@ def test_path_independence_random_psi_gpu(rotated, oracle):
         pli.buildLocator(numCellsPerBucket=128, periodX=360., enableFolding=False)
         pli.computeWeights(xyz, counterclock=False)
         assert abs(pli.getIntegral(data) - want) <= 1e-11, (rotated, trial)
+
+
+def test_field_from_netcdf4_style_files():
+    """Field(tFile, uFile, vFile, ...) straight from NetCDF-4-style HDF5 files (tests/golden/h5/nemo_*.h5: float32,
+    uo chunked + shuffled + deflated and read one time step at a time, vo a zero-copy view of the mapped file) equals
+    Field.fromArrays on the same values, bit for bit, step by step and through computeAll."""
+    import contextlib
+    import io as _io
+    from nemoflux_amd.field import Field
+    g = load_golden('def36_zt')
+    h5 = os.path.join(GOLDEN, 'h5')
+    u = g['u'].astype(numpy.float32)
+    v = g['v'].astype(numpy.float32)
+    u[:, :, 4:9, 10:20] = numpy.float32(1.e20)
+    v[:, :, 4:9, 10:20] = numpy.nan
+    tr = [transect_xyz(T_OPEN), transect_xyz("(-180,-70),(-160,-10),(-35,40),(20,-50),(60,50),(180,40)")]
+    with contextlib.redirect_stdout(_io.StringIO()):
+        ff = Field(os.path.join(h5, 'nemo_T.h5'), os.path.join(h5, 'nemo_U.h5'), os.path.join(h5, 'nemo_V.h5'), tr)
+    fa = quiet_field(g['bounds_lon'].astype(numpy.float32), g['bounds_lat'].astype(numpy.float32),
+                     g['deptht_bounds'].astype(numpy.float32), u, v, tr, fill_value=float(numpy.float32(1.e20)))
+    assert (ff.nt, ff.nz, ff.ny, ff.nx) == (3, 2, 18, 36)
+    for t in (2, 0, 1):
+        assert ff.computeFlux(t, readback=True) == fa.computeFlux(t, readback=True)
+        assert numpy.array_equal(ff.integratedVelocity, fa.integratedVelocity)
+        assert numpy.array_equal(ff.edgeFluxesUArray, fa.edgeFluxesUArray)
+    ft, fs = ff.computeAll()
+    at, as_ = fa.computeAll()
+    assert numpy.array_equal(ft, at) and numpy.array_equal(fs, as_)
+    assert ff.maxAbsFlux == fa.maxAbsFlux

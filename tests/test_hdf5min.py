@@ -1,0 +1,104 @@
+"""CPU suite, part 4: nemoflux_amd/hdf5min.py (the in-process NetCDF-4/HDF5 reader) against files written by the real
+HDF5 library through h5py (oracle/gen_hdf5_fixtures.py, run under /opt/conda/bin/python3.9) and against the reference's
+own data/sa/T.nc.  Expected values are recomputed from the generator's formula."""
+import os
+
+import numpy
+import pytest
+
+from conftest import GOLDEN, load_golden
+
+H5 = os.path.join(GOLDEN, 'h5')
+
+
+def field(shape, dtype, seed):
+    n = int(numpy.prod(shape))
+    a = numpy.sin(0.37 * numpy.arange(n, dtype=numpy.float64) + seed) * (1 + seed)
+    if numpy.dtype(dtype).kind in 'iu':
+        a = numpy.floor(a * 1000)
+    return a.reshape(shape).astype(dtype)
+
+
+EXPECTED = {
+    'old_style': {'bounds_lon': ((5, 7, 4), '<f8', 1), 'uo': ((3, 4, 9, 11), '<f4', 2), 'vo': ((3, 4, 9, 11), '<f4', 3),
+                  'time_counter': ((12,), '>f4', 4), 'index': ((6,), '<i4', 5), 'tiny': ((3,), '<f8', 6),
+                  'sub/inner': ((2, 2), '<f8', 7)},
+    'new_compact': {'bounds_lat': ((5, 7, 4), '<f4', 8), 'deptht_bounds': ((75, 2), '<f4', 9)},
+    'new_dense': dict([(f'var{k:02d}', ((4, 3), '<f8', 10 + k)) for k in range(14)] + [('vo', ((2, 3, 8, 6), '<f4', 30))]),
+    'latest': {'contig': ((6, 5), '<f8', 40), 'single_chunk': ((6, 5), '<f4', 41)},
+}
+
+
+@pytest.mark.parametrize('fname', sorted(EXPECTED))
+def test_every_variable_bit_exact(fname):
+    from nemoflux_amd import hdf5min
+    with hdf5min.File(os.path.join(H5, fname + '.h5')) as f:
+        assert set(EXPECTED[fname]) <= set(f.datasets)
+        for name, (shape, dt, seed) in EXPECTED[fname].items():
+            ds = f.datasets[name]
+            a = ds.read()
+            want = field(shape, dt, seed)
+            assert a.shape == shape and a.dtype == numpy.dtype(dt)
+            assert numpy.array_equal(a.astype(a.dtype.newbyteorder('=')), want.astype(want.dtype.newbyteorder('=')))
+            if len(shape) >= 2:   # one leading slab at a time == slicing the whole array
+                for i in range(shape[0]):
+                    assert numpy.array_equal(ds.read_leading(i), a[i])
+            with pytest.raises(hdf5min.Hdf5Error):
+                ds.read_leading(shape[0])
+
+
+def test_fill_values_attributes_and_storage_kinds():
+    from nemoflux_amd import hdf5min
+    f = hdf5min.File(os.path.join(H5, 'old_style.h5'))
+    assert f.datasets['uo'].fill_value == numpy.float32(1.e20) and f.datasets['vo'].fill_value is None
+    assert f.datasets['bounds_lon'].is_contiguous() and not f.datasets['uo'].is_contiguous()
+    a = f.datasets['bounds_lon'].read()
+    assert not a.flags.owndata and not a.flags.writeable        # a view of the mapped file, no copy
+    assert hdf5min.File(os.path.join(H5, 'new_compact.h5')).datasets['deptht_bounds'].fill_value == numpy.float32(-999.0)
+    # > 8 attributes -> dense (fractal heap + v2 B-tree) storage, _FillValue created through a rename
+    d = hdf5min.File(os.path.join(H5, 'new_dense.h5')).datasets['vo']
+    assert d.fill_value == numpy.float32(1.e20)
+    # HDF5 1.10 "latest" chunk indexes other than single-chunk are refused, never guessed
+    g = hdf5min.File(os.path.join(H5, 'latest.h5'))
+    assert isinstance(g.datasets['many_chunks'], hdf5min.Hdf5Error)
+    with pytest.raises(hdf5min.Hdf5Error):
+        hdf5min.read_variables(os.path.join(H5, 'latest.h5'))
+    with pytest.raises(hdf5min.Hdf5Error, match='not an HDF5 file'):
+        hdf5min.File(os.path.join(GOLDEN, 'cases.json'))
+
+
+def test_nemo_like_triple_through_io():
+    """nemoflux_amd.io on a NetCDF-4-style T/U/V triple: float32, uo chunked+shuffled+deflated (read lazily, one time
+    step at a time) with _FillValue among 10 attributes, vo contiguous (zero-copy view) with NaN land."""
+    from nemoflux_amd import hdf5min, io
+    g = load_golden('def36_zt')
+    t = io.open_tfile(os.path.join(H5, 'nemo_T.h5'))
+    for k in ('bounds_lon', 'bounds_lat', 'deptht_bounds'):
+        assert numpy.array_equal(t[k], g[k].astype(numpy.float32))
+    uo, fu = io.open_uvfile(os.path.join(H5, 'nemo_U.h5'), 'uo')
+    vo, fv = io.open_uvfile(os.path.join(H5, 'nemo_V.h5'), 'vo')
+    assert isinstance(uo, hdf5min.LazyVariable) and uo.shape == (3, 2, 18, 36) and fu == float(numpy.float32(1.e20))
+    assert isinstance(vo, numpy.ndarray) and not vo.flags.owndata and numpy.isnan(fv)
+    u = g['u'].astype(numpy.float32)
+    u[:, :, 4:9, 10:20] = numpy.float32(1.e20)
+    for tt in range(3):
+        a = uo.read_step(tt)
+        assert a.flags.c_contiguous and a.dtype == numpy.float32 and numpy.array_equal(a, u[tt])
+    assert numpy.isnan(vo[:, :, 4:9, 10:20]).all()
+    with pytest.raises(RuntimeError, match='could not read vo'):
+        io.open_uvfile(os.path.join(H5, 'nemo_U.h5'), 'vo')
+
+
+def test_reference_t_file_in_process():
+    """The reference's real NetCDF-4 file (superblock 0, v2 object headers, dense links): hdf5min == committed fixture."""
+    from nemoflux_amd import hdf5min
+    src = '/root/reference/data/sa/T.nc'
+    if not os.path.exists(src):
+        pytest.skip('reference tree not present')
+    d = hdf5min.read_variables(src)
+    g = load_golden('sa_T_bounds')
+    for k in g.files:
+        assert numpy.array_equal(d[k], g[k])
+    assert d['time_counter'].shape == (12,) and d['deptht'].shape == (75,)
+    with hdf5min.File(src) as f:
+        assert f.datasets['deptht'].attrs['units'] == b'm' and f.datasets['deptht'].attrs['axis'] == b'Z'
