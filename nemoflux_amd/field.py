@@ -15,6 +15,7 @@ from . import _lib, mint
 from ._lib import lib, check, NF_F64, NF_F32
 from .horizgrid import HorizGrid
 from .io import open_tfile, open_uvfile
+from .timeobj import TimeObj
 
 EARTH_RADIUS = 6371000.0  # field.py:12
 
@@ -125,9 +126,10 @@ class Field(object):
         t = open_tfile(tFile)
         if 'deptht_bounds' not in t:
             raise RuntimeError(f'ERROR: {tFile} has no variable deptht_bounds')
-        uo, fu = open_uvfile(uFile, 'uo')
+        uo, fu, uvars = open_uvfile(uFile, 'uo', with_all=True)
         vo, fv = open_uvfile(vFile, 'vo')
         fill = kw.pop('fill_value', fu if not numpy.isnan(fu) else fv)
+        kw.setdefault('timeObj', TimeObj.fromVariables(uvars))   # field.py:38: TimeObj(self.ncU)
         self._setup(t['bounds_lon'], t['bounds_lat'], t['deptht_bounds'], uo, vo, lonLatZPoints, sverdrup,
                     fill_value=fill, **kw)
 
@@ -142,7 +144,7 @@ class Field(object):
     # ------------------------------------------------------------------------------------------
     def _setup(self, bounds_lon, bounds_lat, deptht_bounds, uo, vo, lonLatZPoints, sverdrup,
                fill_value=numpy.nan, periodX=360., numCellsPerBucket=128, slab_range=None, readback=True,
-               timeValues=None, stream=None):
+               timeValues=None, stream=None, timeObj=None):
         _lib.require_gpu()
         self.sverdrup = sverdrup
         self.periodX = periodX
@@ -175,7 +177,7 @@ class Field(object):
         print(f'lon-lat box: {self.lonmin}, {self.latmin} -> {self.lonmax}, {self.latmax}')  # field.py:31
 
         self.timeIndex = 0
-        self.timeObj = _TimeObj(timeValues)
+        self.timeObj = timeObj if timeObj is not None else _TimeObj(timeValues)
 
         # --- uo / vo (field.py:34-35, 122-136)
         self.nt, self.nz, sy, sx = self.getSizes(tuple(uo.shape))

@@ -59,6 +59,8 @@ def _open_hdf5(path, lazy=()):
             out[name] = a if a.dtype.isnative else a.astype(a.dtype.newbyteorder('='))
         if ds.fill_value is not None:
             out['_FillValue_' + name] = numpy.asarray(ds.fill_value)
+        if len(ds.shape) == 1:     # coordinate variables: keep the CF attributes (time axis labelling, timeobj.py:9-13)
+            out['_attrs_' + name] = dict(ds.attrs)
     out['_hdf5_file'] = f      # keeps the mapping alive for the views
     return out
 
@@ -99,9 +101,9 @@ def open_tfile(path):
     return d
 
 
-def open_uvfile(path, name):
+def open_uvfile(path, name, with_all=False):
     d = _open(path, lazy=(name,))
     if name not in d:
         raise RuntimeError(f'ERROR: could not read {name} field')  # field.py:154
     fill = d.get('_FillValue_' + name, numpy.array(numpy.nan))
-    return d[name], float(fill)
+    return (d[name], float(fill), d) if with_all else (d[name], float(fill))

@@ -72,7 +72,12 @@ def main():
         d.attrs.create('_FillValue', numpy.float32(1.e20))
         for k in range(9):
             d.attrs[f'note{k}'] = numpy.float64(k)
-        f.create_dataset('time_counter', data=numpy.arange(3, dtype='>f8'), track_order=True)
+        tc = f.create_dataset('time_counter', data=(numpy.arange(3) * 86400. * 30.5 + 1296000.).astype('>f8'),
+                              track_order=True)
+        tc.attrs.create('standard_name', numpy.string_('time'))
+        tc.attrs.create('long_name', numpy.string_('Time axis'))
+        tc.attrs.create('units', numpy.string_('seconds since 1900-01-01 00:00:00'))
+        tc.attrs.create('calendar', numpy.string_('noleap'))
     with h5py.File(os.path.join(OUT, 'nemo_V.h5'), 'w', libver='earliest') as f:
         f.create_dataset('vo', data=v)
     print('wrote', sorted(os.listdir(OUT)))

@@ -714,3 +714,19 @@ def test_field_from_netcdf4_style_files():
     at, as_ = fa.computeAll()
     assert numpy.array_equal(ft, at) and numpy.array_equal(fs, as_)
     assert ff.maxAbsFlux == fa.maxAbsFlux
+
+
+def test_field_time_axis_from_file():
+    """Field built from files carries the U file's time axis (field.py:38) with decoded dates (fluxviz.py:204 title)."""
+    import contextlib
+    import io as _io
+    from nemoflux_amd.field import Field
+    h5 = os.path.join(GOLDEN, 'h5')
+    with contextlib.redirect_stdout(_io.StringIO()):
+        f = Field(os.path.join(h5, 'nemo_T.h5'), os.path.join(h5, 'nemo_U.h5'), os.path.join(h5, 'nemo_V.h5'),
+                  [transect_xyz(T_OPEN)])
+    assert f.timeObj.getSize() == f.nt == 3
+    assert f.timeObj.getTimeAsString(1) == '1900-2-15'
+    g = load_golden('c1_x')
+    f2 = quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], g['u'], g['v'], [])
+    assert f2.timeObj.getTimeAsString(0) == '0'          # no time axis in datagen output: index labels, no exception

@@ -102,3 +102,24 @@ def test_reference_t_file_in_process():
     assert d['time_counter'].shape == (12,) and d['deptht'].shape == (75,)
     with hdf5min.File(src) as f:
         assert f.datasets['deptht'].attrs['units'] == b'm' and f.datasets['deptht'].attrs['axis'] == b'Z'
+
+
+def test_time_axis_labels():
+    """nemoflux/timeobj.py:9-34 on the engine's own decoding: the time variable is found by standard_name / long_name,
+    dates come out as year-month-day strings for the calendars NEMO writes; no time variable -> index labels."""
+    from nemoflux_amd import io
+    from nemoflux_amd.timeobj import TimeObj
+    uo, fill, allv = io.open_uvfile(os.path.join(H5, 'nemo_U.h5'), 'uo', with_all=True)
+    to = TimeObj.fromVariables(allv)
+    assert to.timeVarName == 'time_counter' and to.getSize() == 3
+    # 15 days, 45.5 days, 76 days after 1900-01-01 in a 365-day calendar
+    assert [to.getTimeAsString(i) for i in range(3)] == ['1900-1-16', '1900-2-15', '1900-3-18']
+    assert str(to.getTimeAsDate(0)) == '1900-01-16'
+    T = TimeObj
+    assert [T([425], 'days since 2000-01-01', c).getTimeAsString(0) for c in ('gregorian', 'noleap', '360_day', 'all_leap')] \
+        == ['2001-3-1', '2001-3-2', '2001-3-6', '2001-2-29']
+    assert T([3600 * 36], 'seconds since 1950-01-01 12:00:00', 'standard').getTimeAsString(0) == '1950-1-3'
+    assert T([1.5], 'hours since 2020-02-28 23:00:00').getTimeAsString(0) == '2020-2-29'
+    empty = T.fromVariables(io.open_tfile(os.path.join(H5, 'nemo_T.h5')))
+    assert empty.getSize() == 0 and empty.getTimeAsString(4) == '4' and empty.getTimeAsDate(2) == 2
+    assert T([59], 'days since 2001-01-01', '360_day').getTimeAsDate(0) == 0   # 30 February has no datetime.date
