@@ -153,49 +153,38 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
         }
         const T *pu = u + (long)z0 * ncell + base;
         const T *pv = v + (long)z0 * ncell + base;
-        int z = z0;
-        for (; z + UZ <= z1; z += UZ) {
+        // batches of UZ levels: all loads of a batch are issued before its first use; the last batch may be partial
+        // (wave-uniform predicate), so the tail levels are in flight together too instead of one at a time
+        for (int z = z0; z < z1; z += UZ) {
+            const int nlev = z1 - z < UZ ? z1 - z : UZ;
             Lanes<T, VEC> lu[UZ][CH], lv[UZ][CH];
 #pragma unroll
             for (int r = 0; r < UZ; ++r)
+                if (r < nlev) {
 #pragma unroll
-                for (int q = 0; q < CH; ++q)
-                    if (on[q]) {
-                        lu[r][q] = load_cells<T, VEC, NT>(pu + (long)r * ncell + q * kChunk);
-                        lv[r][q] = load_cells<T, VEC, NT>(pv + (long)r * ncell + q * kChunk);
-                    }
-#pragma unroll
-            for (int r = 0; r < UZ; ++r) {
-                const double th = thickness[z + r];
-#pragma unroll
-                for (int q = 0; q < CH; ++q)
-                    if (on[q]) {
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) {
-                            accU[q][k] = fma(th, (DIAG & 2) ? (double)lu[r][q].x[k] : fixed<T>(lu[r][q].x[k], fill), accU[q][k]);
-                            accV[q][k] = fma(th, (DIAG & 2) ? (double)lv[r][q].x[k] : fixed<T>(lv[r][q].x[k], fill), accV[q][k]);
+                    for (int q = 0; q < CH; ++q)
+                        if (on[q]) {
+                            lu[r][q] = load_cells<T, VEC, NT>(pu + (long)r * ncell + q * kChunk);
+                            lv[r][q] = load_cells<T, VEC, NT>(pv + (long)r * ncell + q * kChunk);
                         }
-                    }
-            }
+                }
+#pragma unroll
+            for (int r = 0; r < UZ; ++r)
+                if (r < nlev) {
+                    const double th = thickness[z + r];
+#pragma unroll
+                    for (int q = 0; q < CH; ++q)
+                        if (on[q]) {
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) {
+                                accU[q][k] = fma(th, (DIAG & 2) ? (double)lu[r][q].x[k] : fixed<T>(lu[r][q].x[k], fill), accU[q][k]);
+                                accV[q][k] = fma(th, (DIAG & 2) ? (double)lv[r][q].x[k] : fixed<T>(lv[r][q].x[k], fill), accV[q][k]);
+                            }
+                        }
+                }
             pu += (long)UZ * ncell;
             pv += (long)UZ * ncell;
             if (SYNC) __syncthreads();
-        }
-        for (; z < z1; ++z) {
-            const double th = thickness[z];
-#pragma unroll
-            for (int q = 0; q < CH; ++q)
-                if (on[q]) {
-                    Lanes<T, VEC> lu = load_cells<T, VEC, NT>(pu + q * kChunk);
-                    Lanes<T, VEC> lv = load_cells<T, VEC, NT>(pv + q * kChunk);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        accU[q][k] = fma(th, fixed<T>(lu.x[k], fill), accU[q][k]);
-                        accV[q][k] = fma(th, fixed<T>(lv.x[k], fill), accV[q][k]);
-                    }
-                }
-            pu += ncell;
-            pv += ncell;
         }
         // edge fluxes (field.py:195-196, 225-228)
 #pragma unroll
@@ -481,20 +470,22 @@ template <typename T, int VEC>
 static int launch_flux_v(const FluxArgs &a, hipStream_t s)
 {
     const int variant = a.batch.zr ? 0 : g_variant;  // the multi-step launch exists for the default kernel only
-    if (VEC == 1) return launch_flux_t<T, VEC, 4, false, 256, 1, false>(a, s);
+    if (VEC == 1) return launch_flux_t<T, VEC, 8, false, 256, 1, false>(a, s);
     switch (variant) {
         // measured alternatives (tools/ab_flux.py): all within +-3 % of the default
-        case 4: return launch_flux_t<T, VEC, 4, true, 256, 2, false>(a, s);   // 2 chunks per lane
-        case 11: return launch_flux_t<T, VEC, 4, false, 256, 1, false>(a, s);  // plain (temporal) loads: -4 %
+        case 3: return launch_flux_t<T, VEC, 4, true, 256, 1, false>(a, s);    // 4 levels in flight (+2..3 %)
+        case 4: return launch_flux_t<T, VEC, 4, true, 256, 2, false>(a, s);    // 4 levels, 2 chunks per lane
+        case 11: return launch_flux_t<T, VEC, 10, false, 256, 1, false>(a, s); // plain (temporal) loads: +4 %
         case 12: return launch_flux_t<T, VEC, 8, true, 256, 1, false>(a, s);   // 8 levels in flight
+        case 14: return launch_flux_t<T, VEC, 16, true, 256, 1, false>(a, s);  // 16 levels in flight
         case 40: return launch_flux_ww<T, VEC, 2>(a, s);                       // writer-wave form
         // diagnostic builds (WRONG RESULTS on purpose) that price one ingredient each
-        case 21: return launch_flux_t<T, VEC, 4, true, 256, 1, false, 1>(a, s);   // no stores
-        case 25: return launch_flux_t<T, VEC, 4, true, 256, 1, false, 5>(a, s);   // no stores, no atomic max
-        case 28: return launch_flux_t<T, VEC, 4, true, 256, 1, false, 16>(a, s);  // only the two signed planes
-        case 29: return launch_flux_t<T, VEC, 4, true, 256, 1, false, 32>(a, s);  // one interleaved (eU,eV) stream
+        case 21: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 1>(a, s);   // no stores
+        case 25: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 5>(a, s);   // no stores, no atomic max
+        case 28: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 16>(a, s);  // only the two signed planes
+        case 29: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 32>(a, s);  // one interleaved (eU,eV) stream
         case 45: return launch_flux_ww<T, VEC, 2, 2>(a, s);                        // writer-wave, no stores
-        default: return launch_flux_t<T, VEC, 4, true, 256, 1, false>(a, s);
+        default: return launch_flux_t<T, VEC, 10, true, 256, 1, false>(a, s);  // 10 levels x 2 fields in flight
     }
 }
 
