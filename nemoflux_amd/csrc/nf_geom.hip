@@ -14,7 +14,7 @@
 // of a wavefront are 256 CONTIGUOUS values: they are read coalesced (lane k <- element k), staged in LDS
 // and re-read per cell (lane c <- its 4 lon + 4 lat).  The arithmetic follows geo.py statement by
 // statement (same operation order, no fma contraction: built with -ffp-contract=off); device sin/cos/acos
-// differ from glibc by ulps, which acos amplifies by 1/sin(angle) -- see tests/test_geometry.py.
+// differ from glibc by ulps, which acos amplifies by 1/sin(angle) -- see test_geometry in tests/test_gpu_parity.py.
 #include "nf_common.h"
 
 namespace nf {

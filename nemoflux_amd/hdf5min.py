@@ -17,7 +17,9 @@ Contiguous little-endian data is returned as a numpy memmap of the file itself -
 Field makes the engine stage each time step from the page cache straight to HBM.  Anything this reader does not
 understand raises Hdf5Error (it never guesses); nemoflux_amd.io then falls back to xarray or an h5py interpreter.
 """
+import concurrent.futures
 import mmap
+import os
 import zlib
 
 import numpy
@@ -30,10 +32,22 @@ class Hdf5Error(RuntimeError):
     pass
 
 
+def io_threads():
+    """Worker threads for chunk inflation: NF_IO_THREADS, else the cores this process may run on (at most 32)."""
+    n = os.environ.get('NF_IO_THREADS')
+    if n:
+        return max(1, int(n))
+    try:
+        return min(32, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return min(32, os.cpu_count() or 1)
+
+
 class Dataset(object):
-    def __init__(self, h5, name, shape, dtype, layout, filters, attrs):
+    def __init__(self, h5, name, shape, dtype, layout, filters, attrs, h5fill=None):
         self._h5, self.name, self.shape, self.dtype = h5, name, tuple(shape), dtype
         self._layout, self._filters, self.attrs = layout, filters, attrs
+        self.h5fill = h5fill       # value of the HDF5 fill-value message: what never-written chunks read as
 
     @property
     def fill_value(self):
@@ -67,8 +81,10 @@ class Dataset(object):
             return self.read()[i]
         return self._read_chunked(lead=i)[0]
 
-    def _decode(self, raw, filter_mask, nbytes):
-        # filters are undone in reverse order of application
+    def _decode(self, raw, filter_mask, nbytes, dst=None):
+        """Undo the filter pipeline (in reverse order of application).  When the last step is the un-shuffle and `dst`
+        (a C-contiguous uint8 view of the chunk's place in the output) is given, that step writes straight into it and
+        None is returned: no intermediate copy, and the strided numpy assignments run without the GIL."""
         for k in range(len(self._filters) - 1, -1, -1):
             fid, cd = self._filters[k]
             if filter_mask & (1 << k):
@@ -79,6 +95,12 @@ class Dataset(object):
                 es = cd[0] if cd else self.dtype.itemsize
                 a = numpy.frombuffer(raw, numpy.uint8)
                 ne = a.size // es
+                last = not any(not (filter_mask & (1 << j)) for j in range(k))
+                if dst is not None and last and ne * es == a.size == dst.size:
+                    d2 = dst.reshape(ne, es)
+                    for j in range(es):
+                        d2[:, j] = a[j * ne:(j + 1) * ne]
+                    return None
                 raw = a[:ne * es].reshape(es, ne).T.tobytes() + a[ne * es:].tobytes()
             elif fid == 3:  # fletcher32: checksum appended
                 raw = raw[:-4]
@@ -92,26 +114,42 @@ class Dataset(object):
         _, btree, cdims, single = self._layout
         rank = len(self.shape)
         cshape = tuple(cdims[:rank])
-        lo = 0 if lead is None else lead          # window [lo, lo + nlead) of the leading axis
         shape = self.shape if lead is None else (1,) + self.shape[1:]
-        out = numpy.zeros(shape, self.dtype)
         nbytes = int(numpy.prod(cshape)) * self.dtype.itemsize
         if getattr(self, '_chunks', None) is None:
             self._chunks = [single] if single is not None else list(self._h5._chunk_btree(btree, rank))
-        for offs, size, mask, addr in self._chunks:
-            if addr == UNDEF:
-                continue
-            if lead is not None and not (offs[0] <= lead < offs[0] + cshape[0]):
-                continue
-            raw = self._h5._m[self._h5._base + addr: self._h5._base + addr + size]
-            raw = self._decode(raw, mask, nbytes)
-            blk = numpy.frombuffer(raw, self.dtype, count=nbytes // self.dtype.itemsize).reshape(cshape)
+        todo = [c for c in self._chunks if c[3] != UNDEF and
+                (lead is None or c[0][0] <= lead < c[0][0] + cshape[0])]
+        expected = int(numpy.prod([-(-s // c) for s, c in zip(shape, cshape)]))
+        if len(todo) >= expected:
+            out = numpy.empty(shape, self.dtype)
+        else:   # chunks that were never written read as the HDF5 fill value (0 when the file defines none)
+            out = numpy.full(shape, 0 if self.h5fill is None else self.h5fill, self.dtype)
+
+        def place(chunk):
+            offs, size, mask, addr = chunk
             sl_out = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cshape, self.shape))
             sl_in = tuple(slice(0, s.stop - s.start) for s in sl_out)
             if lead is not None:
                 sl_in = (slice(lead - offs[0], lead - offs[0] + 1),) + sl_in[1:]
                 sl_out = (slice(0, 1),) + sl_out[1:]
-            out[sl_out] = blk[sl_in]
+            dst = out[sl_out]
+            direct = dst.shape == cshape and dst.flags.c_contiguous     # whole chunk, one contiguous run of `out`
+            raw = self._h5._m[self._h5._base + addr: self._h5._base + addr + size]
+            raw = self._decode(raw, mask, nbytes, dst.reshape(-1).view(numpy.uint8) if direct else None)
+            if raw is not None:
+                blk = numpy.frombuffer(raw, self.dtype, count=nbytes // self.dtype.itemsize).reshape(cshape)
+                dst[...] = blk[sl_in]     # chunks never overlap: the writes of concurrent workers are disjoint
+
+        # zlib.decompress and the numpy copies release the GIL, so the chunks of one time step (real NEMO files: one
+        # deflated chunk per level) inflate on all host cores at once
+        nthreads = min(io_threads(), len(todo))
+        if nthreads > 1:
+            with concurrent.futures.ThreadPoolExecutor(nthreads) as pool:
+                list(pool.map(place, todo))
+        else:
+            for chunk in todo:
+                place(chunk)
         return out
 
 
@@ -401,11 +439,10 @@ class File(object):
                         for k, v in self._fractal_heap_objects(heap, self._attribute_item, btree, 0):
                             if v is not None:
                                 attrs[k] = v
-            if '_FillValue' not in attrs:   # netCDF-4 mirrors _FillValue in the HDF5 fill-value message
-                fv = self._fill_value(info, dt)
-                if fv is not None:
-                    attrs['_FillValue'] = fv
-            self.datasets[prefix + name] = Dataset(self, prefix + name, shape, dt, layout, filters, attrs)
+            fv = self._fill_value(info, dt)
+            if '_FillValue' not in attrs and fv is not None:   # netCDF-4 mirrors _FillValue in the fill-value message
+                attrs['_FillValue'] = fv
+            self.datasets[prefix + name] = Dataset(self, prefix + name, shape, dt, layout, filters, attrs, fv)
         elif 0x11 in info or 0x02 in info or 0x06 in info:
             self._walk_group(addr, prefix + name + '/', depth + 1)
 

@@ -5,7 +5,8 @@ Needs h5py (this image: /opt/conda/bin/python3.9 oracle/gen_hdf5_fixtures.py).  
 function of its shape (see `field`), so the tests recompute the expected values instead of storing them twice.
 The files cover the HDF5 structures netCDF-4 / XIOS / h5py produce for NEMO-like data:
   old_style.h5      libver earliest: symbol-table groups, v1 object headers; contiguous f64, chunked+gzip+shuffle f32
-                    with ragged edge chunks (4-D like uo), big-endian f4, int32, compact storage, _FillValue attributes
+                    with ragged edge chunks (4-D like uo), whole-plane chunks, a partly written chunked variable,
+                    big-endian f4, int32, compact storage, _FillValue attributes
   new_compact.h5    creation-order tracking: v2 object headers, compact Link messages
   new_dense.h5      > 8 links and > 8 attributes: fractal-heap (dense) link and attribute storage, fletcher32
   latest.h5         libver latest: superblock v3, layout message v4 (single-chunk index; other indexes unsupported)
@@ -41,6 +42,12 @@ def main():
         f.create_dataset('tiny', data=field((3,), '<f8', 6), chunks=None)
         g = f.create_group('sub')
         g.create_dataset('inner', data=field((2, 2), '<f8', 7))
+        # one deflated + shuffled chunk per (t, level) plane, as XIOS writes uo/vo (whole-plane chunks)
+        f.create_dataset('planes', data=field((2, 3, 4, 6), '<f4', 50), chunks=(1, 1, 4, 6), compression='gzip',
+                         shuffle=True)
+        # only one of the four chunks is ever written: the others read as the HDF5 fill value
+        d = f.create_dataset('sparse', shape=(4, 6), dtype='<f8', chunks=(2, 3), fillvalue=7.5)
+        d[2:4, 0:3] = field((2, 3), '<f8', 51)
     with h5py.File(os.path.join(OUT, 'new_compact.h5'), 'w', libver='earliest', track_order=True) as f:
         f.create_dataset('bounds_lat', data=field((5, 7, 4), '<f4', 8), track_order=True)
         d = f.create_dataset('deptht_bounds', data=field((75, 2), '<f4', 9), track_order=True)

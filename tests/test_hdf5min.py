@@ -22,7 +22,7 @@ def field(shape, dtype, seed):
 EXPECTED = {
     'old_style': {'bounds_lon': ((5, 7, 4), '<f8', 1), 'uo': ((3, 4, 9, 11), '<f4', 2), 'vo': ((3, 4, 9, 11), '<f4', 3),
                   'time_counter': ((12,), '>f4', 4), 'index': ((6,), '<i4', 5), 'tiny': ((3,), '<f8', 6),
-                  'sub/inner': ((2, 2), '<f8', 7)},
+                  'sub/inner': ((2, 2), '<f8', 7), 'planes': ((2, 3, 4, 6), '<f4', 50)},
     'new_compact': {'bounds_lat': ((5, 7, 4), '<f4', 8), 'deptht_bounds': ((75, 2), '<f4', 9)},
     'new_dense': dict([(f'var{k:02d}', ((4, 3), '<f8', 10 + k)) for k in range(14)] + [('vo', ((2, 3, 8, 6), '<f4', 30))]),
     'latest': {'contig': ((6, 5), '<f8', 40), 'single_chunk': ((6, 5), '<f4', 41)},
@@ -123,3 +123,28 @@ def test_time_axis_labels():
     empty = T.fromVariables(io.open_tfile(os.path.join(H5, 'nemo_T.h5')))
     assert empty.getSize() == 0 and empty.getTimeAsString(4) == '4' and empty.getTimeAsDate(2) == 2
     assert T([59], 'days since 2001-01-01', '360_day').getTimeAsDate(0) == 0   # 30 February has no datetime.date
+
+
+def test_threaded_and_serial_inflation_agree(monkeypatch):
+    """Chunks of one time step are inflated by a thread pool (NF_IO_THREADS); the result does not depend on it."""
+    from nemoflux_amd import hdf5min
+    got = {}
+    for n in ('1', '4'):
+        monkeypatch.setenv('NF_IO_THREADS', n)
+        assert hdf5min.io_threads() == int(n)
+        with hdf5min.File(os.path.join(H5, 'old_style.h5')) as f:
+            ds = f.datasets['uo']
+            got[n] = (ds.read().copy(), [ds.read_leading(i).copy() for i in range(ds.shape[0])])
+    assert numpy.array_equal(got['1'][0], got['4'][0])
+    assert all(numpy.array_equal(a, b) for a, b in zip(got['1'][1], got['4'][1]))
+    assert numpy.array_equal(got['4'][0], field((3, 4, 9, 11), '<f4', 2))
+
+
+def test_never_written_chunks_read_as_the_fill_value():
+    from nemoflux_amd import hdf5min
+    with hdf5min.File(os.path.join(H5, 'old_style.h5')) as f:
+        ds = f.datasets['sparse']
+        want = numpy.full((4, 6), 7.5)
+        want[2:4, 0:3] = field((2, 3), '<f8', 51)
+        assert ds.h5fill == 7.5 and numpy.array_equal(ds.read(), want)
+        assert numpy.array_equal(ds.read_leading(3), want[3]) and numpy.array_equal(ds.read_leading(0), want[0])
