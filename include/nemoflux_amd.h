@@ -38,6 +38,8 @@ extern "C" {
 #define NF_ERR_STATE 2      /* call order violated (e.g. computeWeights before setGrid) */
 #define NF_ERR_HIP 3        /* a HIP runtime call failed */
 #define NF_ERR_NO_DEVICE 4  /* no usable GPU: the engine never falls back to the CPU */
+#define NF_ERR_HOST 5       /* host-side failure (out of host memory, file write error); no C++ exception ever
+                               crosses this ABI */
 
 #define NF_F64 0
 #define NF_F32 1

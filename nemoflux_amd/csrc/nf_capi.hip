@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <vector>
 
 #include "nf_common.h"
@@ -40,6 +41,38 @@ static int require_device()
         int rc_ = nf::require_device();       \
         if (rc_ != NF_OK) return rc_;         \
     } while (0)
+// Exception barrier of the C ABI: every entry point is a function-try-block ending in NF_API_CATCH, so a
+// std::bad_alloc (or any other C++ exception) raised by the host-side containers becomes NF_ERR_HOST.
+static int trap_exception() noexcept
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        try { g_err = "out of host memory"; } catch (...) {}
+    } catch (const std::exception &e) {
+        try { g_err = std::string("internal error: ") + e.what(); } catch (...) {}
+    } catch (...) {
+        try { g_err = "internal error: unknown C++ exception"; } catch (...) {}
+    }
+    return NF_ERR_HOST;
+}
+#define NF_API_CATCH catch (...) { return nf::trap_exception(); }
+
+// device scratch that lives for one call: freed on every return path
+struct DevTmp {
+    void *p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp &) = delete;
+    DevTmp &operator=(const DevTmp &) = delete;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        NF_HIP(hipMalloc(&p, bytes ? bytes : 16));
+        return NF_OK;
+    }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
 #define NF_TRY(call)                  \
     do {                              \
         int rc_ = (call);             \
@@ -73,20 +106,24 @@ const char *nf_last_error(void) { return g_err.c_str(); }
 int nf_version(void) { return 100; }
 
 int nf_device_count(int *count)
-{
+try {
+    NF_REQUIRE(count, NF_ERR_ARG, "nf_device_count: null argument");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     *count = (e == hipSuccess) ? n : 0;
     return NF_OK;
 }
+NF_API_CATCH
 int nf_set_device(int device)
-{
+try {
     NF_NEED_DEVICE();
     NF_HIP(hipSetDevice(device));
     return NF_OK;
 }
+NF_API_CATCH
 int nf_device_name(char *buf, int buflen)
-{
+try {
+    NF_REQUIRE(buf && buflen > 0, NF_ERR_ARG, "nf_device_name: null or empty buffer");
     NF_NEED_DEVICE();
     int dev = 0;
     NF_HIP(hipGetDevice(&dev));
@@ -95,48 +132,58 @@ int nf_device_name(char *buf, int buflen)
     snprintf(buf, buflen, "%s:%s:%dCU", p.gcnArchName, p.name, p.multiProcessorCount);
     return NF_OK;
 }
+NF_API_CATCH
 int nf_malloc(void **dev, size_t bytes)
-{
+try {
+    NF_REQUIRE(dev, NF_ERR_ARG, "nf_malloc: null argument");
     NF_NEED_DEVICE();
     NF_HIP(hipMalloc(dev, bytes ? bytes : 16));
     return NF_OK;
 }
+NF_API_CATCH
 int nf_free(void *dev)
-{
+try {
     if (dev) NF_HIP(hipFree(dev));
     return NF_OK;
 }
+NF_API_CATCH
 int nf_host_alloc(void **host, size_t bytes)
-{
+try {
+    NF_REQUIRE(host, NF_ERR_ARG, "nf_host_alloc: null argument");
     NF_NEED_DEVICE();
     NF_HIP(hipHostMalloc(host, bytes ? bytes : 16, hipHostMallocDefault));
     return NF_OK;
 }
+NF_API_CATCH
 int nf_host_free(void *host)
-{
+try {
     if (host) NF_HIP(hipHostFree(host));
     return NF_OK;
 }
+NF_API_CATCH
 int nf_memcpy_h2d(void *dev, const void *host, size_t bytes)
-{
+try {
     NF_NEED_DEVICE();
     NF_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
     return NF_OK;
 }
+NF_API_CATCH
 int nf_memcpy_d2h(void *host, const void *dev, size_t bytes)
-{
+try {
     NF_NEED_DEVICE();
     NF_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
     return NF_OK;
 }
+NF_API_CATCH
 int nf_memset(void *dev, int value, size_t bytes)
-{
+try {
     NF_NEED_DEVICE();
     NF_HIP(hipMemset(dev, value, bytes));
     return NF_OK;
 }
+NF_API_CATCH
 int nf_tuning_set(const char *name, int value)
-{
+try {
     NF_REQUIRE(name, NF_ERR_ARG, "nf_tuning_set: null name");
     if (!strcmp(name, "batch_steps")) {
         g_batch_steps = value;
@@ -146,12 +193,14 @@ int nf_tuning_set(const char *name, int value)
     NF_REQUIRE(rc == NF_OK, NF_ERR_ARG, std::string("nf_tuning_set: unknown knob ") + name);
     return NF_OK;
 }
+NF_API_CATCH
 int nf_synchronize(void)
-{
+try {
     NF_NEED_DEVICE();
     NF_HIP(hipDeviceSynchronize());
     return NF_OK;
 }
+NF_API_CATCH
 
 }  // extern "C"
 
@@ -179,12 +228,14 @@ struct PolylineIntegral_t {
 extern "C" {
 
 int mnt_grid_new(Grid_t **self)
-{
+try {
+    NF_REQUIRE(self, NF_ERR_ARG, "mnt_grid_new: null argument");
     *self = new Grid_t();
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_grid_del(Grid_t **self)
-{
+try {
     if (self && *self) {
         if ((*self)->owns_xy) dev_free((*self)->d_xy);
         delete *self;
@@ -192,14 +243,16 @@ int mnt_grid_del(Grid_t **self)
     }
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_grid_setPointsPtr(Grid_t **self, double *points)
-{
+try {
     NF_REQUIRE(self && *self && points, NF_ERR_ARG, "mnt_grid_setPointsPtr: null argument");
     (*self)->host_points = points;
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_grid_build(Grid_t **self, int nVertsPerCell, long long ncells)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_grid_build: null grid");
     Grid_t *g = *self;
     NF_REQUIRE(nVertsPerCell == 4, NF_ERR_ARG, "mnt_grid_build: only quad cells (4 vertices) are supported");
@@ -209,25 +262,24 @@ int mnt_grid_build(Grid_t **self, int nVertsPerCell, long long ncells)
     if (g->owns_xy) dev_free(g->d_xy);
     g->owns_xy = true;
     g->ncell = (long)ncells;
-    double *d_points = nullptr;
-    NF_TRY(dev_alloc(&d_points, (size_t)ncells * 12));
+    DevTmp points;
+    NF_TRY(points.alloc(sizeof(double) * 12 * (size_t)ncells));
     NF_TRY(dev_alloc(&g->d_xy, (size_t)ncells * 8));
-    hipError_t e = hipMemcpy(d_points, g->host_points, sizeof(double) * 12 * (size_t)ncells, hipMemcpyHostToDevice);
-    int rc = (e == hipSuccess) ? launch_corner_table_from_points(d_points, g->ncell, g->d_xy, nullptr) : NF_ERR_HIP;
-    hipError_t e2 = hipDeviceSynchronize();
-    dev_free(d_points);
-    NF_HIP(e);
-    NF_HIP(e2);
-    return rc;
+    NF_HIP(hipMemcpy(points.p, g->host_points, sizeof(double) * 12 * (size_t)ncells, hipMemcpyHostToDevice));
+    NF_TRY(launch_corner_table_from_points(points.as<double>(), g->ncell, g->d_xy, nullptr));
+    NF_HIP(hipDeviceSynchronize());
+    return NF_OK;
 }
+NF_API_CATCH
 int mnt_grid_getNumberOfCells(Grid_t **self, size_t *numCells)
-{
+try {
     NF_REQUIRE(self && *self && numCells, NF_ERR_ARG, "mnt_grid_getNumberOfCells: null argument");
     *numCells = (size_t)(*self)->ncell;
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_grid_dump(Grid_t **self, const char *fileName)
-{
+try {
     NF_REQUIRE(self && *self && fileName, NF_ERR_ARG, "mnt_grid_dump: null argument");
     Grid_t *g = *self;
     NF_REQUIRE(g->ncell > 0, NF_ERR_STATE, "mnt_grid_dump: grid not built");
@@ -235,14 +287,11 @@ int mnt_grid_dump(Grid_t **self, const char *fileName)
     const double *p = g->host_points;
     if (!p) {  // grid view of a Field: rebuild (lon,lat,0) from the corner table
         NF_NEED_DEVICE();
-        double *d_points = nullptr;
-        NF_TRY(dev_alloc(&d_points, (size_t)g->ncell * 12));
-        int rc = launch_points_from_corner_table(g->d_xy, g->ncell, d_points, nullptr);
+        DevTmp points;
+        NF_TRY(points.alloc(sizeof(double) * 12 * (size_t)g->ncell));
+        NF_TRY(launch_points_from_corner_table(g->d_xy, g->ncell, points.as<double>(), nullptr));
         pts.resize((size_t)g->ncell * 12);
-        hipError_t e = hipMemcpy(pts.data(), d_points, sizeof(double) * pts.size(), hipMemcpyDeviceToHost);
-        dev_free(d_points);
-        NF_TRY(rc);
-        NF_HIP(e);
+        NF_HIP(hipMemcpy(pts.data(), points.p, sizeof(double) * pts.size(), hipMemcpyDeviceToHost));
         p = pts.data();
     }
     FILE *f = fopen(fileName, "w");
@@ -254,17 +303,21 @@ int mnt_grid_dump(Grid_t **self, const char *fileName)
     for (long c = 0; c < g->ncell; ++c) fprintf(f, "4 %ld %ld %ld %ld\n", 4 * c, 4 * c + 1, 4 * c + 2, 4 * c + 3);
     fprintf(f, "CELL_TYPES %ld\n", g->ncell);
     for (long c = 0; c < g->ncell; ++c) fprintf(f, "9\n");  // VTK_QUAD
-    fclose(f);
+    const bool bad = ferror(f) != 0;
+    NF_REQUIRE(fclose(f) == 0 && !bad, NF_ERR_HOST, std::string("mnt_grid_dump: error writing ") + fileName);
     return NF_OK;
 }
+NF_API_CATCH
 
 int mnt_polylineintegral_new(PolylineIntegral_t **self)
-{
+try {
+    NF_REQUIRE(self, NF_ERR_ARG, "mnt_polylineintegral_new: null argument");
     *self = new PolylineIntegral_t();
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_polylineintegral_del(PolylineIntegral_t **self)
-{
+try {
     if (self && *self) {
         PolylineIntegral_t *p = *self;
         p->ws.release();
@@ -277,16 +330,18 @@ int mnt_polylineintegral_del(PolylineIntegral_t **self)
     }
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_polylineintegral_setGrid(PolylineIntegral_t **self, Grid_t *grid)
-{
+try {
     NF_REQUIRE(self && *self && grid, NF_ERR_ARG, "mnt_polylineintegral_setGrid: null argument");
     NF_REQUIRE(grid->ncell > 0 && grid->d_xy, NF_ERR_STATE, "mnt_polylineintegral_setGrid: grid not built");
     (*self)->grid = grid;
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_polylineintegral_buildLocator(PolylineIntegral_t **self, int numCellsPerBucket, double periodX,
                                       int enableFolding)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_polylineintegral_buildLocator: null argument");
     NF_REQUIRE((*self)->grid, NF_ERR_STATE, "mnt_polylineintegral_buildLocator: setGrid first");
     NF_REQUIRE(numCellsPerBucket > 0, NF_ERR_ARG, "mnt_polylineintegral_buildLocator: numCellsPerBucket <= 0");
@@ -296,6 +351,7 @@ int mnt_polylineintegral_buildLocator(PolylineIntegral_t **self, int numCellsPer
     (*self)->locator = true;  // the cull tile is the 64-cell wavefront tile, rebuilt inside computeWeights
     return NF_OK;
 }
+NF_API_CATCH
 
 static int polyline_segments(const double *xyz, int npoints, int counterclock, std::vector<double> &segs,
                              std::vector<int> &cc)
@@ -312,7 +368,7 @@ static int polyline_segments(const double *xyz, int npoints, int counterclock, s
 
 int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, const double xyz[],
                                         int counterclock)
-{
+try {
     NF_REQUIRE(self && *self && xyz, NF_ERR_ARG, "mnt_polylineintegral_computeWeights: null argument");
     PolylineIntegral_t *p = *self;
     NF_REQUIRE(p->grid && p->locator, NF_ERR_STATE, "mnt_polylineintegral_computeWeights: setGrid/buildLocator first");
@@ -332,10 +388,11 @@ int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, 
     NF_HIP(hipMemcpy(p->d_tr_off, off, sizeof off, hipMemcpyHostToDevice));
     return NF_OK;
 }
+NF_API_CATCH
 
 int mnt_polylineintegral_getIntegralDev(PolylineIntegral_t **self, const double *data_dev, int placement,
                                         double *result, double *seg_totals_host)
-{
+try {
     NF_REQUIRE(self && *self && data_dev && result, NF_ERR_ARG, "mnt_polylineintegral_getIntegral: null argument");
     PolylineIntegral_t *p = *self;
     NF_REQUIRE(p->d_row, NF_ERR_STATE, "mnt_polylineintegral_getIntegral: computeWeights first");
@@ -349,9 +406,10 @@ int mnt_polylineintegral_getIntegralDev(PolylineIntegral_t **self, const double 
     if (seg_totals_host) memcpy(seg_totals_host, row.data(), sizeof(double) * p->nseg);
     return NF_OK;
 }
+NF_API_CATCH
 
 int mnt_polylineintegral_getIntegral(PolylineIntegral_t **self, const double data[], int placement, double *result)
-{
+try {
     NF_REQUIRE(self && *self && data && result, NF_ERR_ARG, "mnt_polylineintegral_getIntegral: null argument");
     PolylineIntegral_t *p = *self;
     NF_REQUIRE(p->grid, NF_ERR_STATE, "mnt_polylineintegral_getIntegral: setGrid first");
@@ -364,20 +422,23 @@ int mnt_polylineintegral_getIntegral(PolylineIntegral_t **self, const double dat
     NF_HIP(hipMemcpy(p->d_stage, data, sizeof(double) * 4 * (size_t)p->grid->ncell, hipMemcpyHostToDevice));
     return mnt_polylineintegral_getIntegralDev(self, p->d_stage, placement, result, nullptr);
 }
+NF_API_CATCH
 
 int mnt_polylineintegral_getNumberOfWeights(PolylineIntegral_t **self, size_t *n)
-{
+try {
     NF_REQUIRE(self && *self && n, NF_ERR_ARG, "mnt_polylineintegral_getNumberOfWeights: null argument");
     *n = (size_t)(*self)->ws.entries();
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_polylineintegral_getWeights(PolylineIntegral_t **self, int64_t *cell_edge, double *weight, int *seg)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_polylineintegral_getWeights: null argument");
     if ((*self)->ws.nrec == 0) return NF_OK;
     NF_NEED_DEVICE();
     return weights_to_host((*self)->ws, cell_edge, weight, seg);
 }
+NF_API_CATCH
 
 }  // extern "C"
 
@@ -406,12 +467,14 @@ static void vi_free_points(VectorInterp_t *v)
 extern "C" {
 
 int mnt_vectorinterp_new(VectorInterp_t **self)
-{
+try {
+    NF_REQUIRE(self, NF_ERR_ARG, "mnt_vectorinterp_new: null argument");
     *self = new VectorInterp_t();
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_vectorinterp_del(VectorInterp_t **self)
-{
+try {
     if (self && *self) {
         vi_free_points(*self);
         dev_free((*self)->d_stage);
@@ -420,15 +483,17 @@ int mnt_vectorinterp_del(VectorInterp_t **self)
     }
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_vectorinterp_setGrid(VectorInterp_t **self, Grid_t *grid)
-{
+try {
     NF_REQUIRE(self && *self && grid, NF_ERR_ARG, "mnt_vectorinterp_setGrid: null argument");
     NF_REQUIRE(grid->ncell > 0 && grid->d_xy, NF_ERR_STATE, "mnt_vectorinterp_setGrid: grid not built");
     (*self)->grid = grid;
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_vectorinterp_buildLocator(VectorInterp_t **self, int numCellsPerBucket, double periodX, int enableFolding)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_vectorinterp_buildLocator: null argument");
     NF_REQUIRE((*self)->grid, NF_ERR_STATE, "mnt_vectorinterp_buildLocator: setGrid first");
     NF_REQUIRE(numCellsPerBucket > 0 && periodX >= 0.0, NF_ERR_ARG, "mnt_vectorinterp_buildLocator: bad arguments");
@@ -437,9 +502,10 @@ int mnt_vectorinterp_buildLocator(VectorInterp_t **self, int numCellsPerBucket, 
     (*self)->locator = true;
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_vectorinterp_findPoints(VectorInterp_t **self, size_t numPoints, const double targetPoints[], double tol2,
                                 size_t *numNotFound)
-{
+try {
     NF_REQUIRE(self && *self && (targetPoints || numPoints == 0), NF_ERR_ARG, "mnt_vectorinterp_findPoints: null argument");
     VectorInterp_t *v = *self;
     NF_REQUIRE(v->grid && v->locator, NF_ERR_STATE, "mnt_vectorinterp_findPoints: setGrid/buildLocator first");
@@ -463,23 +529,15 @@ int mnt_vectorinterp_findPoints(VectorInterp_t **self, size_t numPoints, const d
         std::vector<double> sorted(3 * numPoints);
         for (size_t q = 0; q < numPoints; ++q)
             for (int k = 0; k < 3; ++k) sorted[3 * q + k] = targetPoints[3 * order[q] + k];
-        double *d_sorted = nullptr;
-        long *d_order = nullptr;
-        NF_TRY(dev_alloc(&d_sorted, numPoints * 3));
-        NF_TRY(dev_alloc(&d_order, numPoints));
-        hipError_t e1 = hipMemcpy(d_sorted, sorted.data(), sizeof(double) * 3 * numPoints, hipMemcpyHostToDevice);
-        hipError_t e2 = hipMemcpy(d_order, order.data(), sizeof(long) * numPoints, hipMemcpyHostToDevice);
-        int rc = (e1 == hipSuccess && e2 == hipSuccess)
-                     ? launch_find_points(v->grid->d_xy, v->grid->ncell, v->d_targets, d_sorted, d_order, v->npts,
-                                          v->periodX, tol2, v->d_best, v->d_cell, v->d_pcoords, nullptr)
-                     : NF_ERR_HIP;
-        hipError_t e3 = hipDeviceSynchronize();
-        dev_free(d_sorted);
-        dev_free(d_order);
-        NF_HIP(e1);
-        NF_HIP(e2);
-        NF_TRY(rc);
-        NF_HIP(e3);
+        DevTmp d_sorted, d_order;
+        NF_TRY(d_sorted.alloc(sizeof(double) * 3 * numPoints));
+        NF_TRY(d_order.alloc(sizeof(long) * numPoints));
+        NF_HIP(hipMemcpy(d_sorted.p, sorted.data(), sizeof(double) * 3 * numPoints, hipMemcpyHostToDevice));
+        NF_HIP(hipMemcpy(d_order.p, order.data(), sizeof(long) * numPoints, hipMemcpyHostToDevice));
+        NF_TRY(launch_find_points(v->grid->d_xy, v->grid->ncell, v->d_targets, d_sorted.as<double>(),
+                                  d_order.as<long>(), v->npts, v->periodX, tol2, v->d_best, v->d_cell, v->d_pcoords,
+                                  nullptr));
+        NF_HIP(hipDeviceSynchronize());
     }
     if (numNotFound) {
         std::vector<long> cells(numPoints);
@@ -492,9 +550,10 @@ int mnt_vectorinterp_findPoints(VectorInterp_t **self, size_t numPoints, const d
     }
     return NF_OK;
 }
+NF_API_CATCH
 /* layout: 0 = (ncell,4) AoS, 1 = [4][ncell] planes (the engine's resident layout) */
 int mnt_vectorinterp_getFaceVectorsDev(VectorInterp_t **self, const double *data_dev, int layout, double vectors[])
-{
+try {
     NF_REQUIRE(self && *self && data_dev, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null argument");
     VectorInterp_t *v = *self;
     NF_REQUIRE(v->grid, NF_ERR_STATE, "mnt_vectorinterp_getFaceVectors: setGrid first");
@@ -506,8 +565,9 @@ int mnt_vectorinterp_getFaceVectorsDev(VectorInterp_t **self, const double *data
     NF_HIP(hipMemcpy(vectors, v->d_vectors, sizeof(double) * 3 * v->npts, hipMemcpyDeviceToHost));
     return NF_OK;
 }
+NF_API_CATCH
 int mnt_vectorinterp_getFaceVectors(VectorInterp_t **self, const double data[], int placement, double vectors[])
-{
+try {
     NF_REQUIRE(self && *self && data, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null argument");
     VectorInterp_t *v = *self;
     NF_REQUIRE(v->grid, NF_ERR_STATE, "mnt_vectorinterp_getFaceVectors: setGrid first");
@@ -522,8 +582,9 @@ int mnt_vectorinterp_getFaceVectors(VectorInterp_t **self, const double data[], 
     NF_HIP(hipMemcpy(v->d_stage, data, sizeof(double) * 4 * (size_t)v->grid->ncell, hipMemcpyHostToDevice));
     return mnt_vectorinterp_getFaceVectorsDev(self, v->d_stage, 0, vectors);
 }
+NF_API_CATCH
 int mnt_vectorinterp_getCells(VectorInterp_t **self, long long *cell_ids, double *pcoords)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_vectorinterp_getCells: null argument");
     VectorInterp_t *v = *self;
     if (v->npts == 0) return NF_OK;
@@ -532,6 +593,7 @@ int mnt_vectorinterp_getCells(VectorInterp_t **self, long long *cell_ids, double
     if (pcoords) NF_HIP(hipMemcpy(pcoords, v->d_pcoords, sizeof(double) * 2 * v->npts, hipMemcpyDeviceToHost));
     return NF_OK;
 }
+NF_API_CATCH
 
 }  // extern "C"
 
@@ -665,14 +727,14 @@ static int field_step_async(nf_field *f, long t, double *row_dev)
     a.absV = f->d_abs + f->ncell;
     a.maxbits = f->d_maxbits;
     if (f->timing) {
-        hipEvent_t e0, e1;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
         NF_HIP(hipEventCreate(&e0));
+        f->ev.push_back(e0);   // owned by the field from here on (destroyed by timing_read / del)
         NF_HIP(hipEventCreate(&e1));
+        f->ev.push_back(e1);
         NF_HIP(hipEventRecord(e0, f->stream));
         NF_TRY(launch_flux(a, f->stream));
         NF_HIP(hipEventRecord(e1, f->stream));
-        f->ev.push_back(e0);
-        f->ev.push_back(e1);
     } else {
         NF_TRY(launch_flux(a, f->stream));
     }
@@ -754,14 +816,14 @@ static int field_all_steps_batched(nf_field *f, double *rows_dev)
     a.batch.in_stride = f->nz * f->ncell;
     a.batch.zr = f->d_zr;
     if (f->timing) {  // one event pair around the one flux launch of the pass
-        hipEvent_t e0, e1;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
         NF_HIP(hipEventCreate(&e0));
+        f->ev.push_back(e0);   // owned by the field from here on (destroyed by timing_read / del)
         NF_HIP(hipEventCreate(&e1));
+        f->ev.push_back(e1);
         NF_HIP(hipEventRecord(e0, f->stream));
         NF_TRY(launch_flux(a, f->stream));
         NF_HIP(hipEventRecord(e1, f->stream));
-        f->ev.push_back(e0);
-        f->ev.push_back(e1);
     } else {
         NF_TRY(launch_flux(a, f->stream));
     }
@@ -779,13 +841,15 @@ static int field_all_steps_batched(nf_field *f, double *rows_dev)
 extern "C" {
 
 int nf_field_new(nf_field **self)
-{
+try {
+    NF_REQUIRE(self, NF_ERR_ARG, "nf_field_new: null argument");
     *self = new nf_field();
     (*self)->grid_view.owns_xy = false;
     return NF_OK;
 }
+NF_API_CATCH
 int nf_field_del(nf_field **self)
-{
+try {
     if (self && *self) {
         nf_field *f = *self;
         field_free_geometry(f);
@@ -803,17 +867,19 @@ int nf_field_del(nf_field **self)
     }
     return NF_OK;
 }
+NF_API_CATCH
 int nf_field_set_stream(nf_field **self, void *hip_stream)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_stream: null field");
     (*self)->stream = (hipStream_t)hip_stream;
     ++(*self)->version;
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_set_bounds(nf_field **self, const void *bounds_lon, const void *bounds_lat, long ny, long nx,
                         int dtype, int on_device)
-{
+try {
     NF_REQUIRE(self && *self && bounds_lon && bounds_lat, NF_ERR_ARG, "nf_field_set_bounds: null argument");
     NF_REQUIRE(ny > 0 && nx > 0 && ny * nx < (1l << 31), NF_ERR_ARG, "nf_field_set_bounds: bad (ny, nx)");
     NF_REQUIRE(dtype == NF_F64 || dtype == NF_F32, NF_ERR_ARG, "nf_field_set_bounds: dtype must be NF_F64/NF_F32");
@@ -837,25 +903,20 @@ int nf_field_set_bounds(nf_field **self, const void *bounds_lon, const void *bou
     NF_HIP(hipMemsetAsync(f->d_abs, 0, sizeof(double) * n * 2, f->stream));
     NF_HIP(hipMemsetAsync(f->d_maxbits, 0, sizeof(unsigned long long), f->stream));
     const size_t bytes = n * 4 * elem_size(dtype);
-    void *d_lon = nullptr, *d_lat = nullptr;
+    DevTmp d_lon, d_lat;   // hipFree waits for the stream's work before releasing
     const void *plon = bounds_lon, *plat = bounds_lat;
     if (!on_device) {
-        NF_HIP(hipMalloc(&d_lon, bytes));
-        NF_HIP(hipMalloc(&d_lat, bytes));
-        NF_HIP(hipMemcpyAsync(d_lon, bounds_lon, bytes, hipMemcpyHostToDevice, f->stream));
-        NF_HIP(hipMemcpyAsync(d_lat, bounds_lat, bytes, hipMemcpyHostToDevice, f->stream));
-        plon = d_lon;
-        plat = d_lat;
+        NF_TRY(d_lon.alloc(bytes));
+        NF_TRY(d_lat.alloc(bytes));
+        NF_HIP(hipMemcpyAsync(d_lon.p, bounds_lon, bytes, hipMemcpyHostToDevice, f->stream));
+        NF_HIP(hipMemcpyAsync(d_lat.p, bounds_lat, bytes, hipMemcpyHostToDevice, f->stream));
+        plon = d_lon.p;
+        plat = d_lat.p;
     }
-    int rc = launch_geometry(plon, plat, dtype, f->ncell, f->d_xy, f->d_arc4, f->d_arcE, f->d_arcN, f->d_box, f->stream);
+    NF_TRY(launch_geometry(plon, plat, dtype, f->ncell, f->d_xy, f->d_arc4, f->d_arcE, f->d_arcN, f->d_box, f->stream));
     unsigned long long keys[4] = {0, 0, 0, 0};
-    hipError_t e = hipMemcpyAsync(keys, f->d_box, sizeof keys, hipMemcpyDeviceToHost, f->stream);
-    hipError_t e2 = hipStreamSynchronize(f->stream);
-    if (d_lon) (void)hipFree(d_lon);
-    if (d_lat) (void)hipFree(d_lat);
-    NF_TRY(rc);
-    NF_HIP(e);
-    NF_HIP(e2);
+    NF_HIP(hipMemcpyAsync(keys, f->d_box, sizeof keys, hipMemcpyDeviceToHost, f->stream));
+    NF_HIP(hipStreamSynchronize(f->stream));
     for (int k = 0; k < 4; ++k) f->box[k] = box_key_to_double(keys[k]);
     f->grid_view.ncell = f->ncell;
     f->grid_view.d_xy = f->d_xy;
@@ -864,9 +925,10 @@ int nf_field_set_bounds(nf_field **self, const void *bounds_lon, const void *bou
     ++f->version;
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_set_thickness(nf_field **self, const double *thickness, long nz)
-{
+try {
     NF_REQUIRE(self && *self && thickness, NF_ERR_ARG, "nf_field_set_thickness: null argument");
     NF_REQUIRE(nz > 0 && nz < (1l << 30), NF_ERR_ARG, "nf_field_set_thickness: bad nz");
     NF_NEED_DEVICE();
@@ -878,10 +940,11 @@ int nf_field_set_thickness(nf_field **self, const double *thickness, long nz)
     ++f->version;
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_set_uv(nf_field **self, const void *u, const void *v, long nt, int dtype, int on_device,
                     double fill_value)
-{
+try {
     NF_REQUIRE(self && *self && u && v, NF_ERR_ARG, "nf_field_set_uv: null argument");
     NF_REQUIRE(nt > 0, NF_ERR_ARG, "nf_field_set_uv: nt must be positive");
     NF_REQUIRE(dtype == NF_F64 || dtype == NF_F32, NF_ERR_ARG, "nf_field_set_uv: dtype must be NF_F64/NF_F32");
@@ -900,17 +963,19 @@ int nf_field_set_uv(nf_field **self, const void *u, const void *v, long nt, int 
     ++f->version;
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_set_sverdrup(nf_field **self, int sverdrup)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_sverdrup: null field");
     (*self)->sverdrup = sverdrup ? 1 : 0;
     ++(*self)->version;
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_set_slab_range(nf_field **self, long s_begin, long s_end)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_slab_range: null field");
     NF_REQUIRE(s_begin >= 0 && s_end >= s_begin, NF_ERR_ARG, "nf_field_set_slab_range: need 0 <= begin <= end");
     (*self)->s_begin = s_begin;
@@ -918,9 +983,10 @@ int nf_field_set_slab_range(nf_field **self, long s_begin, long s_end)
     ++(*self)->version;
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_add_transect(nf_field **self, const double *xyz, int npts, int counterclock, int *transect_id)
-{
+try {
     NF_REQUIRE(self && *self && xyz, NF_ERR_ARG, "nf_field_add_transect: null argument");
     NF_REQUIRE(npts >= 2, NF_ERR_ARG, "nf_field_add_transect: need at least 2 points");
     nf_field *f = *self;
@@ -930,9 +996,10 @@ int nf_field_add_transect(nf_field **self, const double *xyz, int npts, int coun
     if (transect_id) *transect_id = (int)f->polylines.size() - 1;
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_build_weights(nf_field **self, int numCellsPerBucket, double periodX)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_build_weights: null field");
     nf_field *f = *self;
     NF_REQUIRE(f->d_xy, NF_ERR_STATE, "nf_field_build_weights: set_bounds first");
@@ -957,49 +1024,56 @@ int nf_field_build_weights(nf_field **self, int numCellsPerBucket, double period
     ++f->version;
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_num_transects(nf_field **self, int *n)
-{
+try {
     NF_REQUIRE(self && *self && n, NF_ERR_ARG, "nf_field_num_transects: null argument");
     *n = (int)(*self)->polylines.size();
     return NF_OK;
 }
+NF_API_CATCH
 int nf_field_num_segments(nf_field **self, int *nseg_total)
-{
+try {
     NF_REQUIRE(self && *self && nseg_total, NF_ERR_ARG, "nf_field_num_segments: null argument");
     NF_REQUIRE((*self)->weights_built, NF_ERR_STATE, "nf_field_num_segments: build_weights first");
     *nseg_total = (*self)->ws.nseg;
     return NF_OK;
 }
+NF_API_CATCH
 int nf_field_segment_offsets(nf_field **self, int *offsets)
-{
+try {
     NF_REQUIRE(self && *self && offsets, NF_ERR_ARG, "nf_field_segment_offsets: null argument");
     NF_REQUIRE((*self)->weights_built, NF_ERR_STATE, "nf_field_segment_offsets: build_weights first");
     memcpy(offsets, (*self)->tr_off.data(), sizeof(int) * (*self)->tr_off.size());
     return NF_OK;
 }
+NF_API_CATCH
 int nf_field_num_weights(nf_field **self, size_t *n)
-{
+try {
     NF_REQUIRE(self && *self && n, NF_ERR_ARG, "nf_field_num_weights: null argument");
     *n = (size_t)(*self)->ws.entries();
     return NF_OK;
 }
+NF_API_CATCH
 int nf_field_get_weights(nf_field **self, int64_t *cell_edge, double *weight, int *seg_global)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_get_weights: null field");
     if ((*self)->ws.nrec == 0) return NF_OK;
     NF_NEED_DEVICE();
     return weights_to_host((*self)->ws, cell_edge, weight, seg_global);
 }
+NF_API_CATCH
 int nf_field_row_length(nf_field **self, int *n)
-{
+try {
     NF_REQUIRE(self && *self && n, NF_ERR_ARG, "nf_field_row_length: null argument");
     *n = field_row_length(*self);
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_compute_flux(nf_field **self, long tIndex, double *row_host)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_compute_flux: null field");
     NF_NEED_DEVICE();
     nf_field *f = *self;
@@ -1010,9 +1084,10 @@ int nf_field_compute_flux(nf_field **self, long tIndex, double *row_host)
     NF_HIP(hipStreamSynchronize(f->stream));
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_compute_all_async(nf_field **self, double *rows_dev)
-{
+try {
     NF_REQUIRE(self && *self && rows_dev, NF_ERR_ARG, "nf_field_compute_all_async: null argument");
     NF_NEED_DEVICE();
     nf_field *f = *self;
@@ -1052,9 +1127,10 @@ int nf_field_compute_all_async(nf_field **self, double *rows_dev)
     for (long t = 0; t < f->nt; ++t) NF_TRY(field_step_async(f, t, rows_dev + (size_t)t * rowlen));
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_read_step(nf_field **self, double *iV_host, double *eU_host, double *eV_host, double *max_abs)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_read_step: null field");
     nf_field *f = *self;
     NF_REQUIRE(f->d_iV, NF_ERR_STATE, "nf_field_read_step: set_bounds first");
@@ -1076,43 +1152,44 @@ int nf_field_read_step(nf_field **self, double *iV_host, double *eU_host, double
     NF_HIP(hipStreamSynchronize(f->stream));
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_reset_max(nf_field **self)
-{
+try {
     NF_REQUIRE(self && *self && (*self)->d_maxbits, NF_ERR_STATE, "nf_field_reset_max: set_bounds first");
     NF_HIP(hipMemsetAsync((*self)->d_maxbits, 0, sizeof(unsigned long long), (*self)->stream));
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_get_arclengths(nf_field **self, double *arc_host)
-{
+try {
     NF_REQUIRE(self && *self && arc_host, NF_ERR_ARG, "nf_field_get_arclengths: null argument");
     NF_REQUIRE((*self)->d_arc4, NF_ERR_STATE, "nf_field_get_arclengths: set_bounds first");
     NF_HIP(hipMemcpy(arc_host, (*self)->d_arc4, sizeof(double) * 4 * (size_t)(*self)->ncell, hipMemcpyDeviceToHost));
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_get_points(nf_field **self, double *points_host)
-{
+try {
     NF_REQUIRE(self && *self && points_host, NF_ERR_ARG, "nf_field_get_points: null argument");
     nf_field *f = *self;
     NF_REQUIRE(f->d_xy, NF_ERR_STATE, "nf_field_get_points: set_bounds first");
-    double *d_points = nullptr;
-    NF_TRY(dev_alloc(&d_points, (size_t)f->ncell * 12));
-    int rc = launch_points_from_corner_table(f->d_xy, f->ncell, d_points, f->stream);
-    hipError_t e = hipMemcpyAsync(points_host, d_points, sizeof(double) * 12 * (size_t)f->ncell,
-                                  hipMemcpyDeviceToHost, f->stream);
-    hipError_t e2 = hipStreamSynchronize(f->stream);
-    dev_free(d_points);
-    NF_TRY(rc);
-    NF_HIP(e);
-    NF_HIP(e2);
+    DevTmp points;
+    NF_TRY(points.alloc(sizeof(double) * 12 * (size_t)f->ncell));
+    NF_TRY(launch_points_from_corner_table(f->d_xy, f->ncell, points.as<double>(), f->stream));
+    NF_HIP(hipMemcpyAsync(points_host, points.p, sizeof(double) * 12 * (size_t)f->ncell, hipMemcpyDeviceToHost,
+                          f->stream));
+    NF_HIP(hipStreamSynchronize(f->stream));
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_get_box(nf_field **self, double *lonmin, double *lonmax, double *latmin, double *latmax)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_get_box: null field");
+    NF_REQUIRE(lonmin && lonmax && latmin && latmax, NF_ERR_ARG, "nf_field_get_box: null argument");
     NF_REQUIRE((*self)->d_xy, NF_ERR_STATE, "nf_field_get_box: set_bounds first");
     *lonmin = (*self)->box[0];
     *lonmax = (*self)->box[1];
@@ -1120,9 +1197,10 @@ int nf_field_get_box(nf_field **self, double *lonmin, double *lonmax, double *la
     *latmax = (*self)->box[3];
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_device_ptr(nf_field **self, int which, void **dev)
-{
+try {
     NF_REQUIRE(self && *self && dev, NF_ERR_ARG, "nf_field_device_ptr: null argument");
     nf_field *f = *self;
     switch (which) {
@@ -1135,17 +1213,19 @@ int nf_field_device_ptr(nf_field **self, int which, void **dev)
     }
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_grid(nf_field **self, Grid_t **grid)
-{
+try {
     NF_REQUIRE(self && *self && grid, NF_ERR_ARG, "nf_field_grid: null argument");
     NF_REQUIRE((*self)->d_xy, NF_ERR_STATE, "nf_field_grid: set_bounds first");
     *grid = &(*self)->grid_view;
     return NF_OK;
 }
+NF_API_CATCH
 
 int nf_field_timing(nf_field **self, int enable)
-{
+try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_timing: null field");
     nf_field *f = *self;
     for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
@@ -1154,8 +1234,9 @@ int nf_field_timing(nf_field **self, int enable)
     ++f->version;
     return NF_OK;
 }
+NF_API_CATCH
 int nf_field_timing_read(nf_field **self, long *launches, double *total_ms)
-{
+try {
     NF_REQUIRE(self && *self && launches && total_ms, NF_ERR_ARG, "nf_field_timing_read: null argument");
     nf_field *f = *self;
     NF_HIP(hipStreamSynchronize(f->stream));
@@ -1171,12 +1252,13 @@ int nf_field_timing_read(nf_field **self, long *launches, double *total_ms)
     f->ev.clear();
     return NF_OK;
 }
+NF_API_CATCH
 
 // ------------------------------------------------------------------------------------------- datagen
 int nf_datagen_bounds(double *bounds_lon_dev, double *bounds_lat_dev, long ny, long nx, double xmin, double xmax,
                       double ymin, double ymax, double delta_lon_deg, double delta_lat_deg, int lat_uses_dx,
                       void *hip_stream)
-{
+try {
     NF_REQUIRE(bounds_lon_dev && bounds_lat_dev, NF_ERR_ARG, "nf_datagen_bounds: null argument");
     NF_NEED_DEVICE();
     NF_TRY(launch_datagen_bounds(bounds_lon_dev, bounds_lat_dev, ny, nx, xmin, xmax, ymin, ymax, delta_lon_deg,
@@ -1184,15 +1266,17 @@ int nf_datagen_bounds(double *bounds_lon_dev, double *bounds_lat_dev, long ny, l
     NF_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
     return NF_OK;
 }
+NF_API_CATCH
 int nf_datagen_uv(void *u_dev, void *v_dev, int dtype, long t_begin, long t_end, long nt, long nz, long ny, long nx,
                   double xmin, double xmax, double ymin, double ymax, double zmin, double zmax, int lat_uses_dx,
                   int psi, void *hip_stream)
-{
+try {
     NF_REQUIRE(u_dev && v_dev, NF_ERR_ARG, "nf_datagen_uv: null argument");
     NF_REQUIRE(dtype == NF_F64 || dtype == NF_F32, NF_ERR_ARG, "nf_datagen_uv: dtype must be NF_F64/NF_F32");
     NF_NEED_DEVICE();
     return launch_datagen_uv(u_dev, v_dev, dtype, t_begin, t_end, nt, nz, ny, nx, xmin, xmax, ymin, ymax, zmin, zmax,
                              lat_uses_dx, psi, (hipStream_t)hip_stream);
 }
+NF_API_CATCH
 
 }  // extern "C"

@@ -74,6 +74,28 @@ def test_argument_errors_without_gpu():
     assert lib.nf_version() == 100
 
 
+def test_null_arguments_are_errors_not_crashes():
+    """Every out-parameter is checked: a NULL gives NF_ERR_ARG (1) and a message, never a segfault; no C++ exception
+    crosses the ABI (include/nemoflux_amd.h: NF_ERR_HOST)."""
+    from nemoflux_amd import _lib
+    lib = _lib.lib
+    hdr = open(os.path.join(ROOT, 'include', 'nemoflux_amd.h')).read()
+    assert '#define NF_ERR_HOST 5' in hdr
+    for fn in (lib.mnt_grid_new, lib.mnt_polylineintegral_new, lib.mnt_vectorinterp_new, lib.nf_field_new,
+               lib.nf_device_count):
+        assert fn(None) == 1 and b'null' in lib.nf_last_error()
+    assert lib.nf_malloc(None, 16) == 1 and lib.nf_host_alloc(None, 16) == 1
+    assert lib.nf_device_name(None, 0) == 1
+    h = ctypes.c_void_p()
+    assert lib.nf_field_new(ctypes.byref(h)) == 0
+    assert lib.nf_field_get_box(ctypes.byref(h), None, None, None, None) == 1
+    assert lib.nf_field_num_transects(ctypes.byref(h), None) == 1
+    assert lib.nf_field_row_length(ctypes.byref(h), None) == 1
+    assert lib.nf_field_del(ctypes.byref(h)) == 0
+    assert lib.nf_field_del(ctypes.byref(h)) == 0          # deleting twice is harmless (handle was nulled)
+    assert lib.nf_tuning_set(None, 0) == 1 and lib.nf_tuning_set(b'no_such_knob', 0) == 1
+
+
 def test_product_never_imports_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
     pkg = os.path.join(ROOT, 'nemoflux_amd')
