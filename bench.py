@@ -118,7 +118,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if dist.get_backend() == 'nccl':
+                dist.barrier(device_ids=[local])     # this rank's GPU, not a guess from the global rank
+            else:
+                dist.barrier()
 
     if world > 1:   # communicator set-up (RCCL ring build) never lands in the timed region, even with --warmup 0
         nfdist.reduce_rows(rows)

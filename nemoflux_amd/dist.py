@@ -39,9 +39,12 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
+        if backend == 'nccl':     # RCCL: bind the communicator to this rank's GPU at init (one process per GPU)
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local
