@@ -13,7 +13,7 @@ import re
 import numpy
 import torch
 
-from . import _lib
+from . import _expr, _lib
 from ._lib import lib, check, NF_F64, NF_F32
 
 STREAM_FUNCTIONS = [
@@ -134,7 +134,7 @@ def main(*, streamFunction="(cos(t*2*pi/nt)+2)*(0.5*(y/180)**2 + sin(2*pi*x/360)
     lldg.setSizes(nx, ny, nz, nt)
     lldg.setBoundingBox(xmin=xmin, xmax=xmax, ymin=ymin, ymax=ymax, zmin=zmin, zmax=zmax)
     lldg.build()
-    dd = eval(deltaDeg) if isinstance(deltaDeg, str) else deltaDeg
+    dd = _expr.literal(deltaDeg, 'deltaDeg') if isinstance(deltaDeg, str) else deltaDeg
     if dd[0] != 0 or dd[1] != 0:
         lldg.rotatePole(deltaDeg=dd)
     lldg.applyStreamFunction(streamFunction)

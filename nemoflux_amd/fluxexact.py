@@ -1,8 +1,10 @@
 """Closed-form transect flux for stream-function data: same arithmetic as nemoflux/fluxexact.py:21-46
-(host-side; it is the analytic oracle of the reference, not a kernel).  arctan2 is added to the eval
-namespace so the README's singular case can be evaluated (the reference imports only pi, cos, sin)."""
+(host-side; it is the analytic oracle of the reference, not a kernel).  The potential is an arithmetic expression in
+x, y, z, t, nt checked by nemoflux_amd._expr (no bare eval); arctan2 is available so the README's singular case can be
+evaluated (the reference imports only pi, cos, sin)."""
 import numpy
-from numpy import pi, cos, sin, arctan2  # noqa: F401
+
+from . import _expr
 
 
 def exactFlux(potentialFunction, lonLatPoints, nz, nt, zmin=0., zmax=1.0):
@@ -14,15 +16,14 @@ def exactFlux(potentialFunction, lonLatPoints, nz, nt, zmin=0., zmax=1.0):
     zbot = numpy.array([zmin + (k + 1) * dz for k in range(nz)])
     thickness = -(ztop - zbot)  # DEPTH HAS OPPOSITE SIGN TO Z
     xyBeg, xyEnd = xyVals[0, :], xyVals[-1, :]
+    psi = _expr.compile_function(potentialFunction)
     out = []
     for t in range(nt):
         flux = 0
         for k in range(nz):
-            z = zhalf[k]  # noqa: F841
-            x, y = xyBeg[:2]
-            phiA = eval(potentialFunction)
-            x, y = xyEnd[:2]
-            phiB = eval(potentialFunction)
+            z = zhalf[k]
+            phiA = _expr.evaluate(psi, x=xyBeg[0], y=xyBeg[1], z=z, t=t, nt=nt)
+            phiB = _expr.evaluate(psi, x=xyEnd[0], y=xyEnd[1], z=z, t=t, nt=nt)
             flux += (phiB - phiA) * thickness[k]
         out.append(float(flux))
     return out
@@ -31,7 +32,7 @@ def exactFlux(potentialFunction, lonLatPoints, nz, nt, zmin=0., zmax=1.0):
 def main(*, potentialFunction="(cos(t*2*pi/nt)+2)*(0.5*(y/180)**2 + sin(2*pi*x/360))", zmin=0., zmax=1.0, nz=5,
          nt=1, deltaDeg="(0.,0.)", lonLatPointsStr):
     """Prints the table of fluxexact.py:35,46."""
-    xyVals = numpy.array(eval(lonLatPointsStr))
+    xyVals = numpy.array(_expr.literal(lonLatPointsStr, 'lonLatPointsStr'), dtype=numpy.float64)
     print(f'zmin/zmax = {zmin}/{zmax}')
     print(f'beg/end target points: {xyVals[0, :]} {xyVals[-1, :]}')
     print('time_index                 flux')

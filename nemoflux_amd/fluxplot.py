@@ -3,7 +3,7 @@
 The reference loops `for itime in range(nt): fld.update(); pli.getIntegral(...)` (fluxplot.py:51-59), one host round
 trip per step and per transect.  Here ALL time steps and ALL transects are integrated in one asynchronous pass on
 the GPU (Field.computeAll) and only the (nt, ntransect) table comes back.  Plotting uses matplotlib (imported
-importable only with --show): the table is always printed or written as CSV, which is what the plot shows.
+only with --show): the table is always printed or written as CSV, which is what the plot shows.
 
     python -m nemoflux_amd.fluxplot -t T.npz -u U.npz -v V.npz -l "[(-100,-80),(100,-80),(0,80)],[...]" [-s] [-o out.csv]
     python -m nemoflux_amd.fluxplot -t T.npz -u U.npz -v V.npz -i "data/nz/*.txt"
@@ -14,6 +14,7 @@ import os
 
 import numpy
 
+from . import _expr
 from .field import Field
 from .latlonreader import LatLonReader
 
@@ -22,15 +23,17 @@ def readTargets(lonLatPoints='', iFiles=''):
     """fluxplot.py:27-46: a list of polylines from a Python-list string or from station files."""
     names = []
     if lonLatPoints:
-        pts = eval(lonLatPoints)
+        pts = _expr.literal(lonLatPoints, 'lonLatPoints')
         if len(pts) and not isinstance(pts[0][0], (list, tuple)):
             pts = [pts]  # README.md:32 passes a single polyline without the outer list (SURVEY 8a quirk 9)
         lonLatZPoints = [numpy.array([(ll[0], ll[1], 0.0) for ll in llp]) for llp in pts]
         names = [f'line{i}' for i in range(len(lonLatZPoints))]
     elif iFiles:
-        try:
-            listOfFiles = eval(iFiles)
-        except Exception:
+        try:      # fluxplot.py:37 evaluates a Python list of names; a glob pattern or a single name is accepted too
+            listOfFiles = _expr.literal(iFiles, 'iFiles')
+            if isinstance(listOfFiles, str):
+                listOfFiles = [listOfFiles]
+        except RuntimeError:
             listOfFiles = sorted(glob.glob(iFiles)) or [iFiles]
         lonLatZPoints = []
         for iFile in listOfFiles:

@@ -1,3 +1,4 @@
+import ast
 import json
 import os
 import sys
@@ -30,7 +31,7 @@ def load_golden(name):
 
 
 def transect_xyz(points_str):
-    xy = numpy.array(eval(points_str), dtype=numpy.float64)
+    xy = numpy.array(ast.literal_eval(points_str), dtype=numpy.float64)
     xyz = numpy.zeros((xy.shape[0], 3), numpy.float64)
     xyz[:, :2] = xy
     return xyz

@@ -153,3 +153,29 @@ def test_netcdf4_ingest_of_the_reference_t_file():
         io.open_tfile('/nonexistent/T.nc')
     with pytest.raises(RuntimeError, match='could not read uo'):
         io.open_uvfile(src, 'uo')      # field.py:154: the T file holds no velocity
+
+
+def test_command_line_expressions_are_parsed_not_evaluated():
+    """The reference eval()s its -l / --potentialFunction strings; the engine parses literals and compiles only
+    arithmetic on x, y, z, t, nt (nemoflux_amd/_expr.py)."""
+    from nemoflux_amd import _expr
+    from nemoflux_amd.fluxexact import exactFlux
+    from nemoflux_amd.fluxplot import readTargets
+    assert _expr.literal(' [(-180,-70),(180,40)] ') == [(-180, -70), (180, 40)]
+    code = _expr.compile_function('(1+10*z)*(t+1)*(cos(2*pi*y/360) + sin(2*pi*x/360))')
+    assert _expr.evaluate(code, x=90., y=0., z=0.5, t=1, nt=2) == 6. * 2. * (numpy.cos(0.) + numpy.sin(numpy.pi / 2))
+    for bad in ("__import__('os').system('true')", 'x.__class__', "open('f')", '[x for x in (1,)]', "'a'*3",
+                'lambda: 1', 'q + 1', 'cos(x, out=y)'):
+        with pytest.raises(RuntimeError):
+            _expr.compile_function(bad)
+        with pytest.raises(RuntimeError):
+            exactFlux(bad, [(0, 0), (1, 1)], 1, 1)
+    with pytest.raises(RuntimeError):
+        _expr.literal("__import__('os')")
+    # README.md:32 single polyline and fluxviz.py:378 list of polylines both work (SURVEY 8a quirk 9)
+    one, names = readTargets('(-180,-70),(-160,-10),(-35,40)')
+    assert len(one) == 1 and one[0].shape == (3, 3) and names == ['line0']
+    two, _ = readTargets('[(-180,-70),(-160,-10)],[(0,0),(10,10),(20,0)]')
+    assert [a.shape for a in two] == [(2, 3), (3, 3)]
+    with pytest.raises(RuntimeError):
+        readTargets("__import__('os').getcwd()")

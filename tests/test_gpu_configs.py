@@ -1,5 +1,6 @@
 """GPU parity, part 2: BASELINE.json's configurations, device datagen, ragged / edge-case shapes, f32 inputs,
 host-staged fields, slab sharding, and size-independent properties at larger sizes."""
+import ast
 import json
 import os
 
@@ -111,7 +112,7 @@ def test_config_c2_rotated_closed_loop_and_twin(oracle):
     # twin: no rotation, open transect whose end points are nodes -> exact
     dg0 = device_case(nx, ny, nz, nt, PSI_ZT)
     f0 = quiet_field(dg0.bounds_lon, dg0.bounds_lat, dg0.deptht_bounds, dg0.u, dg0.v, [transect_xyz(T_OPEN)])
-    ex = numpy.array(exactFlux(PSI_ZT, eval(T_OPEN), nz, nt))
+    ex = numpy.array(exactFlux(PSI_ZT, ast.literal_eval(T_OPEN), nz, nt))
     assert numpy.abs(f0.computeAll()[0][:, 0] - ex).max() <= 1e-12 * numpy.abs(ex).max()
 
 
@@ -434,7 +435,7 @@ def test_fluxplot_batch_driver(tmp_path, capsys):
     totals = fluxplot.main(tFile=prefix + 'T.npz', uFile=prefix + 'U.npz', vFile=prefix + 'V.npz', lonLatPoints=lines,
                            output=out)
     assert totals.shape == (5, 2)
-    ex = numpy.array(exactFlux(PSI_ZT, eval(T_OPEN), 4, 5))
+    ex = numpy.array(exactFlux(PSI_ZT, ast.literal_eval(T_OPEN), 4, 5))
     assert numpy.abs(totals[:, 0] - ex).max() <= 1e-12 * numpy.abs(ex).max()
     assert numpy.abs(totals[:, 1]).max() <= 1e-12 * numpy.abs(ex).max()
     rows = open(out).read().strip().split('\n')

@@ -113,3 +113,16 @@ def test_readme_examples_script():
     import runpy
     mod = runpy.run_path(os.path.join(ROOT, 'examples', 'readme_examples.py'))
     assert mod['main']() <= 1e-9
+
+
+def test_rccl_calls_of_the_bench_on_one_rank():
+    """The exact RCCL calls bench.py / nemoflux_amd.dist make at N>1 (init bound to the GPU, all_reduce SUM and MAX,
+    barrier with device_ids) on a one-rank communicator: all this box can run of the 'nccl' backend."""
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rccl_world1.py')], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and 'rccl world-1 OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

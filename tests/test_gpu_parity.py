@@ -10,6 +10,7 @@ Bars (BASELINE north_star: "match ... to a stated fp64 tolerance"):
   * weights (A6): same algorithm, no transcendental: <= 1e-13 absolute per (segment, cell, edge).
   * transect totals (A7): <= 1e-12 * sum|w f|.
 """
+import ast
 import numpy
 import pytest
 
@@ -147,5 +148,5 @@ def test_field_vs_fluxexact(name, oracle, cases):
             exact = m['transects'][n]['fluxexact'][t]      # reference fluxexact.py prints %20.10g
             assert abs(one[i] - exact) <= 1e-9 * max(1.0, abs(exact))
             assert one[i] == tot[t, i]
-            ex2 = oracle.fluxexact(m['psi'], eval(m['transects'][n]['points']), m['nz'], m['nt'])[t]
+            ex2 = oracle.fluxexact(m['psi'], ast.literal_eval(m['transects'][n]['points']), m['nz'], m['nt'])[t]
             assert abs(one[i] - ex2) <= 1e-13 * max(1.0, abs(ex2))

@@ -1,6 +1,7 @@
 """CPU suite, part 1: the oracle (oracle/nf_oracle.c + numpy restatements) against the golden vectors that
 oracle/gen_golden.py produced by RUNNING the reference's datagen.py / field.py / geo.py / latlonreader.py,
 and against the README known answers (the only pins of mint's A6/A7)."""
+import ast
 import json
 import os
 
@@ -157,7 +158,7 @@ def test_fluxexact_restatement_matches_reference(oracle, cases):
         for tn, tr in m['transects'].items():
             if tr['fluxexact'] is None:
                 continue   # the reference's fluxexact.py cannot evaluate arctan2 (imports only pi, cos, sin)
-            got = oracle.fluxexact(m['psi'], eval(tr['points']), m['nz'], m['nt'])
+            got = oracle.fluxexact(m['psi'], ast.literal_eval(tr['points']), m['nz'], m['nt'])
             assert numpy.allclose(got, tr['fluxexact'], rtol=6e-10, atol=1e-12)   # reference prints %20.10g (10 significant digits)
 
 
