@@ -10,6 +10,7 @@ The reference reads NetCDF through xarray.  This image has neither xarray nor ne
     bounds_lon, deptht_bounds, uo, vo; _FillValue kept, not decoded), and last to a one-off conversion by
     tools/nc2npz.py under any interpreter that has h5py (probed: the running one, /opt/conda/bin/python3.9, python3).
 """
+import json
 import os
 import subprocess
 import sys
@@ -68,7 +69,10 @@ def _open_hdf5(path, lazy=()):
 def _open(path, lazy=()):
     path = str(path)
     if path.endswith('.npz'):
-        return dict(numpy.load(path, allow_pickle=False))
+        d = dict(numpy.load(path, allow_pickle=False))
+        for k in [k for k in d if k.startswith('_attrs_')]:   # CF attributes kept as JSON text (subsetnemo.py)
+            d[k] = json.loads(str(d[k]))
+        return d
     if not os.path.exists(path):
         raise RuntimeError(f'ERROR: cannot read {path}: no such file')
     try:

@@ -148,3 +148,29 @@ def test_never_written_chunks_read_as_the_fill_value():
         want[2:4, 0:3] = field((2, 3), '<f8', 51)
         assert ds.h5fill == 7.5 and numpy.array_equal(ds.read(), want)
         assert numpy.array_equal(ds.read_leading(3), want[3]) and numpy.array_equal(ds.read_leading(0), want[0])
+
+
+def test_subsetnemo_window_round_trip(tmp_path, capsys):
+    """nemoflux_amd.subsetnemo (subsetNEMO.py:6-93): the (j, i) window of a NetCDF-4 style triple, written as the npz
+    bundles the engine opens; fill value and the time axis survive."""
+    from nemoflux_amd import io, subsetnemo
+    from nemoflux_amd.timeobj import TimeObj
+    src = {k: os.path.join(H5, f'nemo_{k}.h5') for k in 'TUV'}
+    out = subsetnemo.main(tfile=src['T'], ufile=src['U'], vfile=src['V'], outputdir=str(tmp_path / 'sub'),
+                          jmin=2, jmax=12, imin=5, imax=25)
+    assert 'creating variable uo' in capsys.readouterr().out
+    t_full, t_sub = io.open_tfile(src['T']), io.open_tfile(os.path.join(out, 'T.npz'))
+    for k in ('bounds_lon', 'bounds_lat'):
+        assert numpy.array_equal(t_sub[k], t_full[k][2:12, 5:25])
+    assert numpy.array_equal(t_sub['deptht_bounds'], t_full['deptht_bounds'])
+    for f, name in (('U', 'uo'), ('V', 'vo')):
+        full, fill_full = io.open_uvfile(src[f], name)
+        sub, fill_sub, d = io.open_uvfile(os.path.join(out, f + '.npz'), name, with_all=True)
+        whole = numpy.stack([full.read_step(t) for t in range(full.shape[0])]) if hasattr(full, 'read_step') else full
+        assert sub.dtype == numpy.float32 and numpy.array_equal(sub, whole[..., 2:12, 5:25], equal_nan=True)
+        assert fill_sub == fill_full or (numpy.isnan(fill_sub) and numpy.isnan(fill_full))
+    _, _, d = io.open_uvfile(os.path.join(out, 'U.npz'), 'uo', with_all=True)
+    assert TimeObj.fromVariables(d).getTimeAsString(1) == '1900-2-15'
+    with pytest.raises(RuntimeError, match='exceeds'):
+        subsetnemo.main(tfile=src['T'], ufile=src['U'], vfile=src['V'], outputdir=str(tmp_path / 'bad'),
+                        jmin=0, jmax=1000, imin=0, imax=4)
