@@ -214,21 +214,17 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
                 } else if (!(DIAG & 1)) store_cells<VEC>(c0, eU, eV, ncell, ny, nx, iV, absUV);
             }
     }
-    // running max (field.py:234): wavefront butterfly, then one atomic per workgroup.  All values are
-    // non-negative doubles, whose bit patterns order like unsigned integers.
+    // running max (field.py:234): wavefront butterfly, then at most one atomic per WAVEFRONT -- no LDS, no workgroup
+    // barrier, so a wave retires the moment its own columns are done (waves parked at a barrier idle their slots:
+    // -0.6..-0.8 % in-process, -8 % in the store-free diagnostic build).  All values are non-negative doubles, whose bit
+    // patterns order like unsigned integers.  The running max only grows, so it is read first (device scope, bypassing
+    // the non-coherent caches) and the atomic is issued only by a wave that would raise it: a stale read can cause a
+    // spare atomic, never a missed one.
     for (int o = 32; o > 0; o >>= 1) tmax = fmax(tmax, __shfl_xor(tmax, o, kWave));
-    __shared__ double s_max[BLOCK / kWave];
-    if ((threadIdx.x & (kWave - 1)) == 0) s_max[threadIdx.x / kWave] = tmax;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double m = s_max[0];
-#pragma unroll
-        for (int w = 1; w < BLOCK / kWave; ++w) m = fmax(m, s_max[w]);
-        if (m > 0.0 && !(DIAG & 4)) {
-            unsigned long long b;
-            __builtin_memcpy(&b, &m, 8);
-            atomicMax(maxbits, b);
-        }
+    if ((threadIdx.x & (kWave - 1)) == 0 && tmax > 0.0 && !(DIAG & 4)) {
+        unsigned long long b;
+        __builtin_memcpy(&b, &tmax, 8);
+        if (b > __hip_atomic_load(maxbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxbits, b);
     }
 }
 
@@ -481,7 +477,6 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
         case 40: return launch_flux_ww<T, VEC, 2>(a, s);                       // writer-wave form
         // diagnostic builds (WRONG RESULTS on purpose) that price one ingredient each
         case 21: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 1>(a, s);   // no stores
-        case 25: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 5>(a, s);   // no stores, no atomic max
         case 28: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 16>(a, s);  // only the two signed planes
         case 29: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 32>(a, s);  // one interleaved (eU,eV) stream
         case 45: return launch_flux_ww<T, VEC, 2, 2>(a, s);                        // writer-wave, no stores
