@@ -56,18 +56,30 @@ __device__ inline double fixed(T x, T fill)
     return (x != x || x == fill) ? 0.0 : (double)x;
 }
 
+template <bool NTS = false>
+__device__ inline void store1(double *p, double a)
+{
+    if (NTS) __builtin_nontemporal_store(a, p);
+    else *p = a;
+}
+template <bool NTS = false>
 __device__ inline void store2(double *p, double a, double b, bool aligned)
 {
     if (aligned) {
-        *reinterpret_cast<double2 *>(p) = make_double2(a, b);
+        if (NTS) {
+            dvec2 v = {a, b};
+            __builtin_nontemporal_store(v, reinterpret_cast<dvec2 *>(p));
+        } else {
+            *reinterpret_cast<double2 *>(p) = make_double2(a, b);
+        }
     } else {
-        p[0] = a;
-        p[1] = b;
+        store1<NTS>(p, a);
+        store1<NTS>(p + 1, b);
     }
 }
 
 // stores of one lane's VEC consecutive cells starting at c0 (see the layout comment at the top)
-template <int VEC>
+template <int VEC, bool NTS = false>
 __device__ inline void store_cells(long c0, const double *eU, const double *eV, long ncell, unsigned ny, unsigned nx,
                                    double *__restrict__ iV, double *__restrict__ absUV)
 {
@@ -76,32 +88,32 @@ __device__ inline void store_cells(long c0, const double *eU, const double *eV, 
     const unsigned j0 = (unsigned)(c0 / nx);
     const unsigned i0 = (unsigned)(c0 - (long)j0 * nx);
     if (VEC == 1) {
-        p1[c0] = eU[0];
-        p2[c0] = eV[0];
-        aU[c0] = fabs(eU[0]);
-        aV[c0] = fabs(eV[0]);
-        if (j0 + 1 < ny) p0[c0 + nx] = eV[0];
-        p3[(i0 + 1 < nx) ? c0 + 1 : c0 + 1 - nx] = eU[0];
+        store1<NTS>(p1 + c0, eU[0]);
+        store1<NTS>(p2 + c0, eV[0]);
+        store1<NTS>(aU + c0, fabs(eU[0]));
+        store1<NTS>(aV + c0, fabs(eV[0]));
+        if (j0 + 1 < ny) store1<NTS>(p0 + c0 + nx, eV[0]);
+        store1<NTS>(p3 + ((i0 + 1 < nx) ? c0 + 1 : c0 + 1 - nx), eU[0]);
     } else {
         // own slots and |.|: dense 16 B/lane stores (c0 is a multiple of VEC)
 #pragma unroll
         for (int k = 0; k < VEC; k += 2) {
-            store2(p1 + c0 + k, eU[k], eU[k + 1], true);
-            store2(p2 + c0 + k, eV[k], eV[k + 1], true);
-            store2(aU + c0 + k, fabs(eU[k]), fabs(eU[k + 1]), true);
-            store2(aV + c0 + k, fabs(eV[k]), fabs(eV[k + 1]), true);
+            store2<NTS>(p1 + c0 + k, eU[k], eU[k + 1], true);
+            store2<NTS>(p2 + c0 + k, eV[k], eV[k + 1], true);
+            store2<NTS>(aU + c0 + k, fabs(eU[k]), fabs(eU[k + 1]), true);
+            store2<NTS>(aV + c0 + k, fabs(eV[k]), fabs(eV[k + 1]), true);
         }
         if (i0 + VEC <= nx) {
             // lane's cells sit in one row: south slots of the row above = the same stream shifted by nx
             if (j0 + 1 < ny) {
                 const bool al = (nx & 1u) == 0;
 #pragma unroll
-                for (int k = 0; k < VEC; k += 2) store2(p0 + c0 + nx + k, eV[k], eV[k + 1], al);
+                for (int k = 0; k < VEC; k += 2) store2<NTS>(p0 + c0 + nx + k, eV[k], eV[k + 1], al);
             }
             // west slots of the cells to the right: shifted by one (8 B stores; the row's last cell wraps to
             // column 0, field.py:223)
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) p3[(i0 + k + 1 < nx) ? c0 + k + 1 : c0 + k + 1 - nx] = eU[k];
+            for (int k = 0; k < VEC; ++k) store1<NTS>(p3 + ((i0 + k + 1 < nx) ? c0 + k + 1 : c0 + k + 1 - nx), eU[k]);
         } else {
             // lane straddles a row end (nx % VEC != 0): per-cell bookkeeping
 #pragma unroll
@@ -109,8 +121,8 @@ __device__ inline void store_cells(long c0, const double *eU, const double *eV, 
                 const long c = c0 + k;
                 const unsigned j = (unsigned)(c / nx);
                 const unsigned i = (unsigned)(c - (long)j * nx);
-                if (j + 1 < ny) p0[c + nx] = eV[k];
-                p3[(i + 1 < nx) ? c + 1 : c + 1 - nx] = eU[k];
+                if (j + 1 < ny) store1<NTS>(p0 + c + nx, eV[k]);
+                store1<NTS>(p3 + ((i + 1 < nx) ? c + 1 : c + 1 - nx), eU[k]);
             }
         }
     }
@@ -204,14 +216,14 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
                 }
                 if (DIAG & 32) {  // diagnostic: ONE interleaved (eU,eV) stream, 32 B per lane
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) store2(iV + 2 * (c0 + k), eU[k], eV[k], true);
+                    for (int k = 0; k < VEC; ++k) store2<true>(iV + 2 * (c0 + k), eU[k], eV[k], true);
                 } else if (DIAG & 16) {  // only the two signed planes (the rest comes from k_expand_planes)
 #pragma unroll
                     for (int k = 0; k < VEC; k += 2) {
-                        store2(iV + ncell + c0 + k, eU[k], eU[k + 1], true);
-                        store2(iV + 2 * ncell + c0 + k, eV[k], eV[k + 1], true);
+                        store2<true>(iV + ncell + c0 + k, eU[k], eU[k + 1], true);
+                        store2<true>(iV + 2 * ncell + c0 + k, eV[k], eV[k + 1], true);
                     }
-                } else if (!(DIAG & 1)) store_cells<VEC>(c0, eU, eV, ncell, ny, nx, iV, absUV);
+                } else if (!(DIAG & 1)) store_cells<VEC, !(DIAG & 64)>(c0, eU, eV, ncell, ny, nx, iV, absUV);
             }
     }
     // running max (field.py:234): wavefront butterfly, then at most one atomic per WAVEFRONT -- no LDS, no workgroup
@@ -380,12 +392,12 @@ __global__ __launch_bounds__(kWwBlock) void k_flux_ww(const T *__restrict__ u, c
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) tmax = fmax(tmax, fmax(fabs(eU[k]), fabs(eV[k])));
                     if (DIAG == 0) {
-                        store_cells<VEC>(ch * VEC, eU, eV, ncell, ny, nx, iV, absUV);
+                        store_cells<VEC, true>(ch * VEC, eU, eV, ncell, ny, nx, iV, absUV);
                     } else if (DIAG == 1) {  // diagnostic: only the two signed planes
 #pragma unroll
                         for (int k = 0; k < VEC; k += 2) {
-                            store2(iV + ncell + ch * VEC + k, eU[k], eU[k + 1], true);
-                            store2(iV + 2 * ncell + ch * VEC + k, eV[k], eV[k + 1], true);
+                            store2<true>(iV + ncell + ch * VEC + k, eU[k], eU[k + 1], true);
+                            store2<true>(iV + 2 * ncell + ch * VEC + k, eV[k], eV[k + 1], true);
                         }
                     }
                 }
@@ -475,6 +487,7 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
         case 12: return launch_flux_t<T, VEC, 8, true, 256, 1, false>(a, s);   // 8 levels in flight
         case 14: return launch_flux_t<T, VEC, 16, true, 256, 1, false>(a, s);  // 16 levels in flight
         case 40: return launch_flux_ww<T, VEC, 2>(a, s);                       // writer-wave form
+        case 13: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 64>(a, s);  // plain (temporal) stores: +2..6 %
         // diagnostic builds (WRONG RESULTS on purpose) that price one ingredient each
         case 21: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 1>(a, s);   // no stores
         case 28: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 16>(a, s);  // only the two signed planes
