@@ -151,7 +151,7 @@ def main():
     res = rows.cpu().numpy()
     nseg = fld._nseg
     max_err, max_ref = 0.0, 0.0
-    for p, pts in enumerate(polys):
+    for p, pts in enumerate(polys if rank == 0 else []):     # rank 0 prints the line: only it needs the check
         ex = exactFlux(psi, pts, nz, nt_global)
         got = res[:, nseg + p]
         max_err = max(max_err, float(numpy.abs(got - numpy.array(ex)).max()))

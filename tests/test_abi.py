@@ -179,3 +179,24 @@ def test_command_line_expressions_are_parsed_not_evaluated():
     assert [a.shape for a in two] == [(2, 3), (3, 3)]
     with pytest.raises(RuntimeError):
         readTargets("__import__('os').getcwd()")
+
+
+def build_c_client(tmp_path):
+    """examples/c_client.c: plain C on the ABI, linked against the in-tree library (no Python, no torch)."""
+    import subprocess
+    exe = str(tmp_path / 'c_client')
+    libdir = os.path.join(ROOT, 'nemoflux_amd')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-I', os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'examples', 'c_client.c'), '-L', libdir, '-lnemoflux_amd',
+                           '-Wl,-rpath,' + libdir, '-lm', '-o', exe])
+    return exe
+
+
+def test_c_client_links_and_fails_loudly_without_gpu(tmp_path):
+    import subprocess
+    from nemoflux_amd import _lib
+    exe = build_c_client(tmp_path)
+    if _lib.device_count() > 0:
+        pytest.skip('GPU present: tests/test_gpu_dist.py runs the client')
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and 'no usable AMD GPU' in r.stderr and 'no CPU fallback' in r.stderr

@@ -126,3 +126,12 @@ def test_rccl_calls_of_the_bench_on_one_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rccl_world1.py')], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and 'rccl world-1 OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_plain_c_client_of_the_abi(tmp_path):
+    """examples/c_client.c (README case C1 through both ABI levels, from C): 360 twice, mint's error convention."""
+    import subprocess
+    from test_abi import build_c_client
+    r = subprocess.run([build_c_client(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'C client OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'level 2: 5 segments, flux = 360.0000' in r.stdout and 'level 1: 648 cells, flux = 360.0000' in r.stdout
