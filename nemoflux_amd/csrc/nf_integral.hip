@@ -30,9 +30,12 @@ __global__ __launch_bounds__(kBlock) void k_gather_segscan(const int *__restrict
     double val = 0.0;
     int key = -1;
     if (k < n) {
-        const long c = cell[k];
-        const double2 *pw = reinterpret_cast<const double2 *>(w4 + 4 * k);
-        const double2 wa = pw[0], wb = pw[1];
+        // the record stream is read once per launch: non-temporal, so that it does not push the plane sectors its
+        // neighbours gather -- nor the arc lengths the next flux kernel re-reads -- out of the caches (-0.7 % per pass)
+        typedef double dvec2 __attribute__((ext_vector_type(2)));
+        const long c = __builtin_nontemporal_load(cell + k);
+        const dvec2 *pw = reinterpret_cast<const dvec2 *>(w4 + 4 * k);
+        const dvec2 wa = __builtin_nontemporal_load(pw), wb = __builtin_nontemporal_load(pw + 1);
         double d0, d1, d2, d3;
         if (planes == 2) {
             // the engine's own planes: the south and west slots are copies of the neighbours' north and east values
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_segscan(const int *__restrict
             d0 = da.x; d1 = da.y; d2 = db.x; d3 = db.y;
         }
         val = ((wa.x * d0 + wa.y * d1) + wb.x * d2) + wb.y * d3;
-        key = seg[k];
+        key = __builtin_nontemporal_load(seg + k);
     }
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
