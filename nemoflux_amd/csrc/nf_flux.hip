@@ -129,9 +129,8 @@ __device__ inline void store_cells(long c0, const double *eU, const double *eV, 
 }
 
 // BLOCK threads; every lane owns CH chunks of VEC cells, chunk q at tile_base + q*BLOCK*VEC + tid*VEC, so the
-// workgroup reads CH x (BLOCK x 16 B) contiguous bytes per (z, field).  SYNC keeps the workgroup's waves in
-// z-lockstep (one barrier per UZ levels) so that those contiguous pieces are requested close in time.
-template <typename T, int VEC, int UZ, bool NT, int BLOCK, int CH, bool SYNC, int DIAG = 0>
+// workgroup reads CH x (BLOCK x 16 B) contiguous bytes per (z, field).  The waves of a workgroup never synchronise.
+template <typename T, int VEC, int UZ, bool NT, int BLOCK, int CH, int DIAG = 0>
 __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T *__restrict__ v, long ncell,
                                                 unsigned ny, unsigned nx, int z0, int z1,
                                                 const double *__restrict__ thickness,
@@ -196,7 +195,6 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
                 }
             pu += (long)UZ * ncell;
             pv += (long)UZ * ncell;
-            if (SYNC) __syncthreads();
         }
         // edge fluxes (field.py:195-196, 225-228)
 #pragma unroll
@@ -434,14 +432,14 @@ int tuning_set(const char *name, int value)
     return NF_OK;
 }
 
-template <typename T, int VEC, int UZ, bool NT, int BLOCK, int CH, bool SYNC, int DIAG = 0>
+template <typename T, int VEC, int UZ, bool NT, int BLOCK, int CH, int DIAG = 0>
 static int launch_flux_t(const FluxArgs &a, hipStream_t s)
 {
     const long per_tile = (long)BLOCK * VEC * CH;
     const unsigned ntiles = (unsigned)((a.ncell + per_tile - 1) / per_tile);
     const int xcd_map = g_xcd_map;
     const unsigned grid = xcd_map ? xcd_grid(ntiles) : ntiles;
-    hipLaunchKernelGGL((k_flux<T, VEC, UZ, NT, BLOCK, CH, SYNC, DIAG>), dim3(grid, (unsigned)(a.batch.zr ? a.batch.nsteps : 1)),
+    hipLaunchKernelGGL((k_flux<T, VEC, UZ, NT, BLOCK, CH, DIAG>), dim3(grid, (unsigned)(a.batch.zr ? a.batch.nsteps : 1)),
                        dim3(BLOCK), 0, s, (const T *)a.u, (const T *)a.v, a.ncell, (unsigned)a.ny, (unsigned)a.nx, a.z0,
                        a.z1, a.thickness, a.arcE, a.arcN, (T)a.fill, a.scale, a.sverdrup, a.iV, a.absU, a.maxbits, ntiles,
                        xcd_map, a.batch);
@@ -478,22 +476,22 @@ template <typename T, int VEC>
 static int launch_flux_v(const FluxArgs &a, hipStream_t s)
 {
     const int variant = a.batch.zr ? 0 : g_variant;  // the multi-step launch exists for the default kernel only
-    if (VEC == 1) return launch_flux_t<T, VEC, 8, false, 256, 1, false>(a, s);
+    if (VEC == 1) return launch_flux_t<T, VEC, 8, true, 256, 1>(a, s);  // odd cell counts / unaligned fields: one cell per lane
     switch (variant) {
         // measured alternatives (tools/ab_flux.py): all within +-3 % of the default
-        case 3: return launch_flux_t<T, VEC, 4, true, 256, 1, false>(a, s);    // 4 levels in flight (+2..3 %)
-        case 4: return launch_flux_t<T, VEC, 4, true, 256, 2, false>(a, s);    // 4 levels, 2 chunks per lane
-        case 11: return launch_flux_t<T, VEC, 10, false, 256, 1, false>(a, s); // plain (temporal) loads: +4 %
-        case 12: return launch_flux_t<T, VEC, 8, true, 256, 1, false>(a, s);   // 8 levels in flight
-        case 14: return launch_flux_t<T, VEC, 16, true, 256, 1, false>(a, s);  // 16 levels in flight
+        case 3: return launch_flux_t<T, VEC, 4, true, 256, 1>(a, s);    // 4 levels in flight (+2..3 %)
+        case 4: return launch_flux_t<T, VEC, 4, true, 256, 2>(a, s);    // 4 levels, 2 chunks per lane
+        case 11: return launch_flux_t<T, VEC, 10, false, 256, 1>(a, s); // plain (temporal) loads: +4 %
+        case 12: return launch_flux_t<T, VEC, 8, true, 256, 1>(a, s);   // 8 levels in flight
+        case 14: return launch_flux_t<T, VEC, 16, true, 256, 1>(a, s);  // 16 levels in flight
         case 40: return launch_flux_ww<T, VEC, 2>(a, s);                       // writer-wave form
-        case 13: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 64>(a, s);  // plain (temporal) stores: +2..6 %
+        case 13: return launch_flux_t<T, VEC, 10, true, 256, 1, 64>(a, s);  // plain (temporal) stores: +2..6 %
         // diagnostic builds (WRONG RESULTS on purpose) that price one ingredient each
-        case 21: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 1>(a, s);   // no stores
-        case 28: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 16>(a, s);  // only the two signed planes
-        case 29: return launch_flux_t<T, VEC, 10, true, 256, 1, false, 32>(a, s);  // one interleaved (eU,eV) stream
+        case 21: return launch_flux_t<T, VEC, 10, true, 256, 1, 1>(a, s);   // no stores
+        case 28: return launch_flux_t<T, VEC, 10, true, 256, 1, 16>(a, s);  // only the two signed planes
+        case 29: return launch_flux_t<T, VEC, 10, true, 256, 1, 32>(a, s);  // one interleaved (eU,eV) stream
         case 45: return launch_flux_ww<T, VEC, 2, 2>(a, s);                        // writer-wave, no stores
-        default: return launch_flux_t<T, VEC, 10, true, 256, 1, false>(a, s);  // 10 levels x 2 fields in flight
+        default: return launch_flux_t<T, VEC, 10, true, 256, 1>(a, s);  // 10 levels x 2 fields in flight
     }
 }
 
