@@ -145,6 +145,13 @@ int nf_field_set_uv(nf_field **self, const void *u, const void *v, long nt, int 
                     double fill_value);
 /* field.py:19,225-228: scale fluxes by 6371000/1e6 */
 int nf_field_set_sverdrup(nf_field **self, int sverdrup);
+/* Compact resident mode (default off).  The reference stores, per time step, the (ncell,4) array whose slots 0 and 3
+ * are copies of the neighbours' slots 2 and 1 (field.py:209-223) and the two |.| arrays (field.py:231-232).  With
+ * compact != 0 the flux kernel keeps only the two signed arrays (eU, eV) resident -- all the transect reduction reads --
+ * and the other four are derived, bit-identically, when nf_field_read_step / nf_field_device_ptr ask for them:
+ * 104 instead of 311 MB of stores per step on the ORCA12-like grid.  Batch drivers (fluxplot.py:51-59) never ask. */
+int nf_field_set_compact(nf_field **self, int compact);
+
 /* Multi-GPU ownership: this rank integrates the flattened slabs s = t*nz + z in [s_begin, s_end)
  * (SURVEY.md section 8e).  Default: all of them. */
 int nf_field_set_slab_range(nf_field **self, long s_begin, long s_end);

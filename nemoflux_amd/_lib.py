@@ -89,6 +89,7 @@ _sig('nf_field_set_thickness', [_pp, c_double_p, ctypes.c_long])
 _sig('nf_field_set_uv', [_pp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                          ctypes.c_double])
 _sig('nf_field_set_sverdrup', [_pp, ctypes.c_int])
+_sig('nf_field_set_compact', [_pp, ctypes.c_int])
 _sig('nf_field_set_slab_range', [_pp, ctypes.c_long, ctypes.c_long])
 _sig('nf_field_add_transect', [_pp, c_double_p, ctypes.c_int, ctypes.c_int, c_int_p])
 _sig('nf_field_build_weights', [_pp, ctypes.c_int, ctypes.c_double])

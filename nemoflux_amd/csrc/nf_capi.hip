@@ -617,6 +617,10 @@ struct nf_field {
     double *d_iV = nullptr;   // [4][ncell]
     double *d_abs = nullptr;  // [2][ncell]
     double *d_aos = nullptr;  // (ncell,4) re-pack buffer for read_step, allocated on first use
+    // compact resident mode (nf_field_set_compact): the flux kernel stores only eU and eV; the neighbour-copy planes and
+    // the two |.| planes are derived when somebody asks for them (read_step, device_ptr)
+    int compact = 0;
+    bool derived_stale = false;
     // multi-step launches for small grids (compute_all): per-step planes, scratch and z ranges
     double *d_iVb = nullptr, *d_absb = nullptr, *d_scratchb = nullptr;
     int *d_zr = nullptr;
@@ -669,6 +673,15 @@ static int field_free_geometry(nf_field *f)
 }
 
 static int elem_size(int dtype) { return dtype == NF_F32 ? 4 : 8; }
+
+// compact mode: bring planes 0, 3 and the |.| planes up to date with planes 1, 2 of the latest step
+static int field_ensure_derived(nf_field *f)
+{
+    if (!f->derived_stale) return NF_OK;
+    NF_TRY(launch_expand_planes(f->d_iV, f->d_abs, f->ncell, f->ny, f->nx, f->stream));
+    f->derived_stale = false;
+    return NF_OK;
+}
 
 static int field_row_length(const nf_field *f) { return f->ws.nseg + (int)f->polylines.size(); }
 
@@ -726,6 +739,8 @@ static int field_step_async(nf_field *f, long t, double *row_dev)
     a.absU = f->d_abs;
     a.absV = f->d_abs + f->ncell;
     a.maxbits = f->d_maxbits;
+    a.signed_only = f->compact && flux_supports_signed_only(a);
+    f->derived_stale = a.signed_only != 0;
     if (f->timing) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         NF_HIP(hipEventCreate(&e0));
@@ -835,6 +850,7 @@ static int field_all_steps_batched(nf_field *f, double *rows_dev)
                           hipMemcpyDeviceToDevice, f->stream));
     NF_HIP(hipMemcpyAsync(f->d_abs, f->d_absb + (size_t)(f->nt - 1) * 2 * n, sizeof(double) * 2 * n,
                           hipMemcpyDeviceToDevice, f->stream));
+    f->derived_stale = false;
     return NF_OK;
 }
 
@@ -970,6 +986,17 @@ try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_sverdrup: null field");
     (*self)->sverdrup = sverdrup ? 1 : 0;
     ++(*self)->version;
+    return NF_OK;
+}
+NF_API_CATCH
+
+int nf_field_set_compact(nf_field **self, int compact)
+try {
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_compact: null field");
+    nf_field *f = *self;
+    if (!compact && f->d_iV) NF_TRY(field_ensure_derived(f));   // leaving the mode: the planes become whole again
+    f->compact = compact ? 1 : 0;
+    ++f->version;
     return NF_OK;
 }
 NF_API_CATCH
@@ -1135,6 +1162,7 @@ try {
     nf_field *f = *self;
     NF_REQUIRE(f->d_iV, NF_ERR_STATE, "nf_field_read_step: set_bounds first");
     NF_NEED_DEVICE();
+    if (iV_host || eU_host || eV_host) NF_TRY(field_ensure_derived(f));
     const size_t n = (size_t)f->ncell;
     if (iV_host) {  // re-pack the planes into the reference's (ncell,4) layout, then one D2H into the caller's array
         if (!f->d_aos) NF_TRY(dev_alloc(&f->d_aos, n * 4));
@@ -1203,6 +1231,7 @@ int nf_field_device_ptr(nf_field **self, int which, void **dev)
 try {
     NF_REQUIRE(self && *self && dev, NF_ERR_ARG, "nf_field_device_ptr: null argument");
     nf_field *f = *self;
+    if (which >= 0 && which <= 2) NF_TRY(field_ensure_derived(f));   // compact mode: the derived planes on demand
     switch (which) {
         case 0: *dev = f->d_iV; break;
         case 1: *dev = f->d_abs; break;

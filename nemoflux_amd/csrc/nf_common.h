@@ -72,8 +72,12 @@ struct FluxArgs {
     double *iV, *absU, *absV; // resident outputs
     unsigned long long *maxbits;  // running max as the bits of a non-negative double
     StepBatch batch;
+    int signed_only = 0;      // 1: store only planes 1 (eU) and 2 (eV); launch_expand_planes derives the other four
 };
 int launch_flux(const FluxArgs &a, hipStream_t s);
+bool flux_supports_signed_only(const FluxArgs &a);
+// planes 0 (south copies), 3 (west copies incl. the periodic wrap) and |eU|, |eV| from planes 1 and 2 (field.py:209-232)
+int launch_expand_planes(double *iV, double *absUV, long ncell, long ny, long nx, hipStream_t s);
 int tuning_set(const char *name, int value);
 long tuning_version();
 int launch_planes_to_aos(const double *planes, long ncell, double *aos, hipStream_t s);

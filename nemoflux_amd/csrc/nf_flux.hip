@@ -411,6 +411,31 @@ __global__ __launch_bounds__(kWwBlock) void k_flux_ww(const T *__restrict__ u, c
     }
 }
 
+// ---- the four derived planes from the two signed ones (compact resident mode; variant 50) ---------------------
+// plane 0[c] = eV[c - nx] (row 0 stays 0: field.py:219), plane 3[c] = eU of the cell to the left, column 0 taking the
+// row's last cell (field.py:221-223), |eU|, |eV| (field.py:231-232).  One lane per cell; pure streaming.
+__global__ __launch_bounds__(kBlock) void k_expand_planes(double *__restrict__ iV, double *__restrict__ absUV, long ncell,
+                                                          unsigned nx)
+{
+    const long c = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= ncell) return;
+    const double *eU = iV + ncell, *eV = iV + 2 * ncell;
+    const unsigned j = (unsigned)(c / nx), i = (unsigned)(c - (long)j * nx);
+    const double u = eU[c], v = eV[c];
+    if (j > 0) store1<true>(iV + c, eV[c - nx]);
+    store1<true>(iV + 3 * ncell + c, eU[i > 0 ? c - 1 : c - 1 + nx]);
+    store1<true>(absUV + c, fabs(u));
+    store1<true>(absUV + ncell + c, fabs(v));
+}
+int launch_expand_planes(double *iV, double *absUV, long ncell, long ny, long nx, hipStream_t s)
+{
+    NF_REQUIRE(iV && absUV && ncell > 0 && ncell == ny * nx, NF_ERR_ARG, "expand: bad arguments");
+    hipLaunchKernelGGL(k_expand_planes, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, iV, absUV,
+                       ncell, (unsigned)nx);
+    NF_HIP(hipGetLastError());
+    return NF_OK;
+}
+
 static int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
@@ -476,6 +501,10 @@ template <typename T, int VEC>
 static int launch_flux_v(const FluxArgs &a, hipStream_t s)
 {
     const int variant = a.batch.zr ? 0 : g_variant;  // the multi-step launch exists for the default kernel only
+    if (a.signed_only) {  // compact resident mode: the caller expands on demand
+        NF_REQUIRE(VEC > 1 && !a.batch.zr, NF_ERR_STATE, "flux: the compact mode needs 16-byte aligned fields, an even cell count and one step per launch");
+        return launch_flux_t<T, VEC, 10, true, 256, 1, 16>(a, s);
+    }
     if (VEC == 1) return launch_flux_t<T, VEC, 8, true, 256, 1>(a, s);  // odd cell counts / unaligned fields: one cell per lane
     switch (variant) {
         // measured alternatives (tools/ab_flux.py): all within +-3 % of the default
@@ -485,6 +514,10 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
         case 12: return launch_flux_t<T, VEC, 8, true, 256, 1>(a, s);   // 8 levels in flight
         case 14: return launch_flux_t<T, VEC, 16, true, 256, 1>(a, s);  // 16 levels in flight
         case 40: return launch_flux_ww<T, VEC, 2>(a, s);                       // writer-wave form
+        case 50: {  // split form: two signed planes from the flux kernel + a streaming expansion
+            const int rc = launch_flux_t<T, VEC, 10, true, 256, 1, 16>(a, s);
+            return rc != NF_OK ? rc : launch_expand_planes(a.iV, a.absU, a.ncell, a.ny, a.nx, s);
+        }
         case 13: return launch_flux_t<T, VEC, 10, true, 256, 1, 64>(a, s);  // plain (temporal) stores: +2..6 %
         // diagnostic builds (WRONG RESULTS on purpose) that price one ingredient each
         case 21: return launch_flux_t<T, VEC, 10, true, 256, 1, 1>(a, s);   // no stores
@@ -493,6 +526,13 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
         case 45: return launch_flux_ww<T, VEC, 2, 2>(a, s);                        // writer-wave, no stores
         default: return launch_flux_t<T, VEC, 10, true, 256, 1>(a, s);  // 10 levels x 2 fields in flight
     }
+}
+
+// the compact mode rides on the 16-byte vector path (aligned fields, cell count a multiple of the lane's vector)
+bool flux_supports_signed_only(const FluxArgs &a)
+{
+    const bool al16 = ((uintptr_t)a.u % 16 == 0) && ((uintptr_t)a.v % 16 == 0);
+    return al16 && !a.batch.zr && a.ncell % (a.dtype == NF_F32 ? 4 : 2) == 0;
 }
 
 int launch_flux(const FluxArgs &a, hipStream_t s)

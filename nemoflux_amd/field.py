@@ -144,7 +144,7 @@ class Field(object):
     # ------------------------------------------------------------------------------------------
     def _setup(self, bounds_lon, bounds_lat, deptht_bounds, uo, vo, lonLatZPoints, sverdrup,
                fill_value=numpy.nan, periodX=360., numCellsPerBucket=128, slab_range=None, readback=True,
-               timeValues=None, stream=None, timeObj=None):
+               timeValues=None, stream=None, timeObj=None, compact=False):
         _lib.require_gpu()
         self.sverdrup = sverdrup
         self.periodX = periodX
@@ -206,6 +206,8 @@ class Field(object):
         if self._lazy is None:
             check(lib.nf_field_set_uv(ctypes.byref(self._h), pu, pv, self.nt, _dtype_code(uo), uv_dev, float(fill_value)))
         check(lib.nf_field_set_sverdrup(ctypes.byref(self._h), 1 if sverdrup else 0))
+        if compact:   # keep only (eU, eV) resident; the (ncell,4) copies and |.| arrays are derived at read-back
+            check(lib.nf_field_set_compact(ctypes.byref(self._h), 1))
         if slab_range is not None:
             check(lib.nf_field_set_slab_range(ctypes.byref(self._h), int(slab_range[0]), int(slab_range[1])))
         self.slab_range = slab_range

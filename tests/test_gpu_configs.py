@@ -731,3 +731,36 @@ def test_field_time_axis_from_file():
     g = load_golden('c1_x')
     f2 = quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], g['u'], g['v'], [])
     assert f2.timeObj.getTimeAsString(0) == '0'          # no time axis in datagen output: index labels, no exception
+
+
+@pytest.mark.parametrize('real,nx,ny', [('float64', 360, 180), ('float32', 360, 180), ('float64', 35, 18)])
+def test_compact_resident_mode_is_bit_identical(real, nx, ny):
+    """nf_field_set_compact: the flux kernel keeps only (eU, eV); the neighbour-copy slots of the (ncell,4) array, the two
+    |.| arrays, the arrows and every transect total read back exactly as in the default mode -- step by step, through
+    computeAll, and after switching the mode off again.  35 x 18: odd nx (lanes straddle rows, periodic wrap)."""
+    import ctypes
+    from nemoflux_amd._lib import lib, check
+    dg = device_case(nx, ny, 7, 3, PSI_ZT, (20., 30.) if nx == 360 else (0., 0.), real=real)
+    tr = [transect_xyz(T_TRI), transect_xyz(T_OPEN)]
+    args = (dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, tr)
+    ref = quiet_field(*args)
+    cmp_ = quiet_field(*args, compact=True)
+    for t in (2, 0, 1):
+        ref.timeIndex = cmp_.timeIndex = t
+        ref.update()
+        cmp_.update()
+        assert numpy.array_equal(ref.integratedVelocity, cmp_.integratedVelocity)
+        assert numpy.array_equal(ref.edgeFluxesUArray, cmp_.edgeFluxesUArray)
+        assert numpy.array_equal(ref.edgeFluxesVArray, cmp_.edgeFluxesVArray)
+        assert numpy.array_equal(ref.vectorValues, cmp_.vectorValues) and ref.maxAbsFlux == cmp_.maxAbsFlux
+        assert ref.computeFlux(t) == cmp_.computeFlux(t)          # no read-back: nothing is expanded
+    ta, sa = ref.computeAll()
+    tb, sb = cmp_.computeAll()
+    assert numpy.array_equal(ta, tb) and numpy.array_equal(sa, sb)
+    cmp_.computeFlux(1)                                            # stale derived planes ...
+    check(lib.nf_field_set_compact(ctypes.byref(cmp_._h), 0))      # ... are completed when the mode is left
+    ref.computeFlux(1, readback=True)
+    m = ctypes.c_double()
+    check(lib.nf_field_read_step(ctypes.byref(cmp_._h), cmp_.integratedVelocity.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                 None, None, ctypes.byref(m)))
+    assert numpy.array_equal(ref.integratedVelocity, cmp_.integratedVelocity)
