@@ -121,8 +121,10 @@ class _Transect(object):
 class Field(object):
 
     def __init__(self, tFile, uFile, vFile, lonLatZPoints, sverdrup=False, **kw):
-        """Same positional signature as the reference (field.py:17).  tFile/uFile/vFile: NetCDF (needs
-        xarray) or the .npz bundles of nemoflux_amd.datagen; see fromArrays for in-memory / HBM data."""
+        """Same positional signature as the reference (field.py:17).  tFile/uFile/vFile: NetCDF-4 files (read by
+        nemoflux_amd.io / hdf5min; compressed uo/vo one time step at a time) or the .npz bundles of
+        nemoflux_amd.datagen / subsetnemo; see fromArrays for in-memory / HBM data and _setup for the keywords
+        (fill_value, periodX, slab_range, readback, compact, stream, ...)."""
         t = open_tfile(tFile)
         if 'deptht_bounds' not in t:
             raise RuntimeError(f'ERROR: {tFile} has no variable deptht_bounds')

@@ -47,7 +47,8 @@ def readTargets(lonLatPoints='', iFiles=''):
 
 def fluxSeries(tFile, uFile, vFile, lonLatZPoints, sverdrup=False):
     """(nt, ntransect) total fluxes and the Field (one batched GPU pass over every time step)."""
-    fld = Field(tFile, uFile, vFile, lonLatZPoints, sverdrup, readback=False)
+    # only the totals are wanted: no read-back, and only the signed edge fluxes stay resident (compact mode)
+    fld = Field(tFile, uFile, vFile, lonLatZPoints, sverdrup, readback=False, compact=True)
     totals, _ = fld.computeAll()
     return totals, fld
 
