@@ -411,27 +411,56 @@ __global__ __launch_bounds__(kWwBlock) void k_flux_ww(const T *__restrict__ u, c
     }
 }
 
-// ---- the four derived planes from the two signed ones (compact resident mode; variant 50) ---------------------
+// ---- the four derived planes from the two signed ones ---------------------------------------------------------
 // plane 0[c] = eV[c - nx] (row 0 stays 0: field.py:219), plane 3[c] = eU of the cell to the left, column 0 taking the
-// row's last cell (field.py:221-223), |eU|, |eV| (field.py:231-232).  One lane per cell; pure streaming.
+// row's last cell (field.py:221-223), |eU|, |eV| (field.py:231-232).  Pure streaming right behind the flux kernel (its
+// two planes are still in the Infinity Cache): a lane owns two cells, every store is a dense aligned 16 B piece.
+// This is the second half of the default step (the flux kernel stores only eU, eV: a third of the store traffic inside
+// the read-saturated kernel; -3 % per pass at f64, -12 % on the kernel at f32 against the fused-store form) and the
+// on-demand expansion of the compact resident mode.
+template <int W>
 __global__ __launch_bounds__(kBlock) void k_expand_planes(double *__restrict__ iV, double *__restrict__ absUV, long ncell,
                                                           unsigned nx)
 {
-    const long c = (long)blockIdx.x * kBlock + threadIdx.x;
-    if (c >= ncell) return;
+    const long c0 = ((long)blockIdx.x * kBlock + threadIdx.x) * W;
+    if (c0 >= ncell) return;
     const double *eU = iV + ncell, *eV = iV + 2 * ncell;
-    const unsigned j = (unsigned)(c / nx), i = (unsigned)(c - (long)j * nx);
-    const double u = eU[c], v = eV[c];
-    if (j > 0) store1<true>(iV + c, eV[c - nx]);
-    store1<true>(iV + 3 * ncell + c, eU[i > 0 ? c - 1 : c - 1 + nx]);
-    store1<true>(absUV + c, fabs(u));
-    store1<true>(absUV + ncell + c, fabs(v));
+    double u[W], v[W], south[W], west[W];
+    bool has_south[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const long c = c0 + k;
+        const unsigned j = (unsigned)(c / nx), i = (unsigned)(c - (long)j * nx);
+        u[k] = eU[c];
+        v[k] = eV[c];
+        has_south[k] = j > 0;
+        south[k] = has_south[k] ? eV[c - nx] : 0.0;
+        west[k] = eU[i > 0 ? c - 1 : c - 1 + nx];
+    }
+    if (W == 2) {
+        if (has_south[0] && has_south[1]) store2<true>(iV + c0, south[0], south[1], true);
+        else if (has_south[1]) store1<true>(iV + c0 + 1, south[1]);   // the pair straddles the end of row 0 (odd nx)
+        store2<true>(iV + 3 * ncell + c0, west[0], west[1], true);
+        store2<true>(absUV + c0, fabs(u[0]), fabs(u[1]), true);
+        store2<true>(absUV + ncell + c0, fabs(v[0]), fabs(v[1]), true);
+    } else {
+        if (has_south[0]) store1<true>(iV + c0, south[0]);
+        store1<true>(iV + 3 * ncell + c0, west[0]);
+        store1<true>(absUV + c0, fabs(u[0]));
+        store1<true>(absUV + ncell + c0, fabs(v[0]));
+    }
 }
 int launch_expand_planes(double *iV, double *absUV, long ncell, long ny, long nx, hipStream_t s)
 {
     NF_REQUIRE(iV && absUV && ncell > 0 && ncell == ny * nx, NF_ERR_ARG, "expand: bad arguments");
-    hipLaunchKernelGGL(k_expand_planes, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, iV, absUV,
-                       ncell, (unsigned)nx);
+    if (ncell % 2 == 0) {
+        const long n2 = ncell / 2;
+        hipLaunchKernelGGL(k_expand_planes<2>, dim3((unsigned)((n2 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, iV, absUV,
+                           ncell, (unsigned)nx);
+    } else {
+        hipLaunchKernelGGL(k_expand_planes<1>, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, iV,
+                           absUV, ncell, (unsigned)nx);
+    }
     NF_HIP(hipGetLastError());
     return NF_OK;
 }
@@ -514,17 +543,17 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
         case 12: return launch_flux_t<T, VEC, 8, true, 256, 1>(a, s);   // 8 levels in flight
         case 14: return launch_flux_t<T, VEC, 16, true, 256, 1>(a, s);  // 16 levels in flight
         case 40: return launch_flux_ww<T, VEC, 2>(a, s);                       // writer-wave form
-        case 50: {  // split form: two signed planes from the flux kernel + a streaming expansion
-            const int rc = launch_flux_t<T, VEC, 10, true, 256, 1, 16>(a, s);
-            return rc != NF_OK ? rc : launch_expand_planes(a.iV, a.absU, a.ncell, a.ny, a.nx, s);
-        }
-        case 13: return launch_flux_t<T, VEC, 10, true, 256, 1, 64>(a, s);  // plain (temporal) stores: +2..6 %
         // diagnostic builds (WRONG RESULTS on purpose) that price one ingredient each
         case 21: return launch_flux_t<T, VEC, 10, true, 256, 1, 1>(a, s);   // no stores
         case 28: return launch_flux_t<T, VEC, 10, true, 256, 1, 16>(a, s);  // only the two signed planes
         case 29: return launch_flux_t<T, VEC, 10, true, 256, 1, 32>(a, s);  // one interleaved (eU,eV) stream
         case 45: return launch_flux_ww<T, VEC, 2, 2>(a, s);                        // writer-wave, no stores
-        default: return launch_flux_t<T, VEC, 10, true, 256, 1>(a, s);  // 10 levels x 2 fields in flight
+        case 5: return launch_flux_t<T, VEC, 10, true, 256, 1>(a, s);   // all seven stores fused into the flux kernel
+        default: {  // 10 levels x 2 fields in flight, eU and eV stored; the copies and |.| by the streaming expansion
+            if (a.batch.zr) return launch_flux_t<T, VEC, 10, true, 256, 1>(a, s);   // multi-step launch: fused stores
+            const int rc = launch_flux_t<T, VEC, 10, true, 256, 1, 16>(a, s);
+            return rc != NF_OK ? rc : launch_expand_planes(a.iV, a.absU, a.ncell, a.ny, a.nx, s);
+        }
     }
 }
 

@@ -38,30 +38,36 @@ with open(os.path.join(out, f'{tag}_kernel_stats.csv'), 'w') as f:
         f.write('"{kernel}",{calls},{total_ns},{avg_ns:.1f},{pct},{min_ns},{max_ns}\n'.format(**r))
 
 
-def counter(sub, cname):
+def counter(sub, cname, kernel):
     fn = find(sub, '*counter_collection.csv')
     vals = []
     if not fn:
         return vals
     with open(fn) as f:
         for r in csv.DictReader(f):
-            if 'k_flux' in r.get('Kernel_Name', '') and r.get('Counter_Name') == cname:
+            if kernel in r.get('Kernel_Name', '') and r.get('Counter_Name') == cname:
                 vals.append(float(r['Counter_Value']))
     return vals
 
 
-fetch, write = counter('pmc_fetch', 'FETCH_SIZE'), counter('pmc_write', 'WRITE_SIZE')
+# one time step = the flux kernel (stores eU, eV) + the streaming expansion (the four derived planes): bench.py's HIP
+# events bracket the pair, so the traffic of the pair is what is compared with the algorithmic bytes
+fetch, write = counter('pmc_fetch', 'FETCH_SIZE', 'k_flux'), counter('pmc_write', 'WRITE_SIZE', 'k_flux')
+xfetch, xwrite = counter('pmc_fetch', 'FETCH_SIZE', 'k_expand_planes'), counter('pmc_write', 'WRITE_SIZE', 'k_expand_planes')
 res = {}
 if fetch and write:
     f_kb, w_kb = sum(fetch) / len(fetch), sum(write) / len(write)
+    xf_kb = sum(xfetch) / len(xfetch) if xfetch else 0.0
+    xw_kb = sum(xwrite) / len(xwrite) if xwrite else 0.0
     # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the
     # bytes of a wide coalesced (16 B/lane) streaming read -> double it; WRITE_SIZE is exact for 16 B/lane stores.
-    hbm = 2.0 * f_kb * 1024 + w_kb * 1024
+    hbm = 2.0 * f_kb * 1024 + w_kb * 1024 + 2.0 * xf_kb * 1024 + xw_kb * 1024
     bj = json.load(open(os.path.join(src, 'bench_trace.json')))
     c = bj['config']
     key = f"{c['nx']}x{c['ny']}x{c['nz']}x{c['nt_global']}_{bj['dtype']}"
-    res[key] = dict(kernel='nf::k_flux', launches_sampled=[len(fetch), len(write)], FETCH_SIZE_KiB_avg=f_kb,
-                    WRITE_SIZE_KiB_avg=w_kb, fetch_correction='x2 (gfx950, 16 B/lane coalesced stream)',
+    res[key] = dict(kernel='nf::k_flux + nf::k_expand_planes', launches_sampled=[len(fetch), len(write)],
+                    FETCH_SIZE_KiB_avg=f_kb, WRITE_SIZE_KiB_avg=w_kb, expand_FETCH_SIZE_KiB_avg=xf_kb,
+                    expand_WRITE_SIZE_KiB_avg=xw_kb, fetch_correction='x2 (gfx950, 16 B/lane coalesced stream)',
                     hbm_bytes_per_launch=hbm,
                     algorithmic_bytes_per_launch=bj['roofline']['algorithmic_bytes_per_unit'] * c['nz'] * c['ny'] * c['nx'])
 with open(os.path.join(out, 'pmc_traffic.json'), 'w') as f:
