@@ -19,6 +19,8 @@
 //                           plane 3[j, (i+1)%nx] = eU[j,i]  (west slot incl. the periodic wrap, :221-223)
 //   abs planes [2][ncell]   |eU|, |eV|
 // nf_field_read_step() re-packs the planes into the reference's (ncell,4) layout on demand.
+// By default the flux kernel stores only planes 1 and 2 and k_expand_planes (below) streams them into the other four
+// right behind it: two thirds of the store traffic leave the read-saturated kernel.
 //
 // Algorithmic bytes per (t,z,j,i) unit: 2*sizeof(T) read + (16 arc + 32 iV + 16 abs)/nz  (SURVEY 8d).
 #include <cstring>
