@@ -101,7 +101,12 @@ class Dataset(object):
                     for j in range(es):
                         d2[:, j] = a[j * ne:(j + 1) * ne]
                     return None
-                raw = a[:ne * es].reshape(es, ne).T.tobytes() + a[ne * es:].tobytes()
+                tmp = numpy.empty(a.size, numpy.uint8)     # byte-plane assignments: numpy releases the GIL for them
+                t2 = tmp[:ne * es].reshape(ne, es)
+                for j in range(es):
+                    t2[:, j] = a[j * ne:(j + 1) * ne]
+                tmp[ne * es:] = a[ne * es:]
+                raw = tmp
             elif fid == 3:  # fletcher32: checksum appended
                 raw = raw[:-4]
             else:
