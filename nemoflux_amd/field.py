@@ -32,13 +32,19 @@ def _dtype_code(a):
     raise RuntimeError(f'ERROR: unsupported dtype {dt} (need float64 or float32)')
 
 
+def _native(a):
+    """C-contiguous host array in native byte order (files may be big-endian: NetCDF classic, some HDF5)."""
+    a = numpy.ascontiguousarray(a)
+    return a if a.dtype.isnative else a.astype(a.dtype.newbyteorder('='))
+
+
 def _geometry_only(bounds_lon, bounds_lat):
     """Run the geometry kernel alone: {'points': (ncell,4,3), 'arcLengths': (ncell,4), 'box': 4 floats}."""
     h = ctypes.c_void_p()
     check(lib.nf_field_new(ctypes.byref(h)))
     try:
-        blon = numpy.ascontiguousarray(bounds_lon)
-        blat = numpy.ascontiguousarray(bounds_lat)
+        blon = _native(bounds_lon)
+        blat = _native(bounds_lat)
         if blon.dtype != blat.dtype:
             blat = blat.astype(blon.dtype)
         ny, nx, _ = blon.shape
@@ -160,8 +166,8 @@ class Field(object):
         # --- cell bounds -> geometry kernel (field.py:22-31, 42, 56)
         plon, plat = _lib.device_pointer(bounds_lon), _lib.device_pointer(bounds_lat)
         if plon is None:
-            bounds_lon = numpy.ascontiguousarray(bounds_lon)
-            bounds_lat = numpy.ascontiguousarray(bounds_lat)
+            bounds_lon = _native(bounds_lon)
+            bounds_lat = _native(bounds_lat)
             if bounds_lat.dtype != bounds_lon.dtype:
                 bounds_lat = bounds_lat.astype(bounds_lon.dtype)
             self._keep += [bounds_lon, bounds_lat]
@@ -191,14 +197,14 @@ class Field(object):
         if hasattr(uo, 'read_step') or hasattr(vo, 'read_step'):
             # file-backed variables inflated one time step at a time (nemoflux_amd.hdf5min.LazyVariable)
             self._lazy = (uo, vo)
-            self._lazy_dtype = numpy.dtype(uo.dtype)
+            self._lazy_dtype = numpy.dtype(uo.dtype).newbyteorder('=')
             self._uv_code, self._fill = _dtype_code(uo), float(fill_value)
             self._lazy_step = (-1, None, None)
             pu = pv = None
             uv_dev = 0
         elif pu is None:
-            uo = numpy.ascontiguousarray(uo)
-            vo = numpy.ascontiguousarray(vo)
+            uo = _native(uo)
+            vo = _native(vo)
             if vo.dtype != uo.dtype:
                 vo = vo.astype(uo.dtype)
             self._keep += [uo, vo]

@@ -6,6 +6,8 @@ The reference reads NetCDF through xarray.  This image has neither xarray nor ne
   * NetCDF-4 / HDF5 files are parsed in-process by nemoflux_amd/hdf5min.py (numpy + zlib only): contiguous variables
     come back as views of the mapped file, so the engine stages each time step from the page cache straight to HBM;
     chunked / deflated variables (real NEMO output) are inflated one time step at a time (LazyVariable);
+  * NetCDF classic / 64-bit-offset files (magic 'CDF\\x01' / 'CDF\\x02': older NEMO output) are opened with
+    scipy.io.netcdf_file (memory-mapped, big-endian views; one time step is converted at a time);
   * what hdf5min does not understand falls back to xarray IF it is importable (same variable names: bounds_lat,
     bounds_lon, deptht_bounds, uo, vo; _FillValue kept, not decoded), and last to a one-off conversion by
     tools/nc2npz.py under any interpreter that has h5py (probed: the running one, /opt/conda/bin/python3.9, python3).
@@ -53,7 +55,8 @@ def _open_hdf5(path, lazy=()):
             continue
         if ds.dtype.kind not in 'fiu':
             continue
-        if name in lazy and len(ds.shape) >= 3 and not (ds.is_contiguous() and ds.dtype.isnative):
+        # only a (t, z, y, x) variable is walked one time step at a time; anything smaller is read whole
+        if name in lazy and len(ds.shape) == 4 and not (ds.is_contiguous() and ds.dtype.isnative):
             out[name] = hdf5min.LazyVariable(ds)
         else:
             a = ds.read()
@@ -66,6 +69,42 @@ def _open_hdf5(path, lazy=()):
     return out
 
 
+class StepView(object):
+    """A (nt, nz, ny, nx) array of a mapped file in the file's byte order, handed out one native-order time step at a
+    time (same surface as hdf5min.LazyVariable: shape, dtype, read_step)."""
+
+    def __init__(self, array):
+        self._a, self.shape = array, tuple(array.shape)
+        self.dtype = numpy.dtype(array.dtype.newbyteorder('='))
+
+    def read_step(self, t):
+        return numpy.ascontiguousarray(self._a[t], dtype=self.dtype)
+
+
+def _open_classic(path, lazy=()):
+    """NetCDF-3 (CDF-1 / CDF-2) through scipy: variables are strided views of the mapped file, _FillValue kept as is."""
+    import warnings
+    from scipy.io import netcdf_file
+    f = netcdf_file(path, 'r', mmap=True, maskandscale=False)
+    out = {}
+    for name, var in f.variables.items():
+        if var.data.dtype.kind not in 'fiu':
+            continue
+        a = var.data
+        if a.ndim == 4 and name in lazy:
+            out[name] = StepView(a)                                  # big-endian on disk: converted step by step
+        else:
+            out[name] = a if a.dtype.isnative else a.astype(a.dtype.newbyteorder('='))
+        attrs = dict(var._attributes)
+        if '_FillValue' in attrs:
+            out['_FillValue_' + name] = numpy.asarray(attrs['_FillValue'])
+        if var.data.ndim == 1:
+            out['_attrs_' + name] = attrs
+    out['_classic_file'] = f       # keeps the mapping alive for the views
+    warnings.filterwarnings('ignore', message='Cannot close a netcdf_file opened with mmap=True')
+    return out
+
+
 def _open(path, lazy=()):
     path = str(path)
     if path.endswith('.npz'):
@@ -75,6 +114,10 @@ def _open(path, lazy=()):
         return d
     if not os.path.exists(path):
         raise RuntimeError(f'ERROR: cannot read {path}: no such file')
+    with open(path, 'rb') as fh:
+        magic = fh.read(4)
+    if magic in (b'CDF\x01', b'CDF\x02'):
+        return _open_classic(path, lazy)
     try:
         return _open_hdf5(path, lazy)
     except hdf5min.Hdf5Error:

@@ -50,3 +50,35 @@ def cases():
 
 
 FULL_CASES = ['c1_x', 'singular', 'cossin36', 'rot36_zt', 'def36_zt', 'sv36_land']
+
+
+def write_classic_triple(dirname, g, version=2):
+    """T/U/V NetCDF-3 (classic / 64-bit-offset) files from a golden case, written by scipy.io.netcdf_file -- an
+    independent implementation of the format -- the way IOIPSL-era NEMO wrote them: float32, big-endian, uo/vo record
+    variables over an unlimited time axis, land as _FillValue (uo) and NaN (vo)."""
+    from scipy.io import netcdf_file
+    u, v = g['u'].astype(numpy.float32), g['v'].astype(numpy.float32)
+    u[:, :, 4:9, 10:20] = numpy.float32(1.e20)
+    v[:, :, 4:9, 10:20] = numpy.nan
+    nt, nz, ny, nx = u.shape
+    paths = {k: os.path.join(str(dirname), f'{k}.nc') for k in 'TUV'}
+    f = netcdf_file(paths['T'], 'w', version=version)
+    for n, s in (('y', ny), ('x', nx), ('nvertex', 4), ('deptht', nz), ('axis_nbounds', 2)):
+        f.createDimension(n, s)
+    for name in ('bounds_lon', 'bounds_lat'):
+        f.createVariable(name, 'f4', ('y', 'x', 'nvertex'))[:] = g[name].astype(numpy.float32)
+    f.createVariable('deptht_bounds', 'f4', ('deptht', 'axis_nbounds'))[:] = g['deptht_bounds'].astype(numpy.float32)
+    f.close()
+    for k, name, a in (('U', 'uo', u), ('V', 'vo', v)):
+        f = netcdf_file(paths[k], 'w', version=version)
+        for n, s in (('time_counter', None), ('depth', nz), ('y', ny), ('x', nx)):
+            f.createDimension(n, s)
+        tc = f.createVariable('time_counter', 'f8', ('time_counter',))
+        tc.standard_name, tc.units, tc.calendar = 'time', 'seconds since 1900-01-01 00:00:00', 'noleap'
+        var = f.createVariable(name, 'f4', ('time_counter', 'depth', 'y', 'x'))
+        if k == 'U':
+            var._FillValue = numpy.float32(1.e20)
+        tc[:] = numpy.arange(nt) * 86400. * 30.5 + 1296000.
+        var[:] = a
+        f.close()
+    return paths, u, v

@@ -717,6 +717,29 @@ def test_field_from_netcdf4_style_files():
     assert ff.maxAbsFlux == fa.maxAbsFlux
 
 
+def test_field_from_netcdf_classic_files(tmp_path):
+    """Field(tFile, uFile, vFile, ...) from NetCDF-3 64-bit-offset files (big-endian float32 record variables, written by
+    scipy) equals Field.fromArrays on the same values, bit for bit; the flux time series of the batch driver too."""
+    import contextlib
+    import io as _io
+    from conftest import write_classic_triple
+    from nemoflux_amd.field import Field
+    from nemoflux_amd.fluxplot import fluxSeries
+    g = load_golden('def36_zt')
+    paths, u, v = write_classic_triple(tmp_path, g)
+    tr = [transect_xyz(T_OPEN), transect_xyz("(-180,-70),(-160,-10),(-35,40),(20,-50),(60,50),(180,40)")]
+    with contextlib.redirect_stdout(_io.StringIO()):
+        ff = Field(paths['T'], paths['U'], paths['V'], tr)
+        totals, _ = fluxSeries(paths['T'], paths['U'], paths['V'], tr)
+    fa = quiet_field(g['bounds_lon'].astype(numpy.float32), g['bounds_lat'].astype(numpy.float32),
+                     g['deptht_bounds'].astype(numpy.float32), u, v, tr, fill_value=float(numpy.float32(1.e20)))
+    for t in (1, 2, 0):
+        assert ff.computeFlux(t, readback=True) == fa.computeFlux(t, readback=True)
+        assert numpy.array_equal(ff.integratedVelocity, fa.integratedVelocity)
+    at, _ = fa.computeAll()
+    assert numpy.array_equal(totals, at) and ff.timeObj.getTimeAsString(2) == '1900-3-18'
+
+
 def test_field_time_axis_from_file():
     """Field built from files carries the U file's time axis (field.py:38) with decoded dates (fluxviz.py:204 title)."""
     import contextlib

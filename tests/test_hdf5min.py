@@ -174,3 +174,25 @@ def test_subsetnemo_window_round_trip(tmp_path, capsys):
     with pytest.raises(RuntimeError, match='exceeds'):
         subsetnemo.main(tfile=src['T'], ufile=src['U'], vfile=src['V'], outputdir=str(tmp_path / 'bad'),
                         jmin=0, jmax=1000, imin=0, imax=4)
+
+
+@pytest.mark.parametrize('version', [1, 2])
+def test_netcdf_classic_files_through_io(tmp_path, version):
+    """NetCDF-3 classic (CDF-1) and 64-bit-offset (CDF-2) files: big-endian record variables come back one native-order
+    time step at a time, fill value and time axis included (nemoflux_amd.io -> scipy.io.netcdf_file)."""
+    from conftest import write_classic_triple
+    from nemoflux_amd import io
+    from nemoflux_amd.timeobj import TimeObj
+    g = load_golden('def36_zt')
+    paths, u, v = write_classic_triple(tmp_path, g, version)
+    t = io.open_tfile(paths['T'])
+    for k in ('bounds_lon', 'bounds_lat', 'deptht_bounds'):
+        assert t[k].dtype == numpy.float32 and t[k].dtype.isnative and numpy.array_equal(t[k], g[k].astype(numpy.float32))
+    uo, fill, d = io.open_uvfile(paths['U'], 'uo', with_all=True)
+    assert uo.shape == u.shape and uo.dtype == numpy.float32 and fill == float(numpy.float32(1.e20))
+    for s in range(u.shape[0]):
+        a = uo.read_step(s)
+        assert a.dtype.isnative and a.flags.c_contiguous and numpy.array_equal(a, u[s])
+    vo, vfill = io.open_uvfile(paths['V'], 'vo')
+    assert numpy.isnan(vfill) and numpy.array_equal(vo.read_step(1), v[1], equal_nan=True)
+    assert TimeObj.fromVariables(d).getTimeAsString(1) == '1900-2-15'
