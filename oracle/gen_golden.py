@@ -20,6 +20,7 @@ mint (python-mint>=1.24.4, README.md:12) is NOT installed: nothing here pins A6/
 the README known answers recorded in tests/golden/known_answers.json.
 
 Run:  python oracle/gen_golden.py          (writes tests/golden/*.npz, *.json)
+      python oracle/gen_golden.py --only=reg16        (one case; the others stay as they are)
       /opt/conda/bin/python3.9 oracle/gen_golden.py --tnc   (T.nc bounds via h5py)
 """
 import sys, os, io, json, types, contextlib, glob
@@ -61,12 +62,16 @@ def main():
                 vals.append(float(p[1]))
         return vals
 
+    only = [a.split('=', 1)[1] for a in sys.argv if a.startswith('--only=')]
+
     def case(name, psi, nx, ny, nz, nt, deltaDeg=(0., 0.), transects=(), sverdrup=False,
-             full=True, land=None):
+             full=True, land=None, box=(-180., 180., -90., 90., 0., 1.)):
+        if only and name not in only:
+            return None
         with contextlib.redirect_stdout(io.StringIO()):
             dg = datagen.DataGen()
             dg.setSizes(nx, ny, nz, nt)
-            dg.setBoundingBox(-180., 180., -90., 90., 0., 1.)
+            dg.setBoundingBox(*box)
             dg.build()
             if deltaDeg[0] != 0 or deltaDeg[1] != 0:
                 dg.rotatePole(deltaDeg=deltaDeg)
@@ -131,7 +136,8 @@ def main():
         meta = dict(name=name, psi=psi, nx=nx, ny=ny, nz=nz, nt=nt, deltaDeg=list(deltaDeg),
                     sverdrup=sverdrup, fill_value=fill, land=land, transects={})
         for tname, pts in transects:
-            meta['transects'][tname] = dict(points=pts, fluxexact=run_fluxexact(psi, nz, nt, pts))
+            meta['transects'][tname] = dict(points=pts, fluxexact=run_fluxexact(psi, nz, nt, pts, box[4], box[5]))
+        meta['box'] = list(box)
         print(name, 'maxAbsFlux', mx[-1])
         return meta
 
@@ -152,6 +158,18 @@ def main():
                       transects=[('open', T_OPEN)]))
     metas.append(case('cossin360', PSI_CS, 360, 180, 1, 1, transects=[('tri', T_TRI)], full=False))
     metas.append(case('rot360_zt', PSI_ZT, 360, 180, 2, 2, deltaDeg=(20., 30.), transects=[('tri', T_TRI), ('open', T_OPEN)], full=False))
+    # a regional box whose dx != dy: the reference spaces LATITUDE with dx (datagen.py:49), and a
+    # depth range other than [0, 1]
+    metas.append(case('reg16', PSI_ZT, 16, 10, 2, 2, box=(-60., 20., -50., 10., 0., 100.),
+                      transects=[('tri', "(-50,-45),(-20,-45),(-35,-10),(-50,-45)"), ('open', "(-50,-45),(-20,-45),(-35,-10)")]))
+    metas = [m for m in metas if m is not None]
+    if only:      # regenerate single cases: merge into the existing index, leave everything else untouched
+        with open(os.path.join(OUT, 'cases.json')) as f:
+            old = json.load(f)
+        metas = [m for m in old if m['name'] not in only] + metas
+        with open(os.path.join(OUT, 'cases.json'), 'w') as f:
+            json.dump(metas, f, indent=1)
+        return
     with open(os.path.join(OUT, 'cases.json'), 'w') as f:
         json.dump(metas, f, indent=1)
 

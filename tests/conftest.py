@@ -49,7 +49,12 @@ def cases():
     return load_cases()
 
 
-FULL_CASES = ['c1_x', 'singular', 'cossin36', 'rot36_zt', 'def36_zt', 'sv36_land']
+FULL_CASES = ['c1_x', 'singular', 'cossin36', 'rot36_zt', 'def36_zt', 'sv36_land', 'reg16']
+
+
+def case_box(m):
+    """(xmin, xmax, ymin, ymax, zmin, zmax) of a golden case; the global box unless the case records another."""
+    return tuple(m.get('box', (-180., 180., -90., 90., 0., 1.)))
 
 
 def write_classic_triple(dirname, g, version=2):

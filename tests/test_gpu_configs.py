@@ -7,7 +7,7 @@ import os
 import numpy
 import pytest
 
-from conftest import FULL_CASES, GOLDEN, load_golden, transect_xyz
+from conftest import FULL_CASES, GOLDEN, case_box, load_golden, transect_xyz
 
 pytestmark = pytest.mark.gpu
 EPS = numpy.finfo(numpy.float64).eps
@@ -26,11 +26,12 @@ def quiet_field(*a, **kw):
         return Field.fromArrays(*a, **kw)
 
 
-def device_case(nx, ny, nz, nt, psi, delta=(0., 0.), real='float64', lat_uses_dx=None):
+def device_case(nx, ny, nz, nt, psi, delta=(0., 0.), real='float64', lat_uses_dx=None,
+                box=(-180., 180., -90., 90., 0., 1.)):
     from nemoflux_amd.datagen import DataGen
     dg = DataGen(real=real, lat_uses_dx=lat_uses_dx)
     dg.setSizes(nx, ny, nz, nt)
-    dg.setBoundingBox(-180., 180., -90., 90., 0., 1.)
+    dg.setBoundingBox(*box)
     dg.build()
     if delta != (0., 0.):
         dg.rotatePole(delta)
@@ -40,13 +41,15 @@ def device_case(nx, ny, nz, nt, psi, delta=(0., 0.), real='float64', lat_uses_dx
 
 
 # ------------------------------------------------------------------------------------------ device datagen
-@pytest.mark.parametrize('name', ['c1_x', 'singular', 'cossin36', 'rot36_zt', 'def36_zt', 'cossin360', 'rot360_zt'])
+@pytest.mark.parametrize('name', ['c1_x', 'singular', 'cossin36', 'rot36_zt', 'def36_zt', 'cossin360', 'rot360_zt', 'reg16'])
 def test_device_datagen_vs_reference(name, cases):
     """nf_datagen.hip against the reference's own DataGen outputs (tests/golden).  Same operation order, device
     vs glibc transcendentals: bounds to 1e-12 deg; u = dpsi/ds inherits ds's acos conditioning (eps/angle^2)."""
     m = [c for c in cases if c['name'] == name][0]
     g = load_golden(name)
-    dg = device_case(m['nx'], m['ny'], m['nz'], m['nt'], m['psi'], tuple(m['deltaDeg']))
+    # reg16: regional box with dx != dy -- the reference spaces latitude with dx (datagen.py:49), so must the device
+    dg = device_case(m['nx'], m['ny'], m['nz'], m['nt'], m['psi'], tuple(m['deltaDeg']), box=case_box(m),
+                     lat_uses_dx=True if name == 'reg16' else None)
     blon, blat = dg.bounds_lon.cpu().numpy(), dg.bounds_lat.cpu().numpy()
     ok = numpy.abs(g['bounds_lat']) < 90 - 1e-9
     assert numpy.abs(blat - g['bounds_lat']).max() <= 1e-12
@@ -55,7 +58,7 @@ def test_device_datagen_vs_reference(name, cases):
         assert numpy.array_equal(blon, g['bounds_lon']) and numpy.array_equal(blat, g['bounds_lat'])
     assert numpy.array_equal(dg.deptht_bounds, g['deptht_bounds'])
     u, v = dg.u.cpu().numpy(), dg.v.cpu().numpy()
-    theta = 2 * numpy.pi / m['nx']
+    theta = numpy.pi / 180. * (case_box(m)[1] - case_box(m)[0]) / m['nx']     # edge length in radians
     rtol = 64 * EPS / theta ** 2
     if 'u' in g.files:
         ru, rv = g['u'], g['v']

@@ -8,7 +8,7 @@ import os
 import numpy
 import pytest
 
-from conftest import FULL_CASES, GOLDEN, load_golden, transect_xyz
+from conftest import FULL_CASES, GOLDEN, case_box, load_golden, transect_xyz
 
 EPS = numpy.finfo(numpy.float64).eps
 
@@ -72,11 +72,11 @@ def test_f32_inputs(oracle):
     assert numpy.allclose(got, ref, rtol=0, atol=1e-15 * numpy.abs(ref).max() * 4)
 
 
-@pytest.mark.parametrize('name', ['c1_x', 'singular', 'cossin36', 'rot36_zt', 'def36_zt', 'cossin360', 'rot360_zt'])
+@pytest.mark.parametrize('name', ['c1_x', 'singular', 'cossin36', 'rot36_zt', 'def36_zt', 'cossin360', 'rot360_zt', 'reg16'])
 def test_datagen_restatement(name, oracle, cases):
     m = case_meta(cases, name)
     g = load_golden(name)
-    dg = oracle.DataGen(m['nx'], m['ny'], m['nz'], m['nt'])
+    dg = oracle.DataGen(m['nx'], m['ny'], m['nz'], m['nt'], *case_box(m))   # reg16: regional box, lat spaced with dx
     if m['deltaDeg'][0] or m['deltaDeg'][1]:
         dg.rotatePole(m['deltaDeg'])
     ok = numpy.abs(g['bounds_lat']) < 90 - 1e-9     # longitude of a point AT a pole is noise in the reference too
@@ -158,7 +158,7 @@ def test_fluxexact_restatement_matches_reference(oracle, cases):
         for tn, tr in m['transects'].items():
             if tr['fluxexact'] is None:
                 continue   # the reference's fluxexact.py cannot evaluate arctan2 (imports only pi, cos, sin)
-            got = oracle.fluxexact(m['psi'], ast.literal_eval(tr['points']), m['nz'], m['nt'])
+            got = oracle.fluxexact(m['psi'], ast.literal_eval(tr['points']), m['nz'], m['nt'], *case_box(m)[4:])
             assert numpy.allclose(got, tr['fluxexact'], rtol=6e-10, atol=1e-12)   # reference prints %20.10g (10 significant digits)
 
 
