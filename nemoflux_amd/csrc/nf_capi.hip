@@ -776,6 +776,27 @@ static bool field_can_batch(const nf_field *f)
            f->weights_built;
 }
 
+// every time step of a pass, one after the other.  A rank of a multi-GPU run owns a contiguous range of steps (slab
+// sharding): the rows of all the others are zeroed with two memsets instead of one per step (at 8 ranks that is 84 tiny
+// launches per pass saved), and only the owned steps are walked.
+static int field_all_steps_direct(nf_field *f, double *rows_dev)
+{
+    const int rowlen = field_row_length(f);
+    const long total = f->nt * f->nz;
+    const long s_end = f->s_end < 0 ? total : std::min(f->s_end, total);
+    const long s_begin = std::min(f->s_begin, s_end);
+    const long ta = s_end > s_begin ? s_begin / f->nz : 0;                    // first step with an owned slab
+    const long tb = s_end > s_begin ? (s_end - 1) / f->nz + 1 : 0;            // one past the last
+    if (rowlen > 0) {
+        if (ta > 0) NF_HIP(hipMemsetAsync(rows_dev, 0, sizeof(double) * rowlen * (size_t)ta, f->stream));
+        if (tb < f->nt)
+            NF_HIP(hipMemsetAsync(rows_dev + (size_t)tb * rowlen, 0, sizeof(double) * rowlen * (size_t)(f->nt - tb),
+                                  f->stream));
+    }
+    for (long t = ta; t < tb; ++t) NF_TRY(field_step_async(f, t, rows_dev + (size_t)t * rowlen));
+    return NF_OK;
+}
+
 static int field_all_steps_batched(nf_field *f, double *rows_dev)
 {
     const int rowlen = field_row_length(f);
@@ -1119,7 +1140,6 @@ try {
     NF_NEED_DEVICE();
     nf_field *f = *self;
     NF_REQUIRE(f->weights_built, NF_ERR_STATE, "nf_field_compute_all_async: build_weights first");
-    const int rowlen = field_row_length(f);
     if (field_can_batch(f)) return field_all_steps_batched(f, rows_dev);
     // Replay a captured graph of the whole pass when nothing changed since it was captured.  Capture needs a real
     // (non-null) stream, resident fields, and no per-launch timing events.
@@ -1133,8 +1153,7 @@ try {
         field_drop_graph(f);
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(f->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            int rc = NF_OK;
-            for (long t = 0; t < f->nt && rc == NF_OK; ++t) rc = field_step_async(f, t, rows_dev + (size_t)t * rowlen);
+            const int rc = field_all_steps_direct(f, rows_dev);
             hipError_t e = hipStreamEndCapture(f->stream, &graph);
             if (rc == NF_OK && e == hipSuccess && graph &&
                 hipGraphInstantiate(&f->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
@@ -1151,8 +1170,7 @@ try {
             (void)hipGetLastError();
         }
     }
-    for (long t = 0; t < f->nt; ++t) NF_TRY(field_step_async(f, t, rows_dev + (size_t)t * rowlen));
-    return NF_OK;
+    return field_all_steps_direct(f, rows_dev);
 }
 NF_API_CATCH
 
