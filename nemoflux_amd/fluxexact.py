@@ -19,12 +19,12 @@ def exactFlux(potentialFunction, lonLatPoints, nz, nt, zmin=0., zmax=1.0):
     psi = _expr.compile_function(potentialFunction)
     out = []
     for t in range(nt):
+        # psi at every level at once (same ufuncs element by element), then the reference's running sum over k
+        phiA = _expr.evaluate(psi, x=xyBeg[0], y=xyBeg[1], z=zhalf, t=t, nt=nt) + numpy.zeros(nz)
+        phiB = _expr.evaluate(psi, x=xyEnd[0], y=xyEnd[1], z=zhalf, t=t, nt=nt) + numpy.zeros(nz)
         flux = 0
         for k in range(nz):
-            z = zhalf[k]
-            phiA = _expr.evaluate(psi, x=xyBeg[0], y=xyBeg[1], z=z, t=t, nt=nt)
-            phiB = _expr.evaluate(psi, x=xyEnd[0], y=xyEnd[1], z=z, t=t, nt=nt)
-            flux += (phiB - phiA) * thickness[k]
+            flux += (phiB[k] - phiA[k]) * thickness[k]
         out.append(float(flux))
     return out
 
