@@ -180,10 +180,13 @@ def test_orca12_properties_two_steps():
 # ------------------------------------------------------------------------------------------ shapes / edge cases
 @pytest.mark.parametrize('nx,ny,nz,nt,dt', [(35, 17, 3, 2, 'float64'), (35, 18, 4, 1, 'float64'), (36, 18, 5, 2, 'float32'),
                                               (35, 18, 2, 1, 'float32'), (7, 1, 1, 1, 'float64'), (1, 5, 2, 1, 'float64'),
-                                              (130, 67, 9, 1, 'float64')])
-def test_ragged_shapes_bit_exact(nx, ny, nz, nt, dt, oracle):
+                                              (130, 67, 9, 1, 'float64'), (2, 3, 2, 1, 'float64'), (4, 1, 3, 2, 'float32'),
+                                              (1, 4, 1, 1, 'float64'), (2, 1, 11, 1, 'float64'), (3, 4, 2, 1, 'float64')])
+@pytest.mark.parametrize('compact', [False, True])
+def test_ragged_shapes_bit_exact(nx, ny, nz, nt, dt, compact, oracle):
     """odd cell counts (scalar path), odd nx with even ncell (lanes straddling row ends, unaligned south-slot
-    stream), f32 4-wide path, single row / column, uz remainder loop; missing values as NaN and 1e20."""
+    stream), f32 4-wide path, single row / column / pair, uz remainder loop; missing values as NaN and 1e20; with the
+    derived planes expanded every step (default) and on demand (compact resident mode)."""
     rng = numpy.random.default_rng(nx * 1000 + ny)
     o = oracle.DataGen(nx, ny, nz, nt, lat_uses_dx=False)
     u = rng.standard_normal((nt, nz, ny, nx)).astype(dt)
@@ -192,7 +195,7 @@ def test_ragged_shapes_bit_exact(nx, ny, nz, nt, dt, oracle):
     v[rng.random(v.shape) < 0.05] = 1.e20
     th = rng.uniform(0.5, 2.0, nz)
     db = numpy.stack([numpy.zeros(nz), th], axis=1)
-    fld = quiet_field(o.bounds_lon, o.bounds_lat, db, u, v, [], fill_value=1.e20, sverdrup=(nx % 2 == 1))
+    fld = quiet_field(o.bounds_lon, o.bounds_lat, db, u, v, [], fill_value=1.e20, sverdrup=(nx % 2 == 1), compact=compact)
     st = oracle.EdgeFluxState(ny, nx)
     for t in range(nt):
         fld.timeIndex = t
