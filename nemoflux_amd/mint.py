@@ -42,8 +42,11 @@ class Grid(object):
         return g
 
     def __del__(self):
-        if getattr(self, '_owner', False) and self.obj:
-            lib.mnt_grid_del(ctypes.byref(self.obj))
+        try:      # at interpreter shutdown the module globals may already be gone
+            if getattr(self, '_owner', False) and self.obj:
+                lib.mnt_grid_del(ctypes.byref(self.obj))
+        except Exception:
+            pass
 
     def setPoints(self, points):
         """points: float64 (ncell, 4, 3), C-contiguous; BORROWED like in mint (kept alive on self)."""
@@ -73,8 +76,11 @@ class PolylineIntegral(object):
         check(lib.mnt_polylineintegral_new(ctypes.byref(self.obj)))
 
     def __del__(self):
-        if self.obj:
-            lib.mnt_polylineintegral_del(ctypes.byref(self.obj))
+        try:
+            if self.obj:
+                lib.mnt_polylineintegral_del(ctypes.byref(self.obj))
+        except Exception:
+            pass
 
     def setGrid(self, grid):
         self.grid = grid  # keep the grid (and its borrowed points) alive
@@ -148,8 +154,11 @@ class VectorInterp(object):
         check(lib.mnt_vectorinterp_new(ctypes.byref(self.obj)))
 
     def __del__(self):
-        if self.obj:
-            lib.mnt_vectorinterp_del(ctypes.byref(self.obj))
+        try:
+            if self.obj:
+                lib.mnt_vectorinterp_del(ctypes.byref(self.obj))
+        except Exception:
+            pass
 
     def setGrid(self, grid):
         self.grid = grid

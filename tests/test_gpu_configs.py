@@ -250,7 +250,7 @@ def test_slab_sharding_sums_to_full(world):
 
 def test_transect_edge_cases(oracle):
     """outside the grid -> no weights; regional (non-periodic) grid; counterclock flips edges 2,3; a polyline that
-    runs along grid lines only (every sub-segment shared by two cells)."""
+    runs along grid lines only (every sub-segment shared by two cells); repeated points (zero-length segments drop out)."""
     from nemoflux_amd import mint
     g = load_golden('cossin36')
     # regional grid: the western third of the 36x18 mesh, lon in [-180,-60]
@@ -262,7 +262,9 @@ def test_transect_edge_cases(oracle):
     for periodX in (0., 360.):
         for xyz_s, cc in [("(10,-50),(100,40)", False), ("(-170,-45),(-75,33),(-100,60)", False),
                           ("(-170,-45),(-75,33),(-100,60)", True), ("(-160,-40),(-100,-40),(-100,20)", False),
-                          ("(-200,0),(-30,0)", False)]:
+                          ("(-200,0),(-30,0)", False),
+                          ("(-170,-45),(-170,-45),(-75,33),(-75,33)", False),     # repeated points: zero-length segments
+                          ("(-100,20),(-100,20)", False)]:                         # ... and nothing else
             xyz = transect_xyz(xyz_s)
             pli = mint.PolylineIntegral()
             pli.setGrid(grid)
