@@ -9,9 +9,12 @@ parses exactly that subset of the HDF5 file format (HDF5 File Format Specificati
   * object headers version 1 and version 2 (with continuation blocks);
   * groups: old style (symbol table: v1 B-tree + local heap + SNOD nodes), new style with compact links (Link
     messages) and with dense links (fractal heap whose root is a direct block or a one-level indirect block);
-  * datasets: IEEE float / integer datatypes of either byte order; contiguous, compact and chunked (v1 B-tree index,
-    layout message v3; layout v4 "single chunk" / "implicit" / contiguous) storage; deflate and shuffle filters;
-  * attributes stored in the object header (scalars / small arrays such as _FillValue).
+  * datasets: IEEE float / integer datatypes of either byte order; contiguous, compact and chunked storage -- layout
+    message v3 with the v1 B-tree chunk index (what netCDF-4 / XIOS write), layout v4 ("latest" format) with the
+    single-chunk, implicit, fixed-array and extensible-array indexes (paged blocks included; a version-2 B-tree index,
+    i.e. two unlimited dimensions, is refused); deflate, shuffle and fletcher32 filters; never-written chunks read as
+    the fill value; the chunks of a read are inflated on all host cores;
+  * attributes in the object header or in dense storage (fractal heap + name-index B-tree), e.g. _FillValue, units.
 
 Contiguous little-endian data is returned as a numpy memmap of the file itself -- no copy: handing such an array to
 Field makes the engine stage each time step from the page cache straight to HBM.  Anything this reader does not
@@ -122,7 +125,13 @@ class Dataset(object):
         shape = self.shape if lead is None else (1,) + self.shape[1:]
         nbytes = int(numpy.prod(cshape)) * self.dtype.itemsize
         if getattr(self, '_chunks', None) is None:
-            self._chunks = [single] if single is not None else list(self._h5._chunk_btree(btree, rank))
+            if single is not None:
+                self._chunks = [single]
+            elif isinstance(btree, tuple):      # layout version 4 indexes
+                self._chunks = list(self._h5._chunk_index_v4(btree[0], btree[1], self.shape, cshape, nbytes,
+                                                             btree[2] if len(btree) > 2 else None))
+            else:
+                self._chunks = list(self._h5._chunk_btree(btree, rank))
         todo = [c for c in self._chunks if c[3] != UNDEF and
                 (lead is None or c[0][0] <= lead < c[0][0] + cshape[0])]
         expected = int(numpy.prod([-(-s // c) for s, c in zip(shape, cshape)]))
@@ -288,6 +297,15 @@ class File(object):
         q += 8 if ver == 1 else 4
         return [self._len(q + i * self._L) for i in range(rank)]
 
+    def _unlimited_dims(self, q):
+        """Indices of the dimensions whose maximum size is unlimited (needed by the extensible-array chunk index)."""
+        m = self._m
+        ver, rank, flags = m[q], m[q + 1], m[q + 2]
+        if not flags & 1:
+            return []
+        q += (8 if ver == 1 else 4) + rank * self._L
+        return [i for i in range(rank) if self._len(q + i * self._L) == UNDEF]
+
     def _datatype(self, q):
         """numpy dtype and the encoded size of the message."""
         m = self._m
@@ -343,7 +361,14 @@ class File(object):
                     if size is None:
                         size = int(numpy.prod(dims[:-1])) * dims[-1]
                     return ('chunked', None, dims, ((0,) * (nd - 1), size, mask, addr))
-                raise Hdf5Error(f'unsupported chunk index type {itype} (HDF5 1.10 "latest" format)')
+                if itype == 2:    # implicit: unfiltered chunks laid out back to back in row-major chunk order
+                    return ('chunked', ('implicit', self._addr(p)), dims, None)
+                if itype == 3:    # fixed array (no unlimited dimension); one byte of creation parameters (page bits)
+                    return ('chunked', ('farray', self._addr(p + 1)), dims, None)
+                if itype == 4:    # extensible array (one unlimited dimension); five bytes of creation parameters
+                    return ('chunked', ('earray', self._addr(p + 5)), dims, None)
+                names = {5: 'version-2 B-tree'}
+                raise Hdf5Error(f'unsupported chunk index: {names.get(itype, itype)} (HDF5 1.10 "latest" format)')
         raise Hdf5Error(f'unsupported data layout message (version {ver})')
 
     def _filters(self, q):
@@ -425,6 +450,11 @@ class File(object):
                 shape = self._dataspace(info[0x01][0])
                 dt, _ = self._datatype(info[0x03][0])
                 layout = self._layout(info[0x08][0])
+                if layout[0] == 'chunked' and isinstance(layout[1], tuple) and layout[1][0] == 'earray':
+                    unl = self._unlimited_dims(info[0x01][0])
+                    if len(unl) != 1:
+                        raise Hdf5Error('extensible-array chunk index without exactly one unlimited dimension')
+                    layout = ('chunked', ('earray', layout[1][1], unl[0]), layout[2], None)
                 filters = self._filters(info[0x0b][0]) if 0x0b in info else []
             except Hdf5Error as e:
                 self.datasets[prefix + name] = e     # reported when the variable is asked for
@@ -639,6 +669,11 @@ class File(object):
                 yield it[0]
                 q0 += it[1]
 
+    def _chunk_index_v4(self, kind, addr, shape, cshape, nbytes, unlimited=None):
+        if kind == 'earray':
+            return _chunk_index_earray(self, addr, shape, cshape, nbytes, unlimited)
+        return _chunk_index_v4_impl(self, kind, addr, shape, cshape, nbytes)
+
     def _chunk_btree(self, addr, rank):
         m = self._m
         if addr == UNDEF:
@@ -658,6 +693,182 @@ class File(object):
                 yield offs, size, mask, child
             else:
                 yield from self._chunk_btree(child, rank)
+
+
+def _chunk_index_v4_impl(h5, kind, addr, shape, cshape, nbytes):
+    m, O = h5._m, h5._O
+    grid = [-(-s // c) for s, c in zip(shape, cshape)]
+    nchunks = int(numpy.prod(grid))
+
+    def offs_of(k):     # chunk number -> element offsets: row-major over the chunk grid
+        o = []
+        for g, c in zip(reversed(grid), reversed(cshape)):
+            o.append((k % g) * c)
+            k //= g
+        return tuple(reversed(o))
+
+    if addr == UNDEF:
+        return
+    if kind == 'implicit':
+        for k in range(nchunks):
+            yield offs_of(k), nbytes, 0, addr + k * nbytes
+        return
+    # ---- fixed array: header FAHD -> data block FADB (optionally paged)
+    p = h5._base + addr
+    if m[p:p + 4] != b'FAHD' or m[p + 4] != 0:
+        raise Hdf5Error('bad fixed-array header')
+    client, esize, page_bits = m[p + 5], m[p + 6], m[p + 7]
+    nelm = h5._len(p + 8)
+    dblk = h5._addr(p + 8 + h5._L)
+    if dblk == UNDEF:
+        return
+    if nelm < nchunks or client not in (0, 1):
+        raise Hdf5Error('fixed-array index does not match the dataset')
+    q = h5._base + dblk
+    if m[q:q + 4] != b'FADB' or m[q + 4] != 0:
+        raise Hdf5Error('bad fixed-array data block')
+    q += 6 + O                                   # signature, version, client id, header address
+    szlen = esize - O - 4                        # filtered chunks: address, chunk size (szlen bytes), filter mask
+
+    def element(r):
+        a = h5._addr(r)
+        if client == 1:
+            return h5._u(r + O, szlen), h5._u(r + O + szlen, 4), a
+        return nbytes, 0, a
+
+    page_n = 1 << page_bits
+    if nelm <= page_n:                           # one un-paged block: elements, checksum
+        for k in range(nchunks):
+            size, mask, a = element(q + k * esize)
+            yield offs_of(k), size, mask, a
+        return
+    npages = -(-nelm // page_n)
+    bitmap = q
+    q += (npages + 7) // 8 + 4                   # page-initialised bitmap, checksum of the prefix
+    for pg in range(npages):
+        n_in = min(page_n, nelm - pg * page_n)
+        if m[bitmap + pg // 8] & (0x80 >> (pg % 8)):    # most significant bit first; untouched pages hold no chunks
+            for e in range(n_in):
+                k = pg * page_n + e
+                if k < nchunks:
+                    size, mask, a = element(q + e * esize)
+                    yield offs_of(k), size, mask, a
+        q += n_in * esize + 4                    # every page carries its own checksum
+
+
+def _chunk_index_earray(h5, addr, shape, cshape, nbytes, unlimited):
+    """Extensible-array chunk index (HDF5 1.10 'latest' files, one unlimited dimension): header EAHD -> index block EAIB
+    (first elements, data-block and super-block addresses) -> super blocks EASB -> data blocks EADB (paged when large).
+    Chunks are numbered row-major with the unlimited dimension moved to the front."""
+    m, O, base = h5._m, h5._O, h5._base
+    if addr == UNDEF:
+        return
+    p = base + addr
+    if m[p:p + 4] != b'EAHD' or m[p + 4] != 0:
+        raise Hdf5Error('bad extensible-array header')
+    client, esize, max_bits, idx_elmts, dmin, sbmin, page_bits = (m[p + 5 + i] for i in range(7))
+    iblk = h5._addr(p + 12 + 6 * h5._L)
+    if client not in (0, 1) or dmin == 0 or sbmin == 0 or dmin & (dmin - 1) or sbmin & (sbmin - 1):
+        raise Hdf5Error('unsupported extensible-array parameters')
+    if iblk == UNDEF:
+        return
+    log2 = lambda v: v.bit_length() - 1
+    nsblks = 1 + (max_bits - log2(dmin))
+    off_size = (max_bits + 7) // 8
+    page_n = 1 << page_bits
+    sb_ndblks = [1 << (u // 2) for u in range(nsblks)]
+    sb_dnelm = [(1 << ((u + 1) // 2)) * dmin for u in range(nsblks)]
+    sb_start_idx, sb_start_dblk, a, b = [], [], 0, 0
+    for u in range(nsblks):
+        sb_start_idx.append(a)
+        sb_start_dblk.append(b)
+        a += sb_ndblks[u] * sb_dnelm[u]
+        b += sb_ndblks[u]
+    ib_nsblks = 2 * log2(sbmin)
+    ndblk_addrs = 2 * (sbmin - 1)
+    szlen = esize - O - 4
+
+    q = base + iblk
+    if m[q:q + 4] != b'EAIB' or m[q + 4] != 0:
+        raise Hdf5Error('bad extensible-array index block')
+    ib_elems = q + 6 + O
+    ib_dblks = ib_elems + idx_elmts * esize
+    ib_sblks = ib_dblks + ndblk_addrs * O
+
+    def element(r):
+        a_ = h5._addr(r)
+        if client == 1:
+            return h5._u(r + O, szlen), h5._u(r + O + szlen, 4), a_
+        return nbytes, 0, a_
+
+    sblock_cache = {}
+
+    def sblock(u):      # (address of the data-block address table, address of the page bitmaps or None)
+        if u not in sblock_cache:
+            sa = h5._addr(ib_sblks + (u - ib_nsblks) * O)
+            if sa == UNDEF:
+                sblock_cache[u] = None
+            else:
+                r = base + sa
+                if m[r:r + 4] != b'EASB' or m[r + 4] != 0:
+                    raise Hdf5Error('bad extensible-array super block')
+                r += 6 + O + off_size
+                bitmaps = None
+                if sb_dnelm[u] > page_n:
+                    # ONE bit array for the whole super block, bit (data block * pages per block + page), most significant
+                    # bit first; its allocated size rounds every data block up to whole bytes
+                    npages = sb_dnelm[u] // page_n
+                    bitmaps = (r, npages)
+                    r += sb_ndblks[u] * ((npages + 7) // 8)
+                sblock_cache[u] = (r, bitmaps)
+        return sblock_cache[u]
+
+    def lookup(idx):    # -> (size, mask, addr) or None when the element was never written
+        if idx < idx_elmts:
+            return element(ib_elems + idx * esize)
+        e = idx - idx_elmts
+        u = log2(e // dmin + 1)
+        e -= sb_start_idx[u]
+        d, within = divmod(e, sb_dnelm[u])
+        bitmaps = None
+        if u < ib_nsblks:
+            da = h5._addr(ib_dblks + (sb_start_dblk[u] + d) * O)
+        else:
+            sb = sblock(u)
+            if sb is None:
+                return None
+            da = h5._addr(sb[0] + d * O)
+            bitmaps = sb[1]
+        if da == UNDEF:
+            return None
+        r = base + da
+        if m[r:r + 4] != b'EADB' or m[r + 4] != 0:
+            raise Hdf5Error('bad extensible-array data block')
+        r += 6 + O + off_size
+        if sb_dnelm[u] > page_n:      # paged: prefix checksum, then pages of page_n elements each with its own checksum
+            pg, within = divmod(within, page_n)
+            if bitmaps is not None:
+                bit = d * bitmaps[1] + pg
+                if not m[bitmaps[0] + bit // 8] & (0x80 >> (bit % 8)):
+                    return None
+            r += 4 + pg * (page_n * esize + 4)
+        return element(r + within * esize)
+
+    # chunk numbering: row-major with the unlimited dimension swizzled to the front
+    rank = len(shape)
+    grid = [-(-s_ // c) for s_, c in zip(shape, cshape)]
+    order = [unlimited] + [i for i in range(rank) if i != unlimited]
+    sgrid = [grid[i] for i in order]
+    nchunks = int(numpy.prod(grid))
+    for k in range(nchunks):
+        got = lookup(k)
+        if got is None or got[2] == UNDEF:
+            continue
+        coords, kk = [0] * rank, k
+        for pos in range(rank - 1, -1, -1):
+            coords[order[pos]] = (kk % sgrid[pos]) * cshape[order[pos]]
+            kk //= sgrid[pos]
+        yield tuple(coords), got[0], got[1], got[2]
 
 
 def read_variables(path, wanted=None):

@@ -9,7 +9,9 @@ The files cover the HDF5 structures netCDF-4 / XIOS / h5py produce for NEMO-like
                     big-endian f4, int32, compact storage, _FillValue attributes
   new_compact.h5    creation-order tracking: v2 object headers, compact Link messages
   new_dense.h5      > 8 links and > 8 attributes: fractal-heap (dense) link and attribute storage, fletcher32
-  latest.h5         libver latest: superblock v3, layout message v4 (single-chunk index; other indexes unsupported)
+  latest.h5         libver latest: superblock v3, layout message v4: single-chunk, implicit and fixed-array chunk indexes
+                    (plain, filtered, paged, partly written), extensible-array indexes (one unlimited dimension); a
+                    version-2 B-tree one (two unlimited dimensions) that the reader must refuse
 """
 import os
 import sys
@@ -28,7 +30,19 @@ def field(shape, dtype, seed):
     return a.reshape(shape).astype(dtype)
 
 
+def big_extensible(path):
+    """140 000 + 600 000 one-element chunks: data blocks of the extensible array become PAGED beyond 131 060 elements
+    (too large to commit: tests/test_hdf5min.py writes it to a temporary directory when an h5py interpreter exists)."""
+    with h5py.File(path, 'w', libver='latest') as f:
+        f.create_dataset('big', data=numpy.arange(140000, dtype='<f4').reshape(140000, 1), chunks=(1, 1), maxshape=(None, 1))
+        d = f.create_dataset('big_sparse', shape=(600000, 1), dtype='<f4', chunks=(1, 1), maxshape=(None, 1), fillvalue=-7.0)
+        for i, x in ((135000, 1.5), (199999, 2.5), (3, 3.5), (599999, 4.5), (300000, 5.5)):
+            d[i] = x
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == '--big-extensible':
+        return big_extensible(sys.argv[2])
     os.makedirs(OUT, exist_ok=True)
     with h5py.File(os.path.join(OUT, 'old_style.h5'), 'w', libver='earliest') as f:
         f.create_dataset('bounds_lon', data=field((5, 7, 4), '<f8', 1))
@@ -63,7 +77,30 @@ def main():
     with h5py.File(os.path.join(OUT, 'latest.h5'), 'w', libver='latest') as f:
         f.create_dataset('contig', data=field((6, 5), '<f8', 40))
         f.create_dataset('single_chunk', data=field((6, 5), '<f4', 41), chunks=(6, 5), compression='gzip')
-        f.create_dataset('many_chunks', data=field((6, 5), '<f4', 42), chunks=(2, 5))
+        f.create_dataset('many_chunks', data=field((6, 5), '<f4', 42), chunks=(2, 5))                 # fixed array
+        f.create_dataset('fa_filtered', data=field((3, 2, 9, 7), '<f4', 43), chunks=(1, 1, 4, 7),       # fixed array of
+                         compression='gzip', shuffle=True)                                              # filtered chunks
+        f.create_dataset('fa_paged', data=field((40, 60), '<f8', 44), chunks=(1, 2))                    # 1200 > 1024 elements
+        d = f.create_dataset('fa_paged_sparse', shape=(40, 60), dtype='<f8', chunks=(1, 2), fillvalue=-1.5)
+        d[39, 58:60] = field((2,), '<f8', 45)                                                           # only the last page
+        # chunks allocated at creation, no filter -> implicit index (low-level API: the high-level one cannot ask for it)
+        dcpl = h5py.h5p.create(h5py.h5p.DATASET_CREATE)
+        dcpl.set_chunk((2, 5))
+        dcpl.set_alloc_time(h5py.h5d.ALLOC_TIME_EARLY)
+        dsid = h5py.h5d.create(f.id, b'implicit', h5py.h5t.IEEE_F32LE, h5py.h5s.create_simple((6, 5)), dcpl)
+        dsid.write(h5py.h5s.ALL, h5py.h5s.ALL, field((6, 5), '<f4', 46))
+        # one unlimited dimension -> extensible-array index: within the index block, through data blocks, through super
+        # blocks, filtered, unlimited dimension not first (chunk numbering swizzled), partly written
+        f.create_dataset('ea4', data=field((4, 3), '<f4', 47), chunks=(1, 3), maxshape=(None, 3))
+        f.create_dataset('ea100', data=field((100, 3), '<f4', 48), chunks=(1, 3), maxshape=(None, 3))
+        f.create_dataset('ea3000', data=field((3000, 2), '<f4', 49), chunks=(1, 2), maxshape=(None, 2))
+        f.create_dataset('ea_filt', data=field((50, 4, 6), '<f4', 50), chunks=(1, 2, 6), maxshape=(None, 4, 6),
+                         compression='gzip', shuffle=True)
+        f.create_dataset('ea_mid', data=field((5, 30, 4), '<f4', 51), chunks=(2, 1, 4), maxshape=(5, None, 4))
+        d = f.create_dataset('ea_sparse', shape=(5000, 2), dtype='<f8', chunks=(1, 2), maxshape=(None, 2), fillvalue=-2.5)
+        d[4321] = [1.0, 2.0]
+        d[7] = [3.0, 4.0]
+        f.create_dataset('two_unlimited', data=field((4, 3), '<f4', 52), chunks=(1, 3), maxshape=(None, None))  # v2 B-tree
     # a NEMO-like T/U/V triple built from the golden case def36_zt (reference datagen output), the way XIOS/netCDF-4
     # writes it: float32, uo chunked + shuffled + deflated with land as _FillValue, vo contiguous with NaN land
     g = numpy.load(os.path.join(OUT, '..', 'def36_zt.npz'))

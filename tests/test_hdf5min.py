@@ -25,7 +25,10 @@ EXPECTED = {
                   'sub/inner': ((2, 2), '<f8', 7), 'planes': ((2, 3, 4, 6), '<f4', 50)},
     'new_compact': {'bounds_lat': ((5, 7, 4), '<f4', 8), 'deptht_bounds': ((75, 2), '<f4', 9)},
     'new_dense': dict([(f'var{k:02d}', ((4, 3), '<f8', 10 + k)) for k in range(14)] + [('vo', ((2, 3, 8, 6), '<f4', 30))]),
-    'latest': {'contig': ((6, 5), '<f8', 40), 'single_chunk': ((6, 5), '<f4', 41)},
+    'latest': {'contig': ((6, 5), '<f8', 40), 'single_chunk': ((6, 5), '<f4', 41), 'many_chunks': ((6, 5), '<f4', 42),
+               'fa_filtered': ((3, 2, 9, 7), '<f4', 43), 'fa_paged': ((40, 60), '<f8', 44), 'implicit': ((6, 5), '<f4', 46),
+               'ea4': ((4, 3), '<f4', 47), 'ea100': ((100, 3), '<f4', 48), 'ea3000': ((3000, 2), '<f4', 49),
+               'ea_filt': ((50, 4, 6), '<f4', 50), 'ea_mid': ((5, 30, 4), '<f4', 51)},
 }
 
 
@@ -58,9 +61,16 @@ def test_fill_values_attributes_and_storage_kinds():
     # > 8 attributes -> dense (fractal heap + v2 B-tree) storage, _FillValue created through a rename
     d = hdf5min.File(os.path.join(H5, 'new_dense.h5')).datasets['vo']
     assert d.fill_value == numpy.float32(1.e20)
-    # HDF5 1.10 "latest" chunk indexes other than single-chunk are refused, never guessed
+    # HDF5 1.10 "latest" chunk indexes: single chunk, implicit, fixed array (plain, filtered, paged) and extensible array
+    # (one unlimited dimension) are read; a version-2 B-tree (two unlimited dimensions) is refused, never guessed
     g = hdf5min.File(os.path.join(H5, 'latest.h5'))
-    assert isinstance(g.datasets['many_chunks'], hdf5min.Hdf5Error)
+    assert isinstance(g.datasets['two_unlimited'], hdf5min.Hdf5Error) and 'B-tree' in str(g.datasets['two_unlimited'])
+    sparse = numpy.full((40, 60), -1.5)
+    sparse[39, 58:60] = field((2,), '<f8', 45)
+    assert numpy.array_equal(g.datasets['fa_paged_sparse'].read(), sparse)     # untouched pages read as the fill value
+    sparse = numpy.full((5000, 2), -2.5)
+    sparse[4321], sparse[7] = [1.0, 2.0], [3.0, 4.0]
+    assert numpy.array_equal(g.datasets['ea_sparse'].read(), sparse)
     with pytest.raises(hdf5min.Hdf5Error):
         hdf5min.read_variables(os.path.join(H5, 'latest.h5'))
     with pytest.raises(hdf5min.Hdf5Error, match='not an HDF5 file'):
@@ -196,3 +206,21 @@ def test_netcdf_classic_files_through_io(tmp_path, version):
     vo, vfill = io.open_uvfile(paths['V'], 'vo')
     assert numpy.isnan(vfill) and numpy.array_equal(vo.read_step(1), v[1], equal_nan=True)
     assert TimeObj.fromVariables(d).getTimeAsString(1) == '1900-2-15'
+
+
+def test_paged_extensible_array_blocks(tmp_path):
+    """Beyond 131 060 chunks the data blocks of an extensible-array index are paged (one bit per page in the super block).
+    The file is too large to commit: it is written here by oracle/gen_hdf5_fixtures.py under an interpreter with h5py."""
+    import subprocess
+    from nemoflux_amd import hdf5min
+    py = '/opt/conda/bin/python3.9'
+    path = str(tmp_path / 'big.h5')
+    gen = os.path.join(os.path.dirname(GOLDEN), '..', 'oracle', 'gen_hdf5_fixtures.py')
+    if not os.path.exists(py) or subprocess.run([py, gen, '--big-extensible', path], capture_output=True).returncode != 0:
+        pytest.skip('no interpreter with h5py')
+    with hdf5min.File(path) as f:
+        assert numpy.array_equal(f.datasets['big'].read()[:, 0], numpy.arange(140000, dtype=numpy.float32))
+        want = numpy.full((600000, 1), -7.0, numpy.float32)
+        for i, x in ((135000, 1.5), (199999, 2.5), (3, 3.5), (599999, 4.5), (300000, 5.5)):
+            want[i] = x
+        assert numpy.array_equal(f.datasets['big_sparse'].read(), want)
