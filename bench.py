@@ -140,7 +140,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    nlaunch, kernel_ms = fld.readKernelTiming()
+    nlaunch, kernel_ms, flux_ms, expand_ms = fld.readKernelTiming(split=True)
     fld.enableKernelTiming(False)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
@@ -180,6 +180,8 @@ def main():
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'kernel': 'nf::k_flux' if args.compact else 'nf::k_flux + nf::k_expand_planes (one event pair around both)',
                 'avg_launch_ms': round(avg_ms, 4), 'launches': nlaunch,
+                'avg_ms_by_kernel': {'nf::k_flux': round(flux_ms / max(1, nlaunch), 4),
+                                     'nf::k_expand_planes': round(expand_ms / max(1, nlaunch), 4)},
                 'algorithmic_bytes_per_unit': round(bytes_per_unit, 3)}
 
     out = {

@@ -191,6 +191,8 @@ int nf_field_grid(nf_field **self, Grid_t **grid);
  * (bench.py's roofline leg): enable, run, then read (launch count, total ms). */
 int nf_field_timing(nf_field **self, int enable);
 int nf_field_timing_read(nf_field **self, long *launches, double *total_ms);
+/* how the total of the last nf_field_timing_read splits between the flux kernel and the expansion kernel behind it */
+int nf_field_timing_split(nf_field **self, double *flux_ms, double *expand_ms);
 
 /* ------------------------------------------------------------------ synthetic data (datagen.py) */
 /* Stream functions offered on device (no eval on the GPU): psi = g(z,t) * h(x,y)

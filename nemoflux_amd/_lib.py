@@ -110,6 +110,7 @@ _sig('nf_field_device_ptr', [_pp, ctypes.c_int, c_void_pp])
 _sig('nf_field_grid', [_pp, _pp])
 _sig('nf_field_timing', [_pp, ctypes.c_int])
 _sig('nf_field_timing_read', [_pp, ctypes.POINTER(ctypes.c_long), c_double_p])
+_sig('nf_field_timing_split', [_pp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)])
 _sig('nf_datagen_bounds', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_long] + [ctypes.c_double] * 6 +
      [ctypes.c_int, ctypes.c_void_p])
 _sig('nf_datagen_uv', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_long] * 6 + [ctypes.c_double] * 6 +

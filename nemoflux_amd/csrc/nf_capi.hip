@@ -637,7 +637,12 @@ struct nf_field {
     Grid_t grid_view;
     // timing
     bool timing = false;
-    std::vector<hipEvent_t> ev;  // pairs
+    struct TimedLaunch {         // events around one flux launch (+ expansion); mid sits between the two kernels
+        hipEvent_t e0 = nullptr, mid = nullptr, e1 = nullptr;
+        bool has_mid = false;
+    };
+    std::vector<TimedLaunch> ev;
+    double last_flux_ms = 0.0, last_expand_ms = 0.0;   // split of the last timing_read
     // hipGraph of one compute_all pass (launch-bound small grids: 4 launches per time step)
     hipGraphExec_t graph_exec = nullptr;
     double *graph_rows = nullptr;
@@ -673,6 +678,35 @@ static int field_free_geometry(nf_field *f)
 }
 
 static int elem_size(int dtype) { return dtype == NF_F32 ? 4 : 8; }
+
+static void field_drop_events(nf_field *f)
+{
+    for (auto &t : f->ev)
+        for (hipEvent_t e : {t.e0, t.mid, t.e1})
+            if (e) (void)hipEventDestroy(e);
+    f->ev.clear();
+}
+
+// one flux launch (and, in the default step, the expansion behind it) bracketed by events on the field's stream
+static int field_timed_flux(nf_field *f, FluxArgs &a)
+{
+    f->ev.emplace_back();          // owned by the field from here on (destroyed by timing_read / del)
+    const size_t k = f->ev.size() - 1;
+    NF_HIP(hipEventCreate(&f->ev[k].e0));
+    NF_HIP(hipEventCreate(&f->ev[k].mid));
+    NF_HIP(hipEventCreate(&f->ev[k].e1));
+    bool mid = false;
+    a.mid_event = f->ev[k].mid;
+    a.mid_recorded = &mid;
+    NF_HIP(hipEventRecord(f->ev[k].e0, f->stream));
+    const int rc = launch_flux(a, f->stream);
+    a.mid_event = nullptr;
+    a.mid_recorded = nullptr;
+    f->ev[k].has_mid = mid;
+    NF_TRY(rc);
+    NF_HIP(hipEventRecord(f->ev[k].e1, f->stream));
+    return NF_OK;
+}
 
 // compact mode: bring planes 0, 3 and the |.| planes up to date with planes 1, 2 of the latest step
 static int field_ensure_derived(nf_field *f)
@@ -742,14 +776,7 @@ static int field_step_async(nf_field *f, long t, double *row_dev)
     a.signed_only = f->compact && flux_supports_signed_only(a);
     f->derived_stale = a.signed_only != 0;
     if (f->timing) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        NF_HIP(hipEventCreate(&e0));
-        f->ev.push_back(e0);   // owned by the field from here on (destroyed by timing_read / del)
-        NF_HIP(hipEventCreate(&e1));
-        f->ev.push_back(e1);
-        NF_HIP(hipEventRecord(e0, f->stream));
-        NF_TRY(launch_flux(a, f->stream));
-        NF_HIP(hipEventRecord(e1, f->stream));
+        NF_TRY(field_timed_flux(f, a));
     } else {
         NF_TRY(launch_flux(a, f->stream));
     }
@@ -851,15 +878,8 @@ static int field_all_steps_batched(nf_field *f, double *rows_dev)
     a.batch.nsteps = (int)f->nt;
     a.batch.in_stride = f->nz * f->ncell;
     a.batch.zr = f->d_zr;
-    if (f->timing) {  // one event pair around the one flux launch of the pass
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        NF_HIP(hipEventCreate(&e0));
-        f->ev.push_back(e0);   // owned by the field from here on (destroyed by timing_read / del)
-        NF_HIP(hipEventCreate(&e1));
-        f->ev.push_back(e1);
-        NF_HIP(hipEventRecord(e0, f->stream));
-        NF_TRY(launch_flux(a, f->stream));
-        NF_HIP(hipEventRecord(e1, f->stream));
+    if (f->timing) {
+        NF_TRY(field_timed_flux(f, a));
     } else {
         NF_TRY(launch_flux(a, f->stream));
     }
@@ -897,7 +917,7 @@ try {
         dev_free(f->d_tr_off);
         dev_free(f->d_scratch);
         dev_free(f->d_row);
-        for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
+        field_drop_events(f);
         field_drop_graph(f);
         delete f;
         *self = nullptr;
@@ -1275,8 +1295,7 @@ int nf_field_timing(nf_field **self, int enable)
 try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_timing: null field");
     nf_field *f = *self;
-    for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
-    f->ev.clear();
+    field_drop_events(f);
     f->timing = enable != 0;
     ++f->version;
     return NF_OK;
@@ -1287,16 +1306,32 @@ try {
     NF_REQUIRE(self && *self && launches && total_ms, NF_ERR_ARG, "nf_field_timing_read: null argument");
     nf_field *f = *self;
     NF_HIP(hipStreamSynchronize(f->stream));
-    double tot = 0.0;
-    for (size_t k = 0; k + 1 < f->ev.size(); k += 2) {
-        float ms = 0.f;
-        NF_HIP(hipEventElapsedTime(&ms, f->ev[k], f->ev[k + 1]));
+    double tot = 0.0, flux = 0.0, expand = 0.0;
+    for (const auto &t : f->ev) {
+        float ms = 0.f, part = 0.f;
+        NF_HIP(hipEventElapsedTime(&ms, t.e0, t.e1));
         tot += ms;
+        if (t.has_mid) {
+            NF_HIP(hipEventElapsedTime(&part, t.e0, t.mid));
+            flux += part;
+            expand += ms - part;
+        } else {
+            flux += ms;
+        }
     }
-    *launches = (long)(f->ev.size() / 2);
+    *launches = (long)f->ev.size();
     *total_ms = tot;
-    for (hipEvent_t e : f->ev) (void)hipEventDestroy(e);
-    f->ev.clear();
+    f->last_flux_ms = flux;
+    f->last_expand_ms = expand;
+    field_drop_events(f);
+    return NF_OK;
+}
+NF_API_CATCH
+int nf_field_timing_split(nf_field **self, double *flux_ms, double *expand_ms)
+try {
+    NF_REQUIRE(self && *self && flux_ms && expand_ms, NF_ERR_ARG, "nf_field_timing_split: null argument");
+    *flux_ms = (*self)->last_flux_ms;
+    *expand_ms = (*self)->last_expand_ms;
     return NF_OK;
 }
 NF_API_CATCH

@@ -73,6 +73,9 @@ struct FluxArgs {
     unsigned long long *maxbits;  // running max as the bits of a non-negative double
     StepBatch batch;
     int signed_only = 0;      // 1: store only planes 1 (eU) and 2 (eV); launch_expand_planes derives the other four
+    // timing: when the default step runs as flux kernel + expansion, mid_event is recorded between the two launches
+    hipEvent_t mid_event = nullptr;
+    bool *mid_recorded = nullptr;
 };
 int launch_flux(const FluxArgs &a, hipStream_t s);
 bool flux_supports_signed_only(const FluxArgs &a);

@@ -554,7 +554,12 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
         default: {  // 10 levels x 2 fields in flight, eU and eV stored; the copies and |.| by the streaming expansion
             if (a.batch.zr) return launch_flux_t<T, VEC, 10, true, 256, 1>(a, s);   // multi-step launch: fused stores
             const int rc = launch_flux_t<T, VEC, 10, true, 256, 1, 16>(a, s);
-            return rc != NF_OK ? rc : launch_expand_planes(a.iV, a.absU, a.ncell, a.ny, a.nx, s);
+            if (rc != NF_OK) return rc;
+            if (a.mid_event) {
+                NF_HIP(hipEventRecord(a.mid_event, s));
+                if (a.mid_recorded) *a.mid_recorded = true;
+            }
+            return launch_expand_planes(a.iV, a.absU, a.ncell, a.ny, a.nx, s);
         }
     }
 }

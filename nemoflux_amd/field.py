@@ -441,7 +441,13 @@ class Field(object):
     def enableKernelTiming(self, on=True):
         check(lib.nf_field_timing(ctypes.byref(self._h), 1 if on else 0))
 
-    def readKernelTiming(self):
+    def readKernelTiming(self, split=False):
+        """(launches, total ms) of the timed steps since enableKernelTiming; split=True appends the flux-kernel and the
+        expansion-kernel shares of that total."""
         n, ms = ctypes.c_long(), ctypes.c_double()
         check(lib.nf_field_timing_read(ctypes.byref(self._h), ctypes.byref(n), ctypes.byref(ms)))
-        return n.value, ms.value
+        if not split:
+            return n.value, ms.value
+        a, b = ctypes.c_double(), ctypes.c_double()
+        check(lib.nf_field_timing_split(ctypes.byref(self._h), ctypes.byref(a), ctypes.byref(b)))
+        return n.value, ms.value, a.value, b.value
