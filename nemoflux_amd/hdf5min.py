@@ -11,8 +11,8 @@ parses exactly that subset of the HDF5 file format (HDF5 File Format Specificati
     messages) and with dense links (fractal heap whose root is a direct block or a one-level indirect block);
   * datasets: IEEE float / integer datatypes of either byte order; contiguous, compact and chunked storage -- layout
     message v3 with the v1 B-tree chunk index (what netCDF-4 / XIOS write), layout v4 ("latest" format) with the
-    single-chunk, implicit, fixed-array and extensible-array indexes (paged blocks included; a version-2 B-tree index,
-    i.e. two unlimited dimensions, is refused); deflate, shuffle and fletcher32 filters; never-written chunks read as
+    single-chunk, implicit, fixed-array, extensible-array (paged blocks included) and version-2 B-tree indexes;
+    deflate, shuffle and fletcher32 filters; never-written chunks read as
     the fill value; the chunks of a read are inflated on all host cores;
   * attributes in the object header or in dense storage (fractal heap + name-index B-tree), e.g. _FillValue, units.
 
@@ -367,8 +367,9 @@ class File(object):
                     return ('chunked', ('farray', self._addr(p + 1)), dims, None)
                 if itype == 4:    # extensible array (one unlimited dimension); five bytes of creation parameters
                     return ('chunked', ('earray', self._addr(p + 5)), dims, None)
-                names = {5: 'version-2 B-tree'}
-                raise Hdf5Error(f'unsupported chunk index: {names.get(itype, itype)} (HDF5 1.10 "latest" format)')
+                if itype == 5:    # version-2 B-tree (two or more unlimited dimensions); six bytes of creation parameters
+                    return ('chunked', ('btree2', self._addr(p + 6)), dims, None)
+                raise Hdf5Error(f'unsupported chunk index type {itype} (HDF5 1.10 "latest" format)')
         raise Hdf5Error(f'unsupported data layout message (version {ver})')
 
     def _filters(self, q):
@@ -672,6 +673,8 @@ class File(object):
     def _chunk_index_v4(self, kind, addr, shape, cshape, nbytes, unlimited=None):
         if kind == 'earray':
             return _chunk_index_earray(self, addr, shape, cshape, nbytes, unlimited)
+        if kind == 'btree2':
+            return _chunk_index_btree2(self, addr, shape, cshape, nbytes)
         return _chunk_index_v4_impl(self, kind, addr, shape, cshape, nbytes)
 
     def _chunk_btree(self, addr, rank):
@@ -869,6 +872,64 @@ def _chunk_index_earray(h5, addr, shape, cshape, nbytes, unlimited):
             coords[order[pos]] = (kk % sgrid[pos]) * cshape[order[pos]]
             kk //= sgrid[pos]
         yield tuple(coords), got[0], got[1], got[2]
+
+
+def _chunk_index_btree2(h5, addr, shape, cshape, nbytes):
+    """Version-2 B-tree chunk index (record types 10 / 11: plain / filtered chunks keyed by their scaled offsets).  The
+    widths of the per-child record counters of the internal nodes follow from the node size, the record size and the
+    depth, as in the HDF5 library."""
+    m, O, base = h5._m, h5._O, h5._base
+    if addr == UNDEF:
+        return
+    p = base + addr
+    if m[p:p + 4] != b'BTHD' or m[p + 4] != 0:
+        raise Hdf5Error('bad version-2 B-tree header')
+    rtype, node_size, rec_size, depth = m[p + 5], h5._u(p + 6, 4), h5._u(p + 10, 2), h5._u(p + 12, 2)
+    root, root_nrec = h5._addr(p + 16), h5._u(p + 16 + O, 2)
+    rank = len(shape)
+    if rtype not in (10, 11):
+        raise Hdf5Error('unsupported version-2 B-tree record type for a chunk index')
+    szlen = rec_size - O - 4 - 8 * rank if rtype == 11 else 0
+    if rtype == 10 and rec_size != O + 8 * rank or rtype == 11 and not (1 <= szlen <= 8):
+        raise Hdf5Error('version-2 B-tree record size does not match the dataset')
+    nbytes_of = lambda v: max(1, (v.bit_length() + 7) // 8)
+    # per level: max records of a node, width of the "records in child" / "records in subtree" counters pointing AT it
+    max_nrec = [(node_size - 10) // rec_size]          # leaf
+    cum_max = [max_nrec[0]]
+    for d in range(1, depth + 1):
+        ptr = O + nbytes_of(max_nrec[d - 1]) + (nbytes_of(cum_max[d - 1]) if d > 1 else 0)
+        max_nrec.append((node_size - 10 - ptr) // (rec_size + ptr))
+        cum_max.append((max_nrec[d] + 1) * cum_max[d - 1] + max_nrec[d])
+
+    def record(r):
+        a = h5._addr(r)
+        if rtype == 11:
+            size, mask, q = h5._u(r + O, szlen), h5._u(r + O + szlen, 4), r + O + szlen + 4
+        else:
+            size, mask, q = nbytes, 0, r + O
+        offs = tuple(h5._u(q + 8 * i, 8) * cshape[i] for i in range(rank))
+        return offs, size, mask, a
+
+    def node(a, nrec, d):
+        r = base + a
+        if m[r:r + 4] != (b'BTIN' if d > 0 else b'BTLF') or m[r + 4] != 0 or m[r + 5] != rtype:
+            raise Hdf5Error('bad version-2 B-tree node')
+        recs = r + 6
+        for i in range(nrec):
+            yield record(recs + i * rec_size)
+        if d > 0:
+            q = recs + nrec * rec_size
+            w1 = nbytes_of(max_nrec[d - 1])
+            w2 = nbytes_of(cum_max[d - 1]) if d > 1 else 0
+            for i in range(nrec + 1):
+                child, cn = h5._addr(q), h5._u(q + O, w1)
+                q += O + w1 + w2
+                yield from node(child, cn, d - 1)
+
+    if root != UNDEF:
+        for offs, size, mask, a in node(root, root_nrec, depth):
+            if a != UNDEF:
+                yield offs, size, mask, a
 
 
 def read_variables(path, wanted=None):

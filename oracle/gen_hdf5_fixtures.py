@@ -10,8 +10,8 @@ The files cover the HDF5 structures netCDF-4 / XIOS / h5py produce for NEMO-like
   new_compact.h5    creation-order tracking: v2 object headers, compact Link messages
   new_dense.h5      > 8 links and > 8 attributes: fractal-heap (dense) link and attribute storage, fletcher32
   latest.h5         libver latest: superblock v3, layout message v4: single-chunk, implicit and fixed-array chunk indexes
-                    (plain, filtered, paged, partly written), extensible-array indexes (one unlimited dimension); a
-                    version-2 B-tree one (two unlimited dimensions) that the reader must refuse
+                    (plain, filtered, paged, partly written), extensible-array indexes (one unlimited dimension) and
+                    version-2 B-tree indexes (two unlimited dimensions; depth 0, 1 and 2)
 """
 import os
 import sys
@@ -100,7 +100,15 @@ def main():
         d = f.create_dataset('ea_sparse', shape=(5000, 2), dtype='<f8', chunks=(1, 2), maxshape=(None, 2), fillvalue=-2.5)
         d[4321] = [1.0, 2.0]
         d[7] = [3.0, 4.0]
-        f.create_dataset('two_unlimited', data=field((4, 3), '<f4', 52), chunks=(1, 3), maxshape=(None, None))  # v2 B-tree
+        # two unlimited dimensions -> version-2 B-tree index: root leaf, depth 1, depth 2, filtered, partly written
+        f.create_dataset('bt2_small', data=field((4, 3), '<f4', 52), chunks=(1, 3), maxshape=(None, None))
+        f.create_dataset('bt2_d1', data=field((30, 40), '<f4', 53), chunks=(1, 2), maxshape=(None, None))
+        f.create_dataset('bt2_d2', data=field((100, 160), '<f4', 54), chunks=(1, 2), maxshape=(None, None))
+        f.create_dataset('bt2_filt', data=field((20, 6, 8), '<f4', 55), chunks=(1, 3, 8), maxshape=(None, None, 8),
+                         compression='gzip', shuffle=True)
+        d = f.create_dataset('bt2_sparse', shape=(50, 50), dtype='<f8', chunks=(5, 5), maxshape=(None, None), fillvalue=9.5)
+        d[47, 3] = 1.0
+        d[0, 49] = 2.0
     # a NEMO-like T/U/V triple built from the golden case def36_zt (reference datagen output), the way XIOS/netCDF-4
     # writes it: float32, uo chunked + shuffled + deflated with land as _FillValue, vo contiguous with NaN land
     g = numpy.load(os.path.join(OUT, '..', 'def36_zt.npz'))

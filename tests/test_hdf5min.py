@@ -28,7 +28,9 @@ EXPECTED = {
     'latest': {'contig': ((6, 5), '<f8', 40), 'single_chunk': ((6, 5), '<f4', 41), 'many_chunks': ((6, 5), '<f4', 42),
                'fa_filtered': ((3, 2, 9, 7), '<f4', 43), 'fa_paged': ((40, 60), '<f8', 44), 'implicit': ((6, 5), '<f4', 46),
                'ea4': ((4, 3), '<f4', 47), 'ea100': ((100, 3), '<f4', 48), 'ea3000': ((3000, 2), '<f4', 49),
-               'ea_filt': ((50, 4, 6), '<f4', 50), 'ea_mid': ((5, 30, 4), '<f4', 51)},
+               'ea_filt': ((50, 4, 6), '<f4', 50), 'ea_mid': ((5, 30, 4), '<f4', 51),
+               'bt2_small': ((4, 3), '<f4', 52), 'bt2_d1': ((30, 40), '<f4', 53), 'bt2_d2': ((100, 160), '<f4', 54),
+               'bt2_filt': ((20, 6, 8), '<f4', 55)},
 }
 
 
@@ -61,18 +63,19 @@ def test_fill_values_attributes_and_storage_kinds():
     # > 8 attributes -> dense (fractal heap + v2 B-tree) storage, _FillValue created through a rename
     d = hdf5min.File(os.path.join(H5, 'new_dense.h5')).datasets['vo']
     assert d.fill_value == numpy.float32(1.e20)
-    # HDF5 1.10 "latest" chunk indexes: single chunk, implicit, fixed array (plain, filtered, paged) and extensible array
-    # (one unlimited dimension) are read; a version-2 B-tree (two unlimited dimensions) is refused, never guessed
+    # HDF5 1.10 "latest" chunk indexes: single chunk, implicit, fixed array (plain, filtered, paged), extensible array (one
+    # unlimited dimension) and version-2 B-tree (two); never-written chunks / pages read as the fill value
     g = hdf5min.File(os.path.join(H5, 'latest.h5'))
-    assert isinstance(g.datasets['two_unlimited'], hdf5min.Hdf5Error) and 'B-tree' in str(g.datasets['two_unlimited'])
     sparse = numpy.full((40, 60), -1.5)
     sparse[39, 58:60] = field((2,), '<f8', 45)
-    assert numpy.array_equal(g.datasets['fa_paged_sparse'].read(), sparse)     # untouched pages read as the fill value
+    assert numpy.array_equal(g.datasets['fa_paged_sparse'].read(), sparse)
     sparse = numpy.full((5000, 2), -2.5)
     sparse[4321], sparse[7] = [1.0, 2.0], [3.0, 4.0]
     assert numpy.array_equal(g.datasets['ea_sparse'].read(), sparse)
-    with pytest.raises(hdf5min.Hdf5Error):
-        hdf5min.read_variables(os.path.join(H5, 'latest.h5'))
+    sparse = numpy.full((50, 50), 9.5)
+    sparse[47, 3], sparse[0, 49] = 1.0, 2.0
+    assert numpy.array_equal(g.datasets['bt2_sparse'].read(), sparse)
+    assert not [k for k, v in g.datasets.items() if isinstance(v, hdf5min.Hdf5Error)]     # nothing in the file is refused
     with pytest.raises(hdf5min.Hdf5Error, match='not an HDF5 file'):
         hdf5min.File(os.path.join(GOLDEN, 'cases.json'))
 
