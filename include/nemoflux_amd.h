@@ -62,6 +62,8 @@ int nf_memcpy_h2d(void *dev, const void *host, size_t bytes);
 int nf_memcpy_d2h(void *host, const void *dev, size_t bytes);
 int nf_memset(void *dev, int value, size_t bytes);
 int nf_synchronize(void);
+/* host-side file decoding helper: undo HDF5's shuffle filter (es byte planes of n elements -> n elements) */
+int nf_host_unshuffle(const void *src, void *dst, size_t n, int es);
 /* tuning knobs for A/B measurements inside one process: "flux_variant" (0 = default; see nf_flux.hip),
  * "xcd_map" (1 = on), "ww_blocks_per_cu", "batch_steps" (1 = small grids run all time steps in one launch) */
 int nf_tuning_set(const char *name, int value);

@@ -1336,6 +1336,32 @@ try {
 }
 NF_API_CATCH
 
+// ------------------------------------------------------------------------------------------- file decode helper
+// Inverse of HDF5's shuffle filter on the HOST (file decoding, like zlib's inflate next to it -- not a compute path):
+// src holds the es byte planes of n elements one after the other, dst receives the n elements.  Called by
+// nemoflux_amd/hdf5min.py from its inflate threads (ctypes releases the GIL); ten times faster than numpy's strided copies.
+int nf_host_unshuffle(const void *src, void *dst, size_t n, int es)
+try {
+    NF_REQUIRE(src && dst && es > 0 && es <= 16, NF_ERR_ARG, "nf_host_unshuffle: bad arguments");
+    const unsigned char *s = (const unsigned char *)src;
+    unsigned char *d = (unsigned char *)dst;
+    if (es == 4) {
+        const unsigned char *p0 = s, *p1 = s + n, *p2 = s + 2 * n, *p3 = s + 3 * n;
+        uint32_t *o = (uint32_t *)d;
+        if (((uintptr_t)d & 3) == 0) {
+            for (size_t i = 0; i < n; ++i)
+                o[i] = (uint32_t)p0[i] | ((uint32_t)p1[i] << 8) | ((uint32_t)p2[i] << 16) | ((uint32_t)p3[i] << 24);
+            return NF_OK;
+        }
+    }
+    for (int j = 0; j < es; ++j) {
+        const unsigned char *pj = s + (size_t)j * n;
+        for (size_t i = 0; i < n; ++i) d[i * es + j] = pj[i];
+    }
+    return NF_OK;
+}
+NF_API_CATCH
+
 // ------------------------------------------------------------------------------------------- datagen
 int nf_datagen_bounds(double *bounds_lon_dev, double *bounds_lat_dev, long ny, long nx, double xmin, double xmax,
                       double ymin, double ymax, double delta_lon_deg, double delta_lat_deg, int lat_uses_dx,

@@ -200,6 +200,7 @@ class Field(object):
             self._lazy_dtype = numpy.dtype(uo.dtype).newbyteorder('=')
             self._uv_code, self._fill = _dtype_code(uo), float(fill_value)
             self._lazy_step = (-1, None, None)
+            self._lazy_buf = None
             pu = pv = None
             uv_dev = 0
         elif pu is None:
@@ -293,13 +294,18 @@ class Field(object):
             self._update_vectors()
 
     # ------------------------------------------------------------------------------------------
-    def _host_zeros(self, shape):
-        """Pinned host array (fast D2H target); the allocation lives as long as any view of the array."""
+    def _host_array(self, shape, dtype=numpy.float64):
+        """Pinned host array (fast D2H / H2D); the allocation lives as long as any view of the array."""
+        dtype = numpy.dtype(dtype)
         n = int(numpy.prod(shape))
-        block = _PinnedBlock(max(n, 1) * 8)
-        buf = (ctypes.c_double * max(n, 1)).from_address(block.ptr)
+        nbytes = max(n, 1) * dtype.itemsize
+        block = _PinnedBlock(nbytes)
+        buf = (ctypes.c_ubyte * nbytes).from_address(block.ptr)
         buf._owner = block  # the ctypes object is the numpy array's base: it keeps the block alive
-        a = numpy.ctypeslib.as_array(buf)[:n].reshape(shape)
+        return numpy.ctypeslib.as_array(buf).view(dtype)[:n].reshape(shape)
+
+    def _host_zeros(self, shape):
+        a = self._host_array(shape)
         a[...] = 0.0
         return a
 
@@ -355,12 +361,19 @@ class Field(object):
         if self._lazy is not None and self._lazy_step[0] != tIndex:
             # one time step from the file; the engine sees a virtual (nt, nz, ny, nx) base that it only
             # dereferences at step tIndex
-            def step_of(src):   # LazyVariable, or a plain / memory-mapped array (one of the two files may be either)
+            if self._lazy_buf is None:   # two pinned step buffers, re-used for every time step (no page faults per
+                shp = (self.nz, self.ny, self.nx)   # step, and the H2D copy of the engine runs from pinned memory)
+                self._lazy_buf = [self._host_array(shp, self._lazy_dtype), self._host_array(shp, self._lazy_dtype)]
+
+            def step_of(src, buf):   # LazyVariable / StepView, or a plain / memory-mapped array (either file may be either)
                 if hasattr(src, 'read_step'):
-                    return numpy.ascontiguousarray(src.read_step(tIndex), dtype=self._lazy_dtype)
-                a = src[tIndex] if len(src.shape) == 4 else src
-                return numpy.ascontiguousarray(a, dtype=self._lazy_dtype)
-            au, av = step_of(self._lazy[0]), step_of(self._lazy[1])
+                    if numpy.dtype(src.dtype) == self._lazy_dtype:
+                        return src.read_step(tIndex, out=buf)
+                    numpy.copyto(buf, src.read_step(tIndex))
+                    return buf
+                numpy.copyto(buf, src[tIndex] if len(src.shape) == 4 else src)
+                return buf
+            au, av = step_of(self._lazy[0], self._lazy_buf[0]), step_of(self._lazy[1], self._lazy_buf[1])
             self._lazy_step = (tIndex, au, av)
             off = tIndex * au.nbytes
             check(lib.nf_field_set_uv(ctypes.byref(self._h), au.ctypes.data - off, av.ctypes.data - off, self.nt,

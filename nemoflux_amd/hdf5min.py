@@ -35,6 +35,26 @@ class Hdf5Error(RuntimeError):
     pass
 
 
+# optional native byte un-shuffle: f(src_uint8_array, dst_uint8_array, n_elements, element_size); nemoflux_amd.io installs
+# the library's nf_host_unshuffle here, hdf5min itself stays importable with numpy + zlib alone
+_native_unshuffle = None
+
+
+def set_unshuffle(func):
+    global _native_unshuffle
+    _native_unshuffle = func
+
+
+def _unshuffle(a, dst, ne, es):
+    """dst (uint8, ne*es bytes, C-contiguous) <- the ne elements whose es byte planes lie one after the other in a."""
+    if _native_unshuffle is not None and dst.flags.c_contiguous and a.flags.c_contiguous:
+        _native_unshuffle(a, dst, ne, es)
+        return
+    d2 = dst.reshape(ne, es)
+    for j in range(es):     # byte-plane assignments: numpy releases the GIL for them
+        d2[:, j] = a[j * ne:(j + 1) * ne]
+
+
 def io_threads():
     """Worker threads for chunk inflation: NF_IO_THREADS, else the cores this process may run on (at most 32)."""
     n = os.environ.get('NF_IO_THREADS')
@@ -75,13 +95,22 @@ class Dataset(object):
             return self._read_chunked()
         raise Hdf5Error(f'{self.name}: unsupported layout {kind}')
 
-    def read_leading(self, i):
+    def read_leading(self, i, out=None):
         """The slab [i] of the leading axis (one time step of uo/vo) without touching the rest of the variable:
-        a view of the mapped file for contiguous data, only the overlapping chunks are inflated otherwise."""
+        a view of the mapped file for contiguous data, only the overlapping chunks are inflated otherwise.  `out`: a
+        C-contiguous array of the slab's shape and this dataset's dtype to inflate into (a caller that walks the time
+        steps re-uses one buffer instead of faulting in a fresh one per step)."""
         if not self.shape or not (0 <= i < self.shape[0]):
             raise Hdf5Error(f'{self.name}: leading index {i} out of range')
         if self._layout[0] != 'chunked':
-            return self.read()[i]
+            if out is None:
+                return self.read()[i]
+            numpy.copyto(out, self.read()[i])
+            return out
+        if out is not None:
+            if out.shape != self.shape[1:] or out.dtype != self.dtype or not out.flags.c_contiguous:
+                raise Hdf5Error(f'{self.name}: output buffer does not match the slab')
+            return self._read_chunked(lead=i, out=out.reshape((1,) + self.shape[1:]))[0]
         return self._read_chunked(lead=i)[0]
 
     def _decode(self, raw, filter_mask, nbytes, dst=None):
@@ -100,14 +129,10 @@ class Dataset(object):
                 ne = a.size // es
                 last = not any(not (filter_mask & (1 << j)) for j in range(k))
                 if dst is not None and last and ne * es == a.size == dst.size:
-                    d2 = dst.reshape(ne, es)
-                    for j in range(es):
-                        d2[:, j] = a[j * ne:(j + 1) * ne]
+                    _unshuffle(a, dst, ne, es)
                     return None
-                tmp = numpy.empty(a.size, numpy.uint8)     # byte-plane assignments: numpy releases the GIL for them
-                t2 = tmp[:ne * es].reshape(ne, es)
-                for j in range(es):
-                    t2[:, j] = a[j * ne:(j + 1) * ne]
+                tmp = numpy.empty(a.size, numpy.uint8)
+                _unshuffle(a[:ne * es], tmp[:ne * es], ne, es)
                 tmp[ne * es:] = a[ne * es:]
                 raw = tmp
             elif fid == 3:  # fletcher32: checksum appended
@@ -118,7 +143,7 @@ class Dataset(object):
             raise Hdf5Error(f'{self.name}: short chunk')
         return raw
 
-    def _read_chunked(self, lead=None):
+    def _read_chunked(self, lead=None, out=None):
         _, btree, cdims, single = self._layout
         rank = len(self.shape)
         cshape = tuple(cdims[:rank])
@@ -135,10 +160,12 @@ class Dataset(object):
         todo = [c for c in self._chunks if c[3] != UNDEF and
                 (lead is None or c[0][0] <= lead < c[0][0] + cshape[0])]
         expected = int(numpy.prod([-(-s // c) for s, c in zip(shape, cshape)]))
-        if len(todo) >= expected:
+        if len(todo) < expected:   # chunks that were never written read as the HDF5 fill value (0 when the file defines none)
+            if out is None:
+                out = numpy.empty(shape, self.dtype)
+            out[...] = 0 if self.h5fill is None else self.h5fill
+        elif out is None:
             out = numpy.empty(shape, self.dtype)
-        else:   # chunks that were never written read as the HDF5 fill value (0 when the file defines none)
-            out = numpy.full(shape, 0 if self.h5fill is None else self.h5fill, self.dtype)
 
         def place(chunk):
             offs, size, mask, addr = chunk
@@ -174,9 +201,15 @@ class LazyVariable(object):
         self.dataset, self.shape = dataset, dataset.shape
         self.dtype = numpy.dtype(dataset.dtype.newbyteorder('='))
 
-    def read_step(self, t):
+    def read_step(self, t, out=None):
+        """Time step t in native byte order, C-contiguous; into `out` (same shape, native dtype) when given."""
+        if out is not None and self.dataset.dtype.isnative:
+            return self.dataset.read_leading(t, out=out)
         a = self.dataset.read_leading(t)
-        return numpy.ascontiguousarray(a, dtype=self.dtype)      # native byte order, C-contiguous
+        if out is None:
+            return numpy.ascontiguousarray(a, dtype=self.dtype)
+        numpy.copyto(out, a)      # converts the byte order
+        return out
 
 
 class File(object):

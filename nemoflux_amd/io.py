@@ -21,6 +21,16 @@ import tempfile
 import numpy
 
 from . import hdf5min
+from ._lib import lib as _nflib
+
+
+def _native_unshuffle(src, dst, n, es):
+    rc = _nflib.nf_host_unshuffle(src.ctypes.data, dst.ctypes.data, n, es)
+    if rc != 0:
+        raise RuntimeError(_nflib.nf_last_error().decode('utf-8', 'replace'))
+
+
+hdf5min.set_unshuffle(_native_unshuffle)     # HDF5 shuffle filter undone by the library's host helper (10x numpy)
 
 _NC2NPZ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'nc2npz.py')
 _H5_PYTHONS = [sys.executable, '/opt/conda/bin/python3.9', 'python3']
@@ -77,8 +87,11 @@ class StepView(object):
         self._a, self.shape = array, tuple(array.shape)
         self.dtype = numpy.dtype(array.dtype.newbyteorder('='))
 
-    def read_step(self, t):
-        return numpy.ascontiguousarray(self._a[t], dtype=self.dtype)
+    def read_step(self, t, out=None):
+        if out is None:
+            return numpy.ascontiguousarray(self._a[t], dtype=self.dtype)
+        numpy.copyto(out, self._a[t])      # converts the byte order
+        return out
 
 
 def _open_classic(path, lazy=()):
