@@ -176,7 +176,7 @@ class Dataset(object):
                 sl_out = (slice(0, 1),) + sl_out[1:]
             dst = out[sl_out]
             direct = dst.shape == cshape and dst.flags.c_contiguous     # whole chunk, one contiguous run of `out`
-            raw = self._h5._m[self._h5._base + addr: self._h5._base + addr + size]
+            raw = memoryview(self._h5._m)[self._h5._base + addr: self._h5._base + addr + size]   # no copy of the chunk
             raw = self._decode(raw, mask, nbytes, dst.reshape(-1).view(numpy.uint8) if direct else None)
             if raw is not None:
                 blk = numpy.frombuffer(raw, self.dtype, count=nbytes // self.dtype.itemsize).reshape(cshape)
