@@ -357,7 +357,7 @@ def test_error_behaviour_matches_reference():
         quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], g['u'], g['v'], [numpy.zeros((1, 3))])
 
 
-@pytest.mark.parametrize('variant', [3, 4, 5, 11, 12, 13, 14, 40])
+@pytest.mark.parametrize('variant', [3, 4, 5, 6, 11, 12, 13, 14, 40])
 def test_flux_kernel_variants_bit_identical(variant):
     """The tuning variants of K1 (2 chunks per lane, temporal loads, 8 levels in flight, writer-wave form) must
     produce the same bits as the default kernel: they only reorder memory traffic, never arithmetic."""
