@@ -178,7 +178,7 @@ def main():
             traffic = json.load(f).get(wl_key, {}).get('hbm_bytes_per_launch')
     roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                'kernel': 'nf::k_flux' if args.compact else 'nf::k_flux + nf::k_expand_planes (one event pair around both)',
+                'kernel': 'nf::k_flux + nf::k_expand_planes (one event pair around both)' if expand_ms > 0 else 'nf::k_flux',
                 'avg_launch_ms': round(avg_ms, 4), 'launches': nlaunch,
                 'avg_ms_by_kernel': {'nf::k_flux': round(flux_ms / max(1, nlaunch), 4),
                                      'nf::k_expand_planes': round(expand_ms / max(1, nlaunch), 4)},

@@ -565,13 +565,18 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
         case 28: return launch_flux_t<T, VEC, 10, true, 256, 1, 16>(a, s);  // only the two signed planes
         case 29: return launch_flux_t<T, VEC, 10, true, 256, 1, 32>(a, s);  // one interleaved (eU,eV) stream
         case 45: return launch_flux_ww<T, VEC, 2, 2>(a, s);                        // writer-wave, no stores
-        case 6: {  // the nested per-level load loop (CH = 1 written as CH-generic code): the previous default
+        case 6: {  // float64 with the nested per-level load loop and the split store form: the default before the flat loop
             const int rc = launch_flux_t<T, VEC, 10, true, 256, 1, 16 | 128>(a, s);
             return rc != NF_OK ? rc : launch_expand_planes(a.iV, a.absU, a.ncell, a.ny, a.nx, s);
         }
-        case 5: return launch_flux_t<T, VEC, 10, true, 256, 1>(a, s);   // all seven stores fused into the flux kernel
-        default: {  // 10 levels x 2 fields in flight, eU and eV stored; the copies and |.| by the streaming expansion
-            if (a.batch.zr) return launch_flux_t<T, VEC, 10, true, 256, 1>(a, s);   // multi-step launch: fused stores
+        case 5:    // the OTHER store form than the default's (float64: split, float32: fused)
+        default: {
+            // 10 levels x 2 fields per batch.  Two store forms: FUSED = all seven stores in the flux kernel; SPLIT = the flux
+            // kernel stores eU, eV and the streaming expansion derives the copies and |.| right behind it.  Which one
+            // wins follows the code the compiler makes of the load loop (in-process A/B, whole passes, several boxes):
+            // float64 (flat load loop): fused -1.1..-1.7 %;  float32 (nested load loop): split -7..-12 %.
+            const bool fused = a.batch.zr || ((sizeof(T) == 8) != (variant == 5));   // multi-step launch: always fused
+            if (fused) return launch_flux_t<T, VEC, 10, true, 256, 1>(a, s);
             const int rc = launch_flux_t<T, VEC, 10, true, 256, 1, 16>(a, s);
             if (rc != NF_OK) return rc;
             if (a.mid_event) {
