@@ -19,8 +19,9 @@
 //                           plane 3[j, (i+1)%nx] = eU[j,i]  (west slot incl. the periodic wrap, :221-223)
 //   abs planes [2][ncell]   |eU|, |eV|
 // nf_field_read_step() re-packs the planes into the reference's (ncell,4) layout on demand.
-// By default the flux kernel stores only planes 1 and 2 and k_expand_planes (below) streams them into the other four
-// right behind it: two thirds of the store traffic leave the read-saturated kernel.
+// Two store forms: FUSED (the flux kernel stores all six planes; float64 default) and SPLIT (it stores only planes 1 and
+// 2 and k_expand_planes, below, streams them into the other four right behind it; float32 default, and the compact
+// resident mode without the expansion) -- see launch_flux_v for the measurements behind the per-dtype choice.
 //
 // Algorithmic bytes per (t,z,j,i) unit: 2*sizeof(T) read + (16 arc + 32 iV + 16 abs)/nz  (SURVEY 8d).
 #include <cstring>
@@ -432,9 +433,8 @@ __global__ __launch_bounds__(kWwBlock) void k_flux_ww(const T *__restrict__ u, c
 // plane 0[c] = eV[c - nx] (row 0 stays 0: field.py:219), plane 3[c] = eU of the cell to the left, column 0 taking the
 // row's last cell (field.py:221-223), |eU|, |eV| (field.py:231-232).  Pure streaming right behind the flux kernel (its
 // two planes are still in the Infinity Cache): a lane owns two cells, every store is a dense aligned 16 B piece.
-// This is the second half of the default step (the flux kernel stores only eU, eV: a third of the store traffic inside
-// the read-saturated kernel; -3 % per pass at f64, -12 % on the kernel at f32 against the fused-store form) and the
-// on-demand expansion of the compact resident mode.
+// This is the second half of a step in the SPLIT store form (the flux kernel then keeps only a third of the store traffic
+// inside the read-saturated kernel) and the on-demand expansion of the compact resident mode.
 template <int W>
 __global__ __launch_bounds__(kBlock) void k_expand_planes(double *__restrict__ iV, double *__restrict__ absUV, long ncell,
                                                           unsigned nx)
