@@ -549,7 +549,7 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
     const int variant = a.batch.zr ? 0 : g_variant;  // the multi-step launch exists for the default kernel only
     if (a.signed_only) {  // compact resident mode: the caller expands on demand
         NF_REQUIRE(VEC > 1 && !a.batch.zr, NF_ERR_STATE, "flux: the compact mode needs 16-byte aligned fields, an even cell count and one step per launch");
-        return launch_flux_t<T, VEC, 10, true, 256, 1, 16>(a, s);
+        return launch_flux_t<T, VEC, (sizeof(T) == 8 ? 10 : 8), true, 256, 1, 16>(a, s);   // same batches as the defaults
     }
     if (VEC == 1) return launch_flux_t<T, VEC, 8, true, 256, 1>(a, s);  // odd cell counts / unaligned fields: one cell per lane
     switch (variant) {
