@@ -172,11 +172,11 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
         for (int z = z0; z < z1; z += UZ) {
             const int nlev = z1 - z < UZ ? z1 - z : UZ;
             Lanes<T, VEC> lu[UZ][CH], lv[UZ][CH];
-            if (CH == 1 && sizeof(T) == 8 && !(DIAG & 128)) {
-                // ONE flat loop over the 2*UZ loads (u0, v0, u1, v1, ...), each under its own wave-uniform predicate: for
-                // float64 this form compiles to a load stream that runs 1-3 % faster (in-process, four boxes) than the
-                // nested per-level form below; for float32 it is 12 % slower, so float32 keeps the nested form.  Putting
-                // all u levels before all v levels costs 14 %.
+            if (CH == 1 && !(DIAG & 128)) {
+                // ONE flat loop over the 2*UZ loads (u0, v0, u1, v1, ...), each under its own wave-uniform predicate: this
+                // form compiles to a load stream that runs 1-3 % faster (in-process, several boxes) than the nested
+                // per-level form below -- at float32 only up to 9 levels per batch (at 10 it is 12 % slower: the kernel
+                // drops to 4 waves per SIMD).  Putting all u levels before all v levels costs 14 %.
 #pragma unroll
                 for (int k = 0; k < 2 * UZ; ++k) {
                     const int r = k / 2;
@@ -565,8 +565,8 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
         case 28: return launch_flux_t<T, VEC, 10, true, 256, 1, 16>(a, s);  // only the two signed planes
         case 29: return launch_flux_t<T, VEC, 10, true, 256, 1, 32>(a, s);  // one interleaved (eU,eV) stream
         case 45: return launch_flux_ww<T, VEC, 2, 2>(a, s);                        // writer-wave, no stores
-        case 6: {  // float64 with the nested per-level load loop and the split store form: the default before the flat loop
-            const int rc = launch_flux_t<T, VEC, 10, true, 256, 1, 16 | 128>(a, s);
+        case 6: {  // the nested per-level load loop with the split store form: the defaults before the flat loop
+            const int rc = launch_flux_t<T, VEC, (sizeof(T) == 8 ? 10 : 8), true, 256, 1, 16 | 128>(a, s);
             return rc != NF_OK ? rc : launch_expand_planes(a.iV, a.absU, a.ncell, a.ny, a.nx, s);
         }
         case 5:    // the OTHER store form than the default's (float64: split, float32: fused)
