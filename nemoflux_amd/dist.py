@@ -35,6 +35,9 @@ def init_from_env(backend=None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if 'NF_FORCE_DEVICE' in os.environ:      # rehearsal of N ranks on a one-GPU box (with NF_DIST_BACKEND=gloo)
         local = int(os.environ['NF_FORCE_DEVICE'])
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev and local >= ndev:   # launcher that restricts every rank to its own device (HIP_VISIBLE_DEVICES per rank)
+        local %= ndev
     backend = backend or os.environ.get('NF_DIST_BACKEND')
     if world > 1 and not dist.is_initialized():
         if backend is None:
