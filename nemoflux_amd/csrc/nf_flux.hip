@@ -8,8 +8,9 @@
 //
 // Access pattern.  uo/vo are (nt,nz,ny,nx) x-fastest.  A lane owns VEC consecutive cells (16 B: 2 x f64 or
 // 4 x f32) and walks z with stride ncell; a wavefront therefore reads 1 KiB contiguous per (z, field) with
-// global_load_dwordx4, UZ levels x 2 fields in flight per lane before the first use.  Nothing is reused, so
-// nothing is staged in LDS; the thickness vector is wave-uniform (scalar loads).
+// global_load_dwordx4, in batches of UZ levels x 2 fields (all loads of a batch are issued, then the batch is consumed;
+// DESIGN.md section 4 has what the compiler makes of that).  Nothing is reused, so nothing is staged in LDS; the
+// thickness vector is wave-uniform (scalar loads).
 //
 // Resident output layout (HBM, float64) -- SoA planes instead of the reference's (ncell,4) AoS, so that every
 // store is a dense 16 B/lane stream and the neighbour copies become SHIFTED dense stores:
