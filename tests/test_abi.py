@@ -200,3 +200,20 @@ def test_c_client_links_and_fails_loudly_without_gpu(tmp_path):
         pytest.skip('GPU present: tests/test_gpu_dist.py runs the client')
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and 'no usable AMD GPU' in r.stderr and 'no CPU fallback' in r.stderr
+
+
+def test_host_unshuffle_helper_matches_numpy():
+    """nf_host_unshuffle (file decoding on the host, no GPU involved): the inverse of HDF5's shuffle filter for element
+    sizes 1..16, aligned and unaligned destinations."""
+    from nemoflux_amd import _lib
+    rng = numpy.random.default_rng(7)
+    for es in (1, 2, 4, 8, 16, 3):
+        for n in (1, 5, 64, 1001):
+            elems = rng.integers(0, 256, size=(n, es), dtype=numpy.uint8)
+            shuffled = numpy.ascontiguousarray(elems.T).reshape(-1)          # es byte planes of n bytes each
+            for shift in (0, 1):
+                buf = numpy.zeros(n * es + shift, numpy.uint8)
+                dst = buf[shift:]
+                assert _lib.lib.nf_host_unshuffle(shuffled.ctypes.data, dst.ctypes.data, n, es) == 0
+                assert numpy.array_equal(dst.reshape(n, es), elems)
+    assert _lib.lib.nf_host_unshuffle(None, None, 4, 4) == 1 and _lib.lib.nf_host_unshuffle(shuffled.ctypes.data, dst.ctypes.data, 4, 0) == 1
