@@ -795,3 +795,19 @@ def test_compact_resident_mode_is_bit_identical(real, nx, ny):
     check(lib.nf_field_read_step(ctypes.byref(cmp_._h), cmp_.integratedVelocity.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
                                  None, None, ctypes.byref(m)))
     assert numpy.array_equal(ref.integratedVelocity, cmp_.integratedVelocity)
+
+
+@pytest.mark.parametrize('real', ['float64', 'float32'])
+def test_kernel_timing_split(real):
+    """nf_field_timing_read / nf_field_timing_split: one timed entry per flux launch; float64 runs the fused store form
+    (no expansion kernel), float32 the split one (flux kernel + expansion), and the shares add up to the total."""
+    dg = device_case(360, 180, 6, 3, PSI_ZT, real=real)
+    fld = quiet_field(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, [transect_xyz(T_OPEN)], readback=False)
+    fld.enableKernelTiming(True)
+    for t in range(3):
+        fld.computeFlux(t)
+    n, total, flux, expand = fld.readKernelTiming(split=True)
+    assert n == 3 and total > 0 and flux > 0 and abs(flux + expand - total) <= 1e-6 * total + 1e-9
+    assert (expand == 0.0) == (real == 'float64')
+    assert fld.readKernelTiming() == (0, 0.0)          # reading resets
+    fld.enableKernelTiming(False)
