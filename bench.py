@@ -258,7 +258,8 @@ def cpu_baseline(dg, u, v, nz, ny, nx, xyz0, args):
     return {'value': units / best, 'unit': 'integrals/s', 'cores': int(threads), 'kind': 'port',
             'sample': f'1 of {args.nt} time steps of the bench workload ({nx}x{ny}x{nz}, {args.dtype}), best of {reps} '
                       f'reps of the numpy restatement of field.py:157-234 (+oracle A7, README transect): '
-                      f'{best:.3f} s/step; one-off arc lengths {t_arc:.2f} s, oracle weights {t_w:.2f} s; '
+                      f'{best:.3f} s/step; one-off: numpy arc lengths {t_arc:.2f} s, C restatement of the mint weights (A6, one '
+                      f'thread like mint, README transect over all {ny * nx} cells) {t_w:.2f} s; '
                       f'C port of the same step with OpenMP ({omp} threads): {units / t_c:.3e} integrals/s; flux {tot:.6g}'}
 
 
