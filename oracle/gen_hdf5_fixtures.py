@@ -40,9 +40,49 @@ def big_extensible(path):
             d[i] = x
 
 
+def random_file(path, seed, libver, count):
+    """`count` random chunked datasets (rank 1-4, random chunk shapes, filters, byte orders, fixed / one / several
+    unlimited dimensions, some only partly written) plus <path>.<name>.npy with the values h5py itself reads back and
+    <path>.json with the names: tests/test_hdf5min.py cross-checks the reader against them."""
+    import json
+    rng = numpy.random.default_rng(seed)
+    names = []
+    with h5py.File(path, 'w', libver=libver) as f:
+        for k in range(count):
+            rank = int(rng.integers(1, 5))
+            shape = tuple(int(x) for x in rng.integers(1, 9, rank))
+            chunks = tuple(int(rng.integers(1, s + 1)) for s in shape)
+            dt = str(rng.choice(['<f4', '<f8', '>f4', '<i4', '<i2']))
+            maxshape = list(shape)
+            for i in rng.permutation(rank)[:[0, 1, 2, rank][int(rng.integers(0, 4))]]:
+                maxshape[i] = None
+            kw = {}
+            if rng.random() < 0.5:
+                kw.update(compression='gzip', compression_opts=int(rng.integers(1, 6)))
+            if rng.random() < 0.4:
+                kw['shuffle'] = True
+            if rng.random() < 0.2:
+                kw['fletcher32'] = True
+            name = f'd{k}'
+            a = (rng.standard_normal(shape) * 100).astype(dt)
+            if rng.random() < 0.3:   # only a corner is ever written: the rest reads as the fill value
+                d = f.create_dataset(name, shape=shape, dtype=dt, chunks=chunks, maxshape=tuple(maxshape),
+                                     fillvalue=float(rng.integers(-5, 5)), **kw)
+                sel = tuple(slice(0, max(1, s // 2)) for s in shape)
+                d[sel] = a[sel]
+            else:
+                d = f.create_dataset(name, data=a, chunks=chunks, maxshape=tuple(maxshape), **kw)
+            numpy.save(f'{path}.{name}.npy', d[...])
+            names.append(name)
+    with open(path + '.json', 'w') as f:
+        json.dump(names, f)
+
+
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == '--big-extensible':
         return big_extensible(sys.argv[2])
+    if len(sys.argv) > 5 and sys.argv[1] == '--random':
+        return random_file(sys.argv[2], int(sys.argv[3]), sys.argv[4], int(sys.argv[5]))
     os.makedirs(OUT, exist_ok=True)
     with h5py.File(os.path.join(OUT, 'old_style.h5'), 'w', libver='earliest') as f:
         f.create_dataset('bounds_lon', data=field((5, 7, 4), '<f8', 1))

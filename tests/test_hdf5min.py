@@ -227,3 +227,32 @@ def test_paged_extensible_array_blocks(tmp_path):
         for i, x in ((135000, 1.5), (199999, 2.5), (3, 3.5), (599999, 4.5), (300000, 5.5)):
             want[i] = x
         assert numpy.array_equal(f.datasets['big_sparse'].read(), want)
+
+
+@pytest.mark.parametrize('libver,seed', [('latest', 11), ('earliest', 12)])
+def test_random_datasets_against_h5py(tmp_path, libver, seed):
+    """Differential test: 30 random chunked datasets per file (rank 1-4, ragged chunks, gzip / shuffle / fletcher32, both
+    byte orders, integer types, 0-4 unlimited dimensions -> every chunk index kind, partly written ones), written by
+    the HDF5 library through h5py under its own interpreter, read back by hdf5min: every value, and the last leading
+    slab through read_leading.  Skipped where no interpreter with h5py exists."""
+    import json
+    import subprocess
+    from nemoflux_amd import hdf5min
+    py = '/opt/conda/bin/python3.9'
+    path = str(tmp_path / f'rand_{libver}.h5')
+    gen = os.path.join(os.path.dirname(GOLDEN), '..', 'oracle', 'gen_hdf5_fixtures.py')
+    if not os.path.exists(py) or subprocess.run([py, gen, '--random', path, str(seed), libver, '30'],
+                                                capture_output=True).returncode != 0:
+        pytest.skip('no interpreter with h5py')
+    with open(path + '.json') as f:
+        names = json.load(f)
+    native = lambda a: a.astype(a.dtype.newbyteorder('='))
+    with hdf5min.File(path) as h5:
+        for name in names:
+            want = numpy.load(f'{path}.{name}.npy')
+            ds = h5.datasets[name]
+            assert not isinstance(ds, Exception), (name, ds)
+            got = ds.read()
+            assert got.shape == want.shape and numpy.array_equal(native(got), native(want)), name
+            if want.ndim >= 2:
+                assert numpy.array_equal(native(ds.read_leading(want.shape[0] - 1)), native(want[-1])), name
