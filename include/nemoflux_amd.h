@@ -190,7 +190,9 @@ int nf_field_device_ptr(nf_field **self, int which, void **dev);
 /* A Grid_t view of the field's corner table (so mint.PolylineIntegral objects can share it). */
 int nf_field_grid(nf_field **self, Grid_t **grid);
 /* Kernel timing with HIP events on the field's stream, around the vertical-integral+edge-flux launches
- * (bench.py's roofline leg): enable, run, then read (launch count, total ms). */
+ * (bench.py's roofline leg): enable, run, then read (launch count, total ms).  enable > 1 also creates that many
+ * event triples up front, so that no event is created inside a timed region; the events are re-used after every read
+ * (at most 65536 launches are recorded between two reads). */
 int nf_field_timing(nf_field **self, int enable);
 int nf_field_timing_read(nf_field **self, long *launches, double *total_ms);
 /* how the total of the last nf_field_timing_read splits between the flux kernel and the expansion kernel behind it */

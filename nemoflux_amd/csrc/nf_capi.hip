@@ -641,7 +641,9 @@ struct nf_field {
         hipEvent_t e0 = nullptr, mid = nullptr, e1 = nullptr;
         bool has_mid = false;
     };
-    std::vector<TimedLaunch> ev;
+    std::vector<TimedLaunch> ev;     // pool: created once (nf_field_timing reserves), re-used after every timing_read
+    size_t ev_used = 0;              // launches recorded since the last timing_read
+    long ev_dropped = 0;             // launches not recorded because the pool was at its cap
     double last_flux_ms = 0.0, last_expand_ms = 0.0;   // split of the last timing_read
     // hipGraph of one compute_all pass (launch-bound small grids: 4 launches per time step)
     hipGraphExec_t graph_exec = nullptr;
@@ -685,16 +687,34 @@ static void field_drop_events(nf_field *f)
         for (hipEvent_t e : {t.e0, t.mid, t.e1})
             if (e) (void)hipEventDestroy(e);
     f->ev.clear();
+    f->ev_used = 0;
+    f->ev_dropped = 0;
+}
+
+// event triples are created outside the timed region (nf_field_timing(n) reserves n) and re-used; the pool never grows
+// past kMaxTimedLaunches, so a caller that never reads the timing does not leak events
+constexpr size_t kMaxTimedLaunches = 1 << 16;
+static int field_reserve_events(nf_field *f, size_t n)
+{
+    if (n > kMaxTimedLaunches) n = kMaxTimedLaunches;
+    while (f->ev.size() < n) {
+        f->ev.emplace_back();
+        NF_HIP(hipEventCreate(&f->ev.back().e0));
+        NF_HIP(hipEventCreate(&f->ev.back().mid));
+        NF_HIP(hipEventCreate(&f->ev.back().e1));
+    }
+    return NF_OK;
 }
 
 // one flux launch (and, in the default step, the expansion behind it) bracketed by events on the field's stream
 static int field_timed_flux(nf_field *f, FluxArgs &a)
 {
-    f->ev.emplace_back();          // owned by the field from here on (destroyed by timing_read / del)
-    const size_t k = f->ev.size() - 1;
-    NF_HIP(hipEventCreate(&f->ev[k].e0));
-    NF_HIP(hipEventCreate(&f->ev[k].mid));
-    NF_HIP(hipEventCreate(&f->ev[k].e1));
+    if (f->ev_used >= kMaxTimedLaunches) {   // nobody reads the timing: keep computing, stop recording
+        ++f->ev_dropped;
+        return launch_flux(a, f->stream);
+    }
+    NF_TRY(field_reserve_events(f, f->ev_used + 1));   // no-op when nf_field_timing reserved enough
+    const size_t k = f->ev_used++;
     bool mid = false;
     a.mid_event = f->ev[k].mid;
     a.mid_recorded = &mid;
@@ -1295,8 +1315,11 @@ int nf_field_timing(nf_field **self, int enable)
 try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_timing: null field");
     nf_field *f = *self;
-    field_drop_events(f);
+    if (!enable) field_drop_events(f);
+    f->ev_used = 0;
+    f->ev_dropped = 0;
     f->timing = enable != 0;
+    if (enable > 1) NF_TRY(field_reserve_events(f, (size_t)enable));   // event creation stays out of the timed region
     ++f->version;
     return NF_OK;
 }
@@ -1307,7 +1330,8 @@ try {
     nf_field *f = *self;
     NF_HIP(hipStreamSynchronize(f->stream));
     double tot = 0.0, flux = 0.0, expand = 0.0;
-    for (const auto &t : f->ev) {
+    for (size_t k = 0; k < f->ev_used; ++k) {
+        const auto &t = f->ev[k];
         float ms = 0.f, part = 0.f;
         NF_HIP(hipEventElapsedTime(&ms, t.e0, t.e1));
         tot += ms;
@@ -1319,11 +1343,11 @@ try {
             flux += ms;
         }
     }
-    *launches = (long)f->ev.size();
+    *launches = (long)f->ev_used;
     *total_ms = tot;
     f->last_flux_ms = flux;
     f->last_expand_ms = expand;
-    field_drop_events(f);
+    f->ev_used = 0;
     return NF_OK;
 }
 NF_API_CATCH

@@ -132,9 +132,20 @@ __device__ inline void store_cells(long c0, const double *eU, const double *eV, 
     }
 }
 
+// FORM bits of k_flux.  The product library instantiates only the two bit-identical code forms; the diagnostic bits (which
+// remove an ingredient of the kernel to price it, i.e. give WRONG results on purpose) exist only in tuning builds
+// (-DNF_TUNING_BUILD, `make tuning`, tools/ab_flux.py) and are compiled out of the shipped .so.
+constexpr int kFormSignedOnly = 16;    // store only planes 1 (eU) and 2 (eV): split step and compact resident mode
+constexpr int kFormNestedLoads = 128;  // per-level nested load loop instead of the flat one
+#ifdef NF_TUNING_BUILD
+constexpr int kDiagNoStores = 1, kDiagNoFix = 2, kDiagNoMax = 4, kDiagNoArc = 8, kDiagInterleaved = 32, kDiagPlainStores = 64;
+#else
+constexpr int kDiagNoStores = 0, kDiagNoFix = 0, kDiagNoMax = 0, kDiagNoArc = 0, kDiagInterleaved = 0, kDiagPlainStores = 0;
+#endif
+
 // BLOCK threads; every lane owns CH chunks of VEC cells, chunk q at tile_base + q*BLOCK*VEC + tid*VEC, so the
 // workgroup reads CH x (BLOCK x 16 B) contiguous bytes per (z, field).  The waves of a workgroup never synchronise.
-template <typename T, int VEC, int UZ, bool NT, int BLOCK, int CH, int DIAG = 0>
+template <typename T, int VEC, int UZ, bool NT, int BLOCK, int CH, int FORM = 0>
 __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T *__restrict__ v, long ncell,
                                                 unsigned ny, unsigned nx, int z0, int z1,
                                                 const double *__restrict__ thickness,
@@ -143,6 +154,9 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
                                                 double *__restrict__ absUV, unsigned long long *maxbits,
                                                 unsigned ntiles, int xcd_map, StepBatch sb)
 {
+#ifndef NF_TUNING_BUILD
+    static_assert((FORM & ~(kFormSignedOnly | kFormNestedLoads)) == 0, "diagnostic forms exist only in tuning builds");
+#endif
     const unsigned tile = xcd_map ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
     if (sb.zr) {  // several time steps in one launch (small grids are launch-bound): blockIdx.y is the step
         const long tb = blockIdx.y;
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
         for (int z = z0; z < z1; z += UZ) {
             const int nlev = z1 - z < UZ ? z1 - z : UZ;
             Lanes<T, VEC> lu[UZ][CH], lv[UZ][CH];
-            if (CH == 1 && !(DIAG & 128)) {
+            if (CH == 1 && !(FORM & kFormNestedLoads)) {
                 // ONE flat loop over the 2*UZ loads (u0, v0, u1, v1, ...), each under its own wave-uniform predicate: this
                 // form compiles to a load stream that runs 1-3 % faster (in-process, several boxes) than the nested
                 // per-level form below -- at float32 only up to 9 levels per batch (at 10 it is 12 % slower: the kernel
@@ -207,8 +221,8 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
                         if (on[q]) {
 #pragma unroll
                             for (int k = 0; k < VEC; ++k) {
-                                accU[q][k] = fma(th, (DIAG & 2) ? (double)lu[r][q].x[k] : fixed<T>(lu[r][q].x[k], fill), accU[q][k]);
-                                accV[q][k] = fma(th, (DIAG & 2) ? (double)lv[r][q].x[k] : fixed<T>(lv[r][q].x[k], fill), accV[q][k]);
+                                accU[q][k] = fma(th, (FORM & kDiagNoFix) ? (double)lu[r][q].x[k] : fixed<T>(lu[r][q].x[k], fill), accU[q][k]);
+                                accV[q][k] = fma(th, (FORM & kDiagNoFix) ? (double)lv[r][q].x[k] : fixed<T>(lv[r][q].x[k], fill), accV[q][k]);
                             }
                         }
                 }
@@ -223,24 +237,24 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
                 double eU[VEC], eV[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    eU[k] = +accU[q][k] * ((DIAG & 8) ? 1.5 : arcE[c0 + k]);
-                    eV[k] = -accV[q][k] * ((DIAG & 8) ? 1.5 : arcN[c0 + k]);
+                    eU[k] = +accU[q][k] * ((FORM & kDiagNoArc) ? 1.5 : arcE[c0 + k]);
+                    eV[k] = -accV[q][k] * ((FORM & kDiagNoArc) ? 1.5 : arcN[c0 + k]);
                     if (sverdrup) {
                         eU[k] *= scale;
                         eV[k] *= scale;
                     }
                     tmax = fmax(tmax, fmax(fabs(eU[k]), fabs(eV[k])));
                 }
-                if (DIAG & 32) {  // diagnostic: ONE interleaved (eU,eV) stream, 32 B per lane
+                if (FORM & kDiagInterleaved) {  // diagnostic: ONE interleaved (eU,eV) stream, 32 B per lane
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) store2<true>(iV + 2 * (c0 + k), eU[k], eV[k], true);
-                } else if (DIAG & 16) {  // only the two signed planes (the rest comes from k_expand_planes)
+                } else if (FORM & kFormSignedOnly) {  // only the two signed planes (the rest comes from k_expand_planes)
 #pragma unroll
                     for (int k = 0; k < VEC; k += 2) {
                         store2<true>(iV + ncell + c0 + k, eU[k], eU[k + 1], true);
                         store2<true>(iV + 2 * ncell + c0 + k, eV[k], eV[k + 1], true);
                     }
-                } else if (!(DIAG & 1)) store_cells<VEC, !(DIAG & 64)>(c0, eU, eV, ncell, ny, nx, iV, absUV);
+                } else if (!(FORM & kDiagNoStores)) store_cells<VEC, !(FORM & kDiagPlainStores)>(c0, eU, eV, ncell, ny, nx, iV, absUV);
             }
     }
     // running max (field.py:234): wavefront butterfly, then at most one atomic per WAVEFRONT -- no LDS, no workgroup
@@ -250,185 +264,18 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
     // the non-coherent caches) and the atomic is issued only by a wave that would raise it: a stale read can cause a
     // spare atomic, never a missed one.
     for (int o = 32; o > 0; o >>= 1) tmax = fmax(tmax, __shfl_xor(tmax, o, kWave));
-    if ((threadIdx.x & (kWave - 1)) == 0 && tmax > 0.0 && !(DIAG & 4)) {
+    if ((threadIdx.x & (kWave - 1)) == 0 && tmax > 0.0 && !(FORM & kDiagNoMax)) {
         unsigned long long b;
         __builtin_memcpy(&b, &tmax, 8);
         if (b > __hip_atomic_load(maxbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxbits, b);
     }
 }
 
-// ---- two-buffer load pipeline helpers (used by the writer-wave variant) ------------------------------------
-template <typename T, int VEC, int UZ> struct Batch {
-    Lanes<T, VEC> u[UZ], v[UZ];
-};
-
-// always UZ x 2 loads: levels past z1 re-read the last level and are ignored by consume_batch.  A FIXED number of
-// memory instructions per step lets the compiler place exact vmcnt(N) waits instead of draining the queue.
-template <typename T, int VEC, int UZ>
-__device__ inline void load_batch(Batch<T, VEC, UZ> &B, const T *__restrict__ u, const T *__restrict__ v, long ncell,
-                                  long c0, int zb, int z1)
-{
-#pragma unroll
-    for (int r = 0; r < UZ; ++r) {
-        const int zz = (zb + r < z1) ? zb + r : z1 - 1;  // wave-uniform clamp
-        B.u[r] = load_cells<T, VEC, true>(u + (long)zz * ncell + c0);
-        B.v[r] = load_cells<T, VEC, true>(v + (long)zz * ncell + c0);
-    }
-}
-
-template <typename T, int VEC, int UZ>
-__device__ inline void consume_batch(const Batch<T, VEC, UZ> &B, const double *__restrict__ thickness, int zb, int z1,
-                                     T fill, double *accU, double *accV)
-{
-#pragma unroll
-    for (int r = 0; r < UZ; ++r)
-        if (zb + r < z1) {  // wave-uniform, no memory instruction inside
-            const double th = thickness[zb + r];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                accU[k] = fma(th, fixed<T>(B.u[r].x[k], fill), accU[k]);
-                accV[k] = fma(th, fixed<T>(B.v[r].x[k], fill), accV[k]);
-            }
-        }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Writer-wave form of K1.  On CDNA the vector-memory counter (vmcnt) is ONE in-order counter for loads and
-// stores, and under a saturated read stream a store's acknowledgement takes 2-4 load round trips: a wave that
-// stores and then waits for its next loads (or exits) idles for tens of microseconds (measured: +0.10..0.23 ms
-// per launch even when the stores never reach HBM).  So the roles are split inside a 5-wave workgroup:
-//   waves 0..3  compute: a pure, exactly counted two-buffer LOAD pipeline over their tiles (u, v levels and, one step
-//               before a tile ends, its arc lengths); at the end of a tile they leave eU, eV in LDS;
-//   wave 4      writer: after the workgroup barrier it reads the 4 x 64 results from LDS and issues all stores
-//               (4-slot planes, |.| planes) and keeps the running max; it never waits on a load, so its store
-//               queue drains in the background while the compute waves are already deep in the next tile.
-// The barrier is a bare s_barrier after lgkmcnt(0): it does not drain the compute waves' prefetched loads.
-// LDS is double buffered (slot = tile & 1); one barrier per tile orders both hand-off and slot reuse.
-constexpr int kCompWaves = 4;
-constexpr int kWwBlock = (kCompWaves + 1) * kWave;  // 320 threads
-
-__device__ inline void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <typename T, int VEC, int UZ, int DIAG = 0>
-__global__ __launch_bounds__(kWwBlock) void k_flux_ww(const T *__restrict__ u, const T *__restrict__ v, long ncell,
-                                                      unsigned ny, unsigned nx, int z0, int z1,
-                                                      const double *__restrict__ thickness,
-                                                      const double *__restrict__ arcE,
-                                                      const double *__restrict__ arcN, T fill, double scale,
-                                                      int sverdrup, double *__restrict__ iV,
-                                                      double *__restrict__ absUV, unsigned long long *maxbits)
-{
-    __shared__ double s_res[2][kCompWaves][2][VEC][kWave];  // [slot][wave][U|V][k][lane]: conflict-free columns
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
-    // workgroup id: XCD x (= blockIdx % 8) owns a contiguous band of workgroup ids
-    const long G = gridDim.x;
-    const long wg = (long)(blockIdx.x % kXcds) * (G / kXcds) + blockIdx.x / kXcds;
-    const long nchunk = ncell / VEC;                                  // 16-B chunks
-    constexpr long kWgChunks = (long)kCompWaves * kWave;             // chunks per workgroup tile
-    const long T_all = (nchunk + kWgChunks - 1) / kWgChunks;         // workgroup tiles, dealt round-robin
-    const long ntile = wg < T_all ? (T_all - wg + G - 1) / G : 0;    // uniform over the workgroup
-    if (wave < kCompWaves) {
-        // ------------------------------------------------------------------ compute waves
-        int nb = (z1 - z0 + UZ - 1) / UZ;  // batches per tile, padded to an even number >= 2
-        nb += nb & 1;
-        if (nb < 2) nb = 2;
-        const int npair = nb / 2;
-        auto cell_of = [&](long t) -> long {  // lanes past the end shadow the last chunk (duplicate loads)
-            long ch = (t * G + wg) * kWgChunks + (long)wave * kWave + lane;
-            if (ch > nchunk - 1) ch = nchunk - 1;
-            return ch * VEC;
-        };
-        if (ntile > 0) {
-            Batch<T, VEC, UZ> A, B;
-            double accU[VEC], accV[VEC], aE[VEC], aN[VEC];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) accU[k] = accV[k] = 0.0;
-            long c0 = cell_of(0);
-            load_batch<T, VEC, UZ>(A, u, v, ncell, c0, z0, z1);
-            for (long tile = 0; tile < ntile; ++tile) {
-                int zb = z0;
-#pragma unroll 1
-                for (int p = 0; p + 1 < npair; ++p) {
-                    load_batch<T, VEC, UZ>(B, u, v, ncell, c0, zb + UZ, z1);
-                    consume_batch<T, VEC, UZ>(A, thickness, zb, z1, fill, accU, accV);
-                    zb += UZ;
-                    load_batch<T, VEC, UZ>(A, u, v, ncell, c0, zb + UZ, z1);
-                    consume_batch<T, VEC, UZ>(B, thickness, zb, z1, fill, accU, accV);
-                    zb += UZ;
-                }
-                // last pair: the tile's arc lengths ride one step ahead of the next tile's first batch
-                load_batch<T, VEC, UZ>(B, u, v, ncell, c0, zb + UZ, z1);
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    aE[k] = arcE[c0 + k];
-                    aN[k] = arcN[c0 + k];
-                }
-                consume_batch<T, VEC, UZ>(A, thickness, zb, z1, fill, accU, accV);
-                zb += UZ;
-                const long cn = cell_of(tile + 1 < ntile ? tile + 1 : tile);  // after the last tile: dropped
-                load_batch<T, VEC, UZ>(A, u, v, ncell, cn, z0, z1);
-                consume_batch<T, VEC, UZ>(B, thickness, zb, z1, fill, accU, accV);
-                // edge fluxes (field.py:195-196, 225-228) -> LDS
-                const int slot = (int)(tile & 1);
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    double eU = +accU[k] * aE[k];
-                    double eV = -accV[k] * aN[k];
-                    if (sverdrup) {
-                        eU *= scale;
-                        eV *= scale;
-                    }
-                    s_res[slot][wave][0][k][lane] = eU;
-                    s_res[slot][wave][1][k][lane] = eV;
-                    accU[k] = accV[k] = 0.0;
-                }
-                c0 = cn;
-                lds_barrier();
-            }
-        }
-    } else {
-        // ------------------------------------------------------------------ writer wave
-        double tmax = 0.0;
-        for (long tile = 0; tile < ntile; ++tile) {
-            lds_barrier();
-            const int slot = (int)(tile & 1);
-#pragma unroll 1
-            for (int w = 0; w < kCompWaves; ++w) {
-                const long ch = (tile * G + wg) * kWgChunks + (long)w * kWave + lane;
-                double eU[VEC], eV[VEC];
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    eU[k] = s_res[slot][w][0][k][lane];
-                    eV[k] = s_res[slot][w][1][k][lane];
-                }
-                if (ch < nchunk) {
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) tmax = fmax(tmax, fmax(fabs(eU[k]), fabs(eV[k])));
-                    if (DIAG == 0) {
-                        store_cells<VEC, true>(ch * VEC, eU, eV, ncell, ny, nx, iV, absUV);
-                    } else if (DIAG == 1) {  // diagnostic: only the two signed planes
-#pragma unroll
-                        for (int k = 0; k < VEC; k += 2) {
-                            store2<true>(iV + ncell + ch * VEC + k, eU[k], eU[k + 1], true);
-                            store2<true>(iV + 2 * ncell + ch * VEC + k, eV[k], eV[k + 1], true);
-                        }
-                    }
-                }
-            }
-        }
-        // running max (field.py:234): one atomic per workgroup, after all of its tiles
-        for (int o = 32; o > 0; o >>= 1) tmax = fmax(tmax, __shfl_xor(tmax, o, kWave));
-        if (lane == 0 && tmax > 0.0) {
-            unsigned long long b;
-            __builtin_memcpy(&b, &tmax, 8);
-            atomicMax(maxbits, b);
-        }
-    }
-}
+#ifdef NF_TUNING_BUILD
+// tuning builds only (make -C nemoflux_amd/csrc tuning): the writer-wave form of K1 (measured 4-13 % slower, kept as a
+// record of the experiment) lives with the tools that measure it
+#include "../../tools/nf_flux_ww.inc"
+#endif
 
 // ---- the four derived planes from the two signed ones ---------------------------------------------------------
 // plane 0[c] = eV[c - nx] (row 0 stays 0: field.py:219), plane 3[c] = eU of the cell to the left, column 0 taking the
@@ -489,7 +336,6 @@ static int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 // tuning knobs: environment at first use, nf_tuning_set() at run time (A/B runs inside one process)
-static int g_pipe_waves = env_int("NF_WW_BLOCKS_PER_CU", 0);  // writer-wave form: 0 = from the occupancy query
 static int g_xcd_map = env_int("NF_XCD_MAP", 1);
 static int g_variant = env_int("NF_FLUX_VARIANT", 0);
 static long g_tuning_version = 0;
@@ -499,19 +345,21 @@ int tuning_set(const char *name, int value)
     ++g_tuning_version;  // captured graphs bake the variant in
     if (!strcmp(name, "xcd_map")) g_xcd_map = value;
     else if (!strcmp(name, "flux_variant")) g_variant = value;
+#ifdef NF_TUNING_BUILD
     else if (!strcmp(name, "ww_blocks_per_cu")) g_pipe_waves = value;
+#endif
     else return NF_ERR_ARG;
     return NF_OK;
 }
 
-template <typename T, int VEC, int UZ, bool NT, int BLOCK, int CH, int DIAG = 0>
+template <typename T, int VEC, int UZ, bool NT, int BLOCK, int CH, int FORM = 0>
 static int launch_flux_t(const FluxArgs &a, hipStream_t s)
 {
     const long per_tile = (long)BLOCK * VEC * CH;
     const unsigned ntiles = (unsigned)((a.ncell + per_tile - 1) / per_tile);
     const int xcd_map = g_xcd_map;
     const unsigned grid = xcd_map ? xcd_grid(ntiles) : ntiles;
-    hipLaunchKernelGGL((k_flux<T, VEC, UZ, NT, BLOCK, CH, DIAG>), dim3(grid, (unsigned)(a.batch.zr ? a.batch.nsteps : 1)),
+    hipLaunchKernelGGL((k_flux<T, VEC, UZ, NT, BLOCK, CH, FORM>), dim3(grid, (unsigned)(a.batch.zr ? a.batch.nsteps : 1)),
                        dim3(BLOCK), 0, s, (const T *)a.u, (const T *)a.v, a.ncell, (unsigned)a.ny, (unsigned)a.nx, a.z0,
                        a.z1, a.thickness, a.arcE, a.arcN, (T)a.fill, a.scale, a.sverdrup, a.iV, a.absU, a.maxbits, ntiles,
                        xcd_map, a.batch);
@@ -519,38 +367,16 @@ static int launch_flux_t(const FluxArgs &a, hipStream_t s)
     return NF_OK;
 }
 
-template <typename T, int VEC, int UZ, int DIAG = 0>
-static int launch_flux_ww(const FluxArgs &a, hipStream_t s)
-{
-    static int blocks = 0, blocks_for = -1;  // per instantiation: resident workgroups on the chip, a multiple of 8
-    if (!blocks || blocks_for != g_pipe_waves) {
-        blocks_for = g_pipe_waves;
-        int dev = 0, per_cu = 0;
-        hipDeviceProp_t prop;
-        NF_HIP(hipGetDevice(&dev));
-        NF_HIP(hipGetDeviceProperties(&prop, dev));
-        NF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_flux_ww<T, VEC, UZ, DIAG>, kWwBlock, 0));
-        if (per_cu < 1) per_cu = 1;
-        if (per_cu > 4) per_cu = 4;  // every workgroup must be resident at once (bare barriers, static split)
-        if (g_pipe_waves > 0) per_cu = g_pipe_waves;
-        blocks = ((prop.multiProcessorCount * per_cu) / kXcds) * kXcds;
-        if (blocks < kXcds) blocks = kXcds;
-    }
-    hipLaunchKernelGGL((k_flux_ww<T, VEC, UZ, DIAG>), dim3((unsigned)blocks), dim3(kWwBlock), 0, s, (const T *)a.u,
-                       (const T *)a.v, a.ncell, (unsigned)a.ny, (unsigned)a.nx, a.z0, a.z1, a.thickness, a.arcE, a.arcN,
-                       (T)a.fill, a.scale, a.sverdrup, a.iV, a.absU, a.maxbits);
-    NF_HIP(hipGetLastError());
-    return NF_OK;
-}
-
-// Tuning variants of the vector path (NF_FLUX_VARIANT); 0 is the default.
+// Tuning variants of the vector path (NF_FLUX_VARIANT / nf_tuning_set("flux_variant")); 0 is the default.  Every variant the
+// product library accepts produces the same bits as the default (tests/test_gpu_configs.py); an unknown number runs the
+// default kernel.
 template <typename T, int VEC>
 static int launch_flux_v(const FluxArgs &a, hipStream_t s)
 {
     const int variant = a.batch.zr ? 0 : g_variant;  // the multi-step launch exists for the default kernel only
     if (a.signed_only) {  // compact resident mode: the caller expands on demand
         NF_REQUIRE(VEC > 1 && !a.batch.zr, NF_ERR_STATE, "flux: the compact mode needs 16-byte aligned fields, an even cell count and one step per launch");
-        return launch_flux_t<T, VEC, (sizeof(T) == 8 ? 10 : 8), true, 256, 1, 16>(a, s);   // same batches as the defaults
+        return launch_flux_t<T, VEC, (sizeof(T) == 8 ? 10 : 8), true, 256, 1, kFormSignedOnly>(a, s);   // same batches as the defaults
     }
     if (VEC == 1) return launch_flux_t<T, VEC, 8, true, 256, 1>(a, s);  // odd cell counts / unaligned fields: one cell per lane
     switch (variant) {
@@ -560,14 +386,17 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
         case 11: return launch_flux_t<T, VEC, 10, false, 256, 1>(a, s); // plain (temporal) loads: +4 %
         case 12: return launch_flux_t<T, VEC, 8, true, 256, 1>(a, s);   // 8 levels in flight
         case 14: return launch_flux_t<T, VEC, 16, true, 256, 1>(a, s);  // 16 levels in flight
+#ifdef NF_TUNING_BUILD
+        case 13: return launch_flux_t<T, VEC, 10, true, 256, 1, kDiagPlainStores>(a, s);  // plain instead of non-temporal stores
         case 40: return launch_flux_ww<T, VEC, 2>(a, s);                       // writer-wave form
         // diagnostic builds (WRONG RESULTS on purpose) that price one ingredient each
-        case 21: return launch_flux_t<T, VEC, 10, true, 256, 1, 1>(a, s);   // no stores
-        case 28: return launch_flux_t<T, VEC, 10, true, 256, 1, 16>(a, s);  // only the two signed planes
-        case 29: return launch_flux_t<T, VEC, 10, true, 256, 1, 32>(a, s);  // one interleaved (eU,eV) stream
+        case 21: return launch_flux_t<T, VEC, 10, true, 256, 1, kDiagNoStores>(a, s);     // no stores
+        case 28: return launch_flux_t<T, VEC, 10, true, 256, 1, kFormSignedOnly>(a, s);   // only the two signed planes, no expansion
+        case 29: return launch_flux_t<T, VEC, 10, true, 256, 1, kDiagInterleaved>(a, s);  // one interleaved (eU,eV) stream
         case 45: return launch_flux_ww<T, VEC, 2, 2>(a, s);                        // writer-wave, no stores
+#endif
         case 6: {  // the nested per-level load loop with the split store form: the defaults before the flat loop
-            const int rc = launch_flux_t<T, VEC, (sizeof(T) == 8 ? 10 : 8), true, 256, 1, 16 | 128>(a, s);
+            const int rc = launch_flux_t<T, VEC, (sizeof(T) == 8 ? 10 : 8), true, 256, 1, kFormSignedOnly | kFormNestedLoads>(a, s);
             return rc != NF_OK ? rc : launch_expand_planes(a.iV, a.absU, a.ncell, a.ny, a.nx, s);
         }
         case 5:    // the OTHER store form than the default's (float64: split, float32: fused)
@@ -580,7 +409,7 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
             constexpr int kLevels = sizeof(T) == 8 ? 10 : 8;
             const bool fused = a.batch.zr || ((sizeof(T) == 8) != (variant == 5));   // multi-step launch: always fused
             if (fused) return launch_flux_t<T, VEC, kLevels, true, 256, 1>(a, s);
-            const int rc = launch_flux_t<T, VEC, kLevels, true, 256, 1, 16>(a, s);
+            const int rc = launch_flux_t<T, VEC, kLevels, true, 256, 1, kFormSignedOnly>(a, s);
             if (rc != NF_OK) return rc;
             if (a.mid_event) {
                 NF_HIP(hipEventRecord(a.mid_event, s));

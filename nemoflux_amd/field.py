@@ -451,8 +451,9 @@ class Field(object):
         return ce, w, sg
 
     # timing hooks for bench.py
-    def enableKernelTiming(self, on=True):
-        check(lib.nf_field_timing(ctypes.byref(self._h), 1 if on else 0))
+    def enableKernelTiming(self, on=True, reserve=0):
+        """reserve: number of launches whose events are created now, outside the timed region"""
+        check(lib.nf_field_timing(ctypes.byref(self._h), max(1, int(reserve)) if on else 0))
 
     def readKernelTiming(self, split=False):
         """(launches, total ms) of the timed steps since enableKernelTiming; split=True appends the flux-kernel and the
