@@ -11,8 +11,10 @@ Workload at N=1 (config C4 of BASELINE.json, the one the metric is quoted on; it
 A "step" = one pass over all (t,z) slabs this rank owns (12 launches of the flux kernel + the transect
 reduction per time step), followed -- for N>1 -- by ONE RCCL all-reduce of the (nt, nseg+ntransect) rows.
 
-Scaling: weak (default; every rank owns a C4-sized block of 12 time steps of a 12*N-step series) or strong
-(--scaling strong: the 900 slabs of C4 are cut into N contiguous ranges).
+Scaling: strong by default -- BASELINE config 4 is the FIXED 3600 x 1800 x 75 x 12 problem "nt x nz sharded over
+8 x MI355X": its 900 (t,z) slabs are cut into N contiguous ranges, one per rank (11.7 GB of u,v per GPU at N=8).
+--scaling weak gives every rank a C4-sized block of 12 time steps of a 12*N-step series instead.
+At N=1 the line also carries a float32 sub-record (the dtype of real NEMO files) and the CPU baseline.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
@@ -31,18 +33,35 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def make_transects(nx, ny, xmin, xmax, ymin, ymax, nbatch, seed=20260401):
-    """README.md:51 singular transect + `nbatch` seeded polylines: 8-64 vertices snapped to grid
-    nodes, |lat| <= 80, half of them closed, all inside the lon box and clear of column 0: psi is not x-periodic,
-    and the west slot of column 0 is always the periodic copy of column nx-1 (field.py:223), so a polyline that
-    cuts through column 0 would not see psi(-180, .)."""
+def make_transects(nx, ny, xmin, xmax, ymin, ymax, nbatch, seed=20260401, seam=False):
+    """Transect batch of SURVEY 8d C5: `nbatch` seeded polylines of 8-64 vertices snapped to grid nodes, |lat| <= 80, every
+    second one closed.
+
+    seam=False (the bench, psi = the singular arctan2 case): README.md:51's singular transect first; all vertices
+    inside the lon box and clear of column 0 -- that psi is not x-periodic, and the west slot of column 0 is always the
+    periodic copy of column nx-1 (field.py:223), so a polyline that cuts through column 0 would not see psi(-180, .).
+    seam=True (for x-periodic psi): node columns are drawn from [-nx/4, nx + nx/4], i.e. longitudes from xmin - 90 to
+    xmax + 90, so the polylines cross the +-180 seam and column 0 in both directions; three fixed polylines come first:
+    one across the seam eastwards, one that runs ALONG the seam (every piece shared by column nx-1 and the periodic
+    image of column 0) and one westwards given with longitudes below -180."""
     dx, dy = (xmax - xmin) / nx, (ymax - ymin) / ny
-    polys = [[(-180., -80.), (-10., -80.), (-10., 80.), (-180., 80.)]]
     rng = numpy.random.default_rng(seed)
     jlo, jhi = int(numpy.ceil((-80. - ymin) / dy)), int(numpy.floor((80. - ymin) / dy))
+    if seam:
+        def node(i, j):
+            return (xmin + int(i) * dx, ymin + int(j) * dy)
+        j0, q = ny // 2, max(1, ny // 9)
+        e = max(1, nx // 36)
+        polys = [[node(nx - e, j0 - 3 * q), node(nx + e, j0 - q), node(nx + 2 * e, j0 + 2 * q)],
+                 [node(nx - 3 * e, j0 - 2 * q), node(nx, j0 - 2 * q), node(nx, j0 + 2 * q), node(nx + 3 * e, j0 + 2 * q)],
+                 [node(e, j0 + q), node(-e, j0 + 3 * q), node(-2 * e, j0 - 2 * q)]]
+        ilo, ihi = -(nx // 4), nx + nx // 4
+    else:
+        polys = [[(-180., -80.), (-10., -80.), (-10., 80.), (-180., 80.)]]
+        ilo, ihi = 1, nx
     for p in range(nbatch):
         n = int(rng.integers(8, 65))
-        i = rng.integers(1, nx + 1, size=n)
+        i = rng.integers(ilo, ihi + 1, size=n)
         j = rng.integers(jlo, jhi + 1, size=n)
         pts = [(xmin + int(a) * dx, ymin + int(b) * dy) for a, b in zip(i, j)]
         if p % 2 == 1:
@@ -51,47 +70,29 @@ def make_transects(nx, ny, xmin, xmax, ymin, ymax, nbatch, seed=20260401):
     return polys
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--nx', type=int, default=3600)
-    ap.add_argument('--ny', type=int, default=1800)
-    ap.add_argument('--nz', type=int, default=75)
-    ap.add_argument('--nt', type=int, default=12, help='time steps per rank (weak) or in total (strong)')
-    ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-    ap.add_argument('--batch', type=int, default=64, help='number of extra seeded transects')
-    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
-    ap.add_argument('--compact', action='store_true',
-                    help='NOT the headline configuration: keep only (eU, eV) resident per step (nf_field_set_compact); the '
-                         '(ncell,4) copies and |.| arrays are derived at read-back, which a batch driver never asks for')
-    args = ap.parse_args()
-
+def run_workload(args, dtype, scaling, rank, world, local, want_totals=False):
+    """Generate the workload on the device, time `steps` passes, check the accuracy.  Returns a dict of measurements."""
+    import contextlib
+    import ctypes
+    import io
     import torch
     import torch.distributed as dist
     from nemoflux_amd import dist as nfdist
-    from nemoflux_amd._lib import DeviceArray
+    from nemoflux_amd._lib import DeviceArray, lib, check
     from nemoflux_amd.datagen import DataGen, STREAM_FUNCTIONS
     from nemoflux_amd.field import Field
     from nemoflux_amd.fluxexact import exactFlux
 
-    rank, world, local = nfdist.init_from_env()
-    if world != args.gpus and rank == 0:
-        print(f'# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: nemoflux_amd has no CPU fallback')
-    torch.cuda.set_device(local)
-
     nx, ny, nz = args.nx, args.ny, args.nz
     psi = STREAM_FUNCTIONS[5]
-    nt_global = args.nt * world if args.scaling == 'weak' else args.nt
+    nt_global = args.nt * world if scaling == 'weak' else args.nt
     srange = nfdist.slab_range(nt_global, nz, rank, world)
     t_begin, t_end = nfdist.time_steps_touched(srange, nz)
-    real = 'float64' if args.dtype == 'f64' else 'float32'
+    if t_end <= t_begin:        # more ranks than slabs: this rank owns nothing, but its pointers must still be valid
+        t_begin, t_end = 0, 1
+    real = 'float64' if dtype == 'f64' else 'float32'
 
-    # ---- synthetic input, generated on the device (datagen.py counterpart)
+    # ---- synthetic input, generated on the device (datagen.py counterpart): only the time steps this rank touches
     dg = DataGen(real=real)
     dg.setSizes(nx, ny, nz, nt_global)
     dg.setBoundingBox(-180., 180., -90., 90., 0., 1.)
@@ -105,15 +106,11 @@ def main():
     xyzs = [numpy.array([(x, y, 0.) for x, y in p]) for p in polys]
     stream = torch.cuda.current_stream().cuda_stream
     t0 = time.time()
-    import io, contextlib
     with contextlib.redirect_stdout(io.StringIO()):
         fld = Field.fromArrays(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, ug, vg, xyzs, slab_range=srange,
                                readback=False, stream=stream, compact=args.compact)
     setup_s = time.time() - t0
     rows = torch.zeros((nt_global, fld._rowlen), dtype=torch.float64, device='cuda')
-
-    from nemoflux_amd._lib import lib, check
-    import ctypes
 
     def step():
         check(lib.nf_field_compute_all_async(ctypes.byref(fld._h), ctypes.c_void_p(rows.data_ptr())))
@@ -131,7 +128,8 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    fld.enableKernelTiming(True)
+    # events for every launch of the timed region are created here, outside it
+    fld.enableKernelTiming(True, reserve=args.steps * max(1, t_end - t_begin))
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -144,11 +142,27 @@ def main():
     fld.enableKernelTiming(False)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        nfdist.all_reduce(tt, dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     units_total = float(nt_global) * nz * ny * nx
-    value = units_total * args.steps / elapsed
+    m = {'value': units_total * args.steps / elapsed, 'ms_per_step': elapsed / args.steps * 1e3,
+         'nt_global': nt_global, 'setup_s': setup_s, 'psi': psi, 'polys': polys, 'nseg': fld._nseg,
+         'weight_entries': int(fld.getWeights()[0].size), 'dg': dg, 'u': u, 'v': v, 'xyz0': xyzs[0]}
+
+    # ---- the one collective of the N>1 path, timed on its own after the timed region (message = the rows)
+    if world > 1:
+        reps = 20
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            nfdist.reduce_rows(rows)
+        torch.cuda.synchronize()
+        m['reduce'] = {'message_bytes': int(rows.numel() * rows.element_size()), 'op': 'all_reduce(SUM, float64)',
+                       'backend': dist.get_backend(), 'allreduce_ms': round((time.perf_counter() - t0) / reps * 1e3, 4),
+                       'calls_per_step': 1}
+        step()                       # the rows the accuracy block reads: one clean pass after the repeated reduces
 
     # ---- accuracy: every transect total of every time step vs the closed form (fluxexact.py:36-46)
     res = rows.cpu().numpy()
@@ -159,10 +173,13 @@ def main():
         got = res[:, nseg + p]
         max_err = max(max_err, float(numpy.abs(got - numpy.array(ex)).max()))
         max_ref = max(max_ref, float(numpy.abs(ex).max()))
-    singular_t0 = float(res[0, nseg + 0])
+    m['accuracy'] = {'max_abs_err_vs_fluxexact': max_err, 'max_abs_exact': max_ref,
+                     'singular_transect_t0': float(res[0, nseg + 0]), 'transect_steps_checked': len(polys) * nt_global}
+    if want_totals:
+        m['totals'] = res[:, nseg:nseg + len(polys)].tolist()
 
     # ---- roofline of the dominant kernel (vertical integral + edge flux), HIP events on its stream
-    s = 8 if args.dtype == 'f64' else 4
+    s = 8 if dtype == 'f64' else 4
     bytes_per_unit = 2 * s + 64.0 / nz                      # u,v reads + (arc 16 + iV 32 + abs 16)/nz
     if args.compact:
         bytes_per_unit = 2 * s + 32.0 / nz                  # compact mode: arc 16 + (eU, eV) 16 per column
@@ -172,60 +189,133 @@ def main():
     achieved = bytes_per_unit * units_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    wl_key = f'{nx}x{ny}x{nz}x{args.nt}_{args.dtype}' + ('_compact' if args.compact else '')
-    if os.path.exists(pmc):
+    wl_key = f'{nx}x{ny}x{nz}x{args.nt}_{dtype}' + ('_compact' if args.compact else '')
+    if world == 1 and os.path.exists(pmc):   # the PMC pass measured whole time steps (75 levels per launch): N=1 only
         with open(pmc) as f:
             traffic = json.load(f).get(wl_key, {}).get('hbm_bytes_per_launch')
-    roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                'kernel': 'nf::k_flux + nf::k_expand_planes (one event pair around both)' if expand_ms > 0 else 'nf::k_flux',
-                'avg_launch_ms': round(avg_ms, 4), 'launches': nlaunch,
-                'avg_ms_by_kernel': {'nf::k_flux': round(flux_ms / max(1, nlaunch), 4),
-                                     'nf::k_expand_planes': round(expand_ms / max(1, nlaunch), 4)},
-                'algorithmic_bytes_per_unit': round(bytes_per_unit, 3)}
+    m['roofline'] = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                     'traffic_source': 'profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command, '
+                                       'not measured in this run)' if traffic is not None else None,
+                     'kernel': 'nf::k_flux + nf::k_expand_planes (one event pair around both)' if expand_ms > 0 else 'nf::k_flux',
+                     'avg_launch_ms': round(avg_ms, 4), 'launches': nlaunch,
+                     'avg_ms_by_kernel': {'nf::k_flux': round(flux_ms / max(1, nlaunch), 4),
+                                          'nf::k_expand_planes': round(expand_ms / max(1, nlaunch), 4)},
+                     'algorithmic_bytes_per_unit': round(bytes_per_unit, 3),
+                     'units_per_launch': units_per_launch,
+                     'wall_frac': round(bytes_per_unit * units_total * (own / float(nt_global * nz)) /
+                                        (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+    del fld
+    return m
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--nx', type=int, default=3600)
+    ap.add_argument('--ny', type=int, default=1800)
+    ap.add_argument('--nz', type=int, default=75)
+    ap.add_argument('--nt', type=int, default=12, help='time steps in total (strong) or per rank (weak)')
+    ap.add_argument('--dtype', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--scaling', default='strong', choices=['weak', 'strong'],
+                    help='strong (default): the nt*nz slabs of the stated problem are cut N ways; weak: nt steps per rank')
+    ap.add_argument('--batch', type=int, default=64, help='number of extra seeded transects')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--no-f32', action='store_true', help='skip the float32 sub-record (N=1, --dtype f64 only)')
+    ap.add_argument('--dump-totals', action='store_true', help='add the (nt, ntransect) totals to the JSON (small grids)')
+    ap.add_argument('--compact', action='store_true',
+                    help='NOT the headline configuration: keep only (eU, eV) resident per step (nf_field_set_compact); the '
+                         '(ncell,4) copies and |.| arrays are derived at read-back, which a batch driver never asks for')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nemoflux_amd import dist as nfdist
+
+    rank, world, local = nfdist.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f'# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: nemoflux_amd has no CPU fallback')
+    torch.cuda.set_device(local)
+
+    nx, ny, nz = args.nx, args.ny, args.nz
+    m = run_workload(args, args.dtype, args.scaling, rank, world, local, want_totals=args.dump_totals)
+    slabs = m['nt_global'] * nz
     out = {
-        'metric': 'edge-flux integrals/sec', 'value': value, 'unit': 'integrals/s', 'n_gpus': world,
-        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'metric': 'edge-flux integrals/sec', 'value': m['value'], 'unit': 'integrals/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': m['ms_per_step'],
         'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype,
         'data': 'synthetic',
         'config': {'workload': f'C4 ORCA12-like {nx}x{ny}x{nz}x{args.nt}' +
-                               (' per GPU' if args.scaling == 'weak' else ' total') +
-                               f', psi={psi}, README singular transect + {args.batch} node-snapped transects',
-                   'nx': nx, 'ny': ny, 'nz': nz, 'nt_global': nt_global, 'transects': len(polys),
-                   'target_segments': nseg, 'weight_entries': int(fld.getWeights()[0].size), 'parallelism': f'(t,z)-slab sharding x{world}, 1 all-reduce',
+                               (f' per GPU (weak: {m["nt_global"]} time steps in total)' if args.scaling == 'weak' else
+                                f' in total (strong: {slabs} (t,z) slabs cut {world} way' + ('s' if world > 1 else '') + ')') +
+                               f', psi={m["psi"]}, README singular transect + {args.batch} node-snapped transects',
+                   'nx': nx, 'ny': ny, 'nz': nz, 'nt_global': m['nt_global'], 'transects': len(m['polys']),
+                   'target_segments': m['nseg'], 'weight_entries': m['weight_entries'],
+                   'parallelism': f'(t,z)-slab sharding x{world}, 1 all-reduce',
                    'resident_outputs': 'eU,eV only (compact, non-headline)' if args.compact else
                                        'integratedVelocity [4][ncell] + |eU|,|eV| every step',
-                   'setup_s': round(setup_s, 3)},
-        'roofline': roofline,
-        'accuracy': {'max_abs_err_vs_fluxexact': max_err, 'max_abs_exact': max_ref,
-                     'singular_transect_t0': singular_t0, 'transect_steps_checked': len(polys) * nt_global},
+                   'setup_s': round(m['setup_s'], 3)},
+        'roofline': m['roofline'],
+        'accuracy': m['accuracy'],
     }
+    if 'reduce' in m:
+        out['reduce'] = m['reduce']
+    if 'totals' in m:
+        out['totals'] = m['totals']
 
     # ---- CPU baseline (rank 0, N=1 only): the reference's numpy statements on one time step
     if rank == 0 and world == 1 and not args.no_cpu:
-        out['cpu_baseline'] = cpu_baseline(dg, u, v, nz, ny, nx, xyzs[0], args)
+        out['cpu_baseline'] = cpu_baseline(m['dg'], m['u'], m['v'], nz, ny, nx, m['polys'], args)
+
+    # ---- float32 inputs (real NEMO files are float32: SURVEY 2 row 13): same workload, same checks, short record
+    if world == 1 and args.dtype == 'f64' and not args.no_f32:
+        import gc
+        for k in ('dg', 'u', 'v'):
+            m.pop(k, None)
+        gc.collect()
+        torch.cuda.empty_cache()
+        m32 = run_workload(args, 'f32', args.scaling, rank, world, local)
+        r = m32['roofline']
+        out['f32'] = {'value': m32['value'], 'unit': 'integrals/s', 'ms_per_step': m32['ms_per_step'], 'dtype': 'f32',
+                      'roofline': {k: r[k] for k in ('achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source',
+                                                    'kernel', 'avg_launch_ms', 'launches', 'avg_ms_by_kernel',
+                                                    'algorithmic_bytes_per_unit', 'wall_frac')},
+                      'accuracy': m32['accuracy']}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(dg, u, v, nz, ny, nx, xyz0, args):
-    """Reference CPU path timed on this box's host cores: numpy restatement of field.py:157,161 (missing->0,
-    tensordot over z) + field.py:183-234 (edge fluxes) + the oracle's A7 for the README transect, on ONE time
-    step of the bench workload already in RAM (NetCDF I/O excluded, like the GPU side)."""
+def cpu_baseline(dg, u, v, nz, ny, nx, polys, args):
+    """Reference CPU path timed on this box's host cores, on ONE time step of the bench workload already in RAM (NetCDF
+    I/O excluded, like the GPU side).  Legs (SURVEY 8d "CPU baseline beside it"):
+      (i)  numpy restatement of field.py:157,161 (missing->0, tensordot over z) + field.py:183-234 (edge fluxes) + the
+           oracle's A7 for the README transect: default BLAS threads (= `value`, `cores`) and again with 1 thread;
+           the plain-C port of the same step with OpenMP;
+      (ii) the C restatement of the mint weights + getIntegral (A6+A7): one thread (like mint) on the README transect,
+           and on all host cores over a sample of the batch polylines (one polyline per thread)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import nf_oracle as o
     o.build()
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
         threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
     except Exception:
+        threadpool_limits = None
         threads = os.cpu_count()
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        ncores = os.cpu_count()
     uh, vh = u[0].cpu().numpy(), v[0].cpu().numpy()
     blon, blat = dg.bounds_lon.cpu().numpy(), dg.bounds_lat.cpu().numpy()
     pts = o.assemble_points(blon, blat)
+    xyz0 = numpy.array([(x, y, 0.) for x, y in polys[0]])
     t0 = time.perf_counter()
     arc = o.np_arc_lengths(pts)
     t_arc = time.perf_counter() - t0
@@ -234,18 +324,28 @@ def cpu_baseline(dg, u, v, nz, ny, nx, xyz0, args):
     t_w = time.perf_counter() - t0
     th = dg.zbot - dg.ztop
     st = o.EdgeFluxState(ny, nx)
+
+    def numpy_step():
+        U = o.np_read_field(uh, th)
+        V = o.np_read_field(vh, th)
+        o.np_edge_flux(st, U, V, arc)
+        return o.get_integral(w, st.integratedVelocity)
+
     best = 1e30
     reps = 0
     t_all = time.perf_counter()
     while reps < 3 or (time.perf_counter() - t_all < 10.0 and reps < 8):
         t0 = time.perf_counter()
-        U = o.np_read_field(uh, th)
-        V = o.np_read_field(vh, th)
-        o.np_edge_flux(st, U, V, arc)
-        tot = o.get_integral(w, st.integratedVelocity)
+        tot = numpy_step()
         best = min(best, time.perf_counter() - t0)
         reps += 1
     units = float(nz) * ny * nx
+    t_1 = None
+    if threadpool_limits is not None:        # the same statements with ONE BLAS thread, one repetition
+        with threadpool_limits(limits=1):
+            t0 = time.perf_counter()
+            numpy_step()
+            t_1 = time.perf_counter() - t0
     # the plain-C port (OpenMP over columns; OMP_NUM_THREADS or all host cores), same step
     t_c = 1e30
     for _ in range(2):
@@ -255,12 +355,39 @@ def cpu_baseline(dg, u, v, nz, ny, nx, xyz0, args):
         o.edge_flux(o.EdgeFluxState(ny, nx), Uc, Vc, arc)
         t_c = min(t_c, time.perf_counter() - t0)
     omp = os.environ.get('OMP_NUM_THREADS', str(os.cpu_count()))
+    # A6+A7 on all host cores: one polyline of the batch per thread (the C restatement releases the GIL under ctypes)
+    from concurrent.futures import ThreadPoolExecutor
+    sample = polys[1:1 + min(len(polys) - 1, max(4, min(32, ncores)))]
+    nseg_sample = sum(len(p) - 1 for p in sample)
+    t_a6 = None
+    if sample:
+        def one(p):
+            ww = o.polyline_weights(pts, numpy.array([(x, y, 0.) for x, y in p]))
+            return o.get_integral(ww, st.integratedVelocity)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=ncores) as ex:
+            list(ex.map(one, sample))
+        t_a6 = time.perf_counter() - t0
+    legs = {'numpy_default_threads_s_per_step': round(best, 4), 'numpy_threads': int(threads),
+            'numpy_1_thread_s_per_step': None if t_1 is None else round(t_1, 4),
+            'numpy_1_thread_integrals_per_s': None if t_1 is None else units / t_1,
+            'c_openmp_s_per_step': round(t_c, 4), 'c_openmp_threads': omp, 'c_openmp_integrals_per_s': units / t_c,
+            'numpy_arc_lengths_s': round(t_arc, 3),
+            'a6_a7_1_thread_s': round(t_w, 3), 'a6_a7_1_thread_segments': len(polys[0]) - 1,
+            'a6_a7_all_cores_s': None if t_a6 is None else round(t_a6, 3), 'a6_a7_all_cores_threads': ncores,
+            'a6_a7_all_cores_segments': nseg_sample,
+            'a6_a7_all_cores_segments_per_s': None if not t_a6 else nseg_sample / t_a6}
+    one_thread = 'n/a' if t_1 is None else f'{units / t_1:.3e} integrals/s ({t_1:.2f} s/step)'
+    a6 = 'n/a' if t_a6 is None else (f'{len(sample)} batch polylines ({nseg_sample} segments) on {ncores} threads, one '
+                                     f'polyline per thread: {t_a6:.2f} s')
     return {'value': units / best, 'unit': 'integrals/s', 'cores': int(threads), 'kind': 'port',
             'sample': f'1 of {args.nt} time steps of the bench workload ({nx}x{ny}x{nz}, {args.dtype}), best of {reps} '
                       f'reps of the numpy restatement of field.py:157-234 (+oracle A7, README transect): '
-                      f'{best:.3f} s/step; one-off: numpy arc lengths {t_arc:.2f} s, C restatement of the mint weights (A6, one '
-                      f'thread like mint, README transect over all {ny * nx} cells) {t_w:.2f} s; '
-                      f'C port of the same step with OpenMP ({omp} threads): {units / t_c:.3e} integrals/s; flux {tot:.6g}'}
+                      f'{best:.3f} s/step; the same with 1 BLAS thread, 1 rep: {one_thread}; one-off: numpy arc lengths '
+                      f'{t_arc:.2f} s; C restatement of the mint weights + getIntegral (A6+A7): one '
+                      f'thread like mint, README transect over all {ny * nx} cells {t_w:.2f} s; {a6}; '
+                      f'C port of the same step with OpenMP ({omp} threads): {units / t_c:.3e} integrals/s; flux {tot:.6g}',
+            'legs': legs}
 
 
 if __name__ == '__main__':

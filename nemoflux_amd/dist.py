@@ -53,10 +53,23 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def all_reduce(tensor, op=None, group=None):
+    """In-place all_reduce that also works for an HBM tensor over a host-only backend: RCCL ('nccl') reduces HBM tensors
+    directly over xGMI; gloo (CPU tests, and the rehearsal of N ranks on a one-GPU box) gets a host copy."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if tensor.is_cuda and dist.get_backend(group) != 'nccl':
+        host = tensor.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        tensor.copy_(host)
+    else:
+        dist.all_reduce(tensor, op=op, group=group)
+    return tensor
+
+
 def reduce_rows(rows, group=None):
     """Sum the per-rank partial rows in place (all ranks get the totals).  One collective."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(rows, op=dist.ReduceOp.SUM, group=group)
+        all_reduce(rows, dist.ReduceOp.SUM, group)
     return rows
 
 

@@ -1,9 +1,9 @@
-# Round-1 profile of the headline bench: kernel trace + stats, then HBM traffic counters in two separate PMC passes
+# Profile of the headline bench (float64 workload + float32 sub-record in one process): kernel trace + stats, then HBM traffic counters in two separate PMC passes
 # (MI355X_MICROARCH.md: FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2 -- they do not fit one pass).
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-R=${1:-r01}
+R=${1:-r02}
 mkdir -p gpurun_out/$R
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/$R/bench_trace.json 2> gpurun_out/$R/bench_trace.err
 echo "trace done"

@@ -51,25 +51,35 @@ def counter(sub, cname, kernel):
 
 
 # one time step = the flux kernel, plus -- in the split store form (float32 default) -- the streaming expansion of the
-# four derived planes: bench.py's HIP events bracket whatever a step launches, so that is what the traffic is summed over
-fetch, write = counter('pmc_fetch', 'FETCH_SIZE', 'k_flux'), counter('pmc_write', 'WRITE_SIZE', 'k_flux')
-xfetch, xwrite = counter('pmc_fetch', 'FETCH_SIZE', 'k_expand_planes'), counter('pmc_write', 'WRITE_SIZE', 'k_expand_planes')
+# four derived planes: bench.py's HIP events bracket whatever a step launches, so that is what the traffic is summed over.
+# bench.py runs the float64 workload and then the float32 one in the same process: the flux kernels are told apart by
+# their template argument, the expansion kernel belongs to whichever dtype runs the split form.
+bj = json.load(open(os.path.join(src, 'bench_trace.json')))
+c = bj['config']
 res = {}
-if fetch and write:
+legs = [(bj['dtype'], bj['roofline'])]
+if 'f32' in bj and bj['dtype'] == 'f64':
+    legs.append(('f32', bj['f32']['roofline']))
+for dtype, roof in legs:
+    kname = 'k_flux<double' if dtype == 'f64' else 'k_flux<float'
+    fetch, write = counter('pmc_fetch', 'FETCH_SIZE', kname), counter('pmc_write', 'WRITE_SIZE', kname)
+    if not (fetch and write):
+        continue
+    split = roof['avg_ms_by_kernel'].get('nf::k_expand_planes', 0) > 0
+    xfetch = counter('pmc_fetch', 'FETCH_SIZE', 'k_expand_planes') if split else []
+    xwrite = counter('pmc_write', 'WRITE_SIZE', 'k_expand_planes') if split else []
     f_kb, w_kb = sum(fetch) / len(fetch), sum(write) / len(write)
     xf_kb = sum(xfetch) / len(xfetch) if xfetch else 0.0
     xw_kb = sum(xwrite) / len(xwrite) if xwrite else 0.0
     # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the
     # bytes of a wide coalesced (16 B/lane) streaming read -> double it; WRITE_SIZE is exact for 16 B/lane stores.
     hbm = 2.0 * f_kb * 1024 + w_kb * 1024 + 2.0 * xf_kb * 1024 + xw_kb * 1024
-    bj = json.load(open(os.path.join(src, 'bench_trace.json')))
-    c = bj['config']
-    key = f"{c['nx']}x{c['ny']}x{c['nz']}x{c['nt_global']}_{bj['dtype']}"
-    res[key] = dict(kernel='nf::k_flux + nf::k_expand_planes' if xfetch or xwrite else 'nf::k_flux', launches_sampled=[len(fetch), len(write)],
+    key = f"{c['nx']}x{c['ny']}x{c['nz']}x{c['nt_global']}_{dtype}"
+    res[key] = dict(kernel='nf::k_flux + nf::k_expand_planes' if split else 'nf::k_flux', launches_sampled=[len(fetch), len(write)],
                     FETCH_SIZE_KiB_avg=f_kb, WRITE_SIZE_KiB_avg=w_kb, expand_FETCH_SIZE_KiB_avg=xf_kb,
                     expand_WRITE_SIZE_KiB_avg=xw_kb, fetch_correction='x2 (gfx950, 16 B/lane coalesced stream)',
                     hbm_bytes_per_launch=hbm,
-                    algorithmic_bytes_per_launch=bj['roofline']['algorithmic_bytes_per_unit'] * c['nz'] * c['ny'] * c['nx'])
+                    algorithmic_bytes_per_launch=roof['algorithmic_bytes_per_unit'] * c['nz'] * c['ny'] * c['nx'])
 with open(os.path.join(out, 'pmc_traffic.json'), 'w') as f:
     json.dump(res, f, indent=1)
 for fn in ('bench_trace.json',):

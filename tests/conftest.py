@@ -87,3 +87,23 @@ def write_classic_triple(dirname, g, version=2):
         var[:] = a
         f.close()
     return paths, u, v
+
+
+def exact_segment_fluxes(psi, polys, nz, nt, zmin=0., zmax=1.):
+    """Closed form per target SEGMENT: sum_k [psi(node s+1) - psi(node s)] dz_k for every time step --
+    fluxexact.py:36-46 applied to each piece of each polyline, vectorised over levels and vertices with the same
+    expression evaluator nemoflux_amd.fluxexact uses.  Returns one (nt, npts-1) array per polyline."""
+    from nemoflux_amd import _expr
+    code = _expr.compile_function(psi)
+    dz = (zmax - zmin) / float(nz)
+    zhalf = zmin + (numpy.arange(nz) + 0.5) * dz
+    out = []
+    for pts in polys:
+        xy = numpy.array(pts, dtype=numpy.float64)
+        seg = numpy.zeros((nt, xy.shape[0] - 1))
+        for t in range(nt):
+            phi = _expr.evaluate(code, x=xy[:, 0][:, None], y=xy[:, 1][:, None], z=zhalf[None, :], t=t, nt=nt)
+            phi = phi + numpy.zeros((xy.shape[0], nz))
+            seg[t] = ((phi[1:] - phi[:-1]) * dz).sum(axis=1)
+        out.append(seg)
+    return out

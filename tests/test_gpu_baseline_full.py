@@ -1,0 +1,100 @@
+"""GPU parity, part 3: BASELINE.json's configurations C4 and C5 at their STATED size -- 3600 x 1800 x 75 levels x 12
+time steps with the 64-transect batch -- with the checks SURVEY.md 8(d) specifies: every transect total against the
+closed form of fluxexact.py:36-46 AND every per-segment sum against psi(node s+1) - psi(node s) (sum_k dz and the
+(1+10z)(t+1) modulation applied); a second batch on an x-periodic psi whose polylines cross the +-180 seam and column 0;
+both at float64 and at float32 inputs (the dtype of real NEMO files).  93 GB (f64) / 47 GB (f32) of u,v are generated on
+the device and freed after each case.  Through the C ABI (Field.computeAll -> nf_field_compute_all_async)."""
+import gc
+
+import numpy
+import pytest
+
+import bench
+from conftest import exact_segment_fluxes
+
+pytestmark = pytest.mark.gpu
+
+NX, NY, NZ, NT = 3600, 1800, 75, 12
+BOX = (-180., 180., -90., 90.)
+
+
+def _run_case(psi, polys, real):
+    import contextlib
+    import io
+    import torch
+    from nemoflux_amd.datagen import DataGen
+    from nemoflux_amd.field import Field
+    dg = DataGen(real=real)
+    dg.setSizes(NX, NY, NZ, NT)
+    dg.setBoundingBox(*BOX, 0., 1.)
+    dg.build()
+    dg.applyStreamFunction(psi)
+    u, v = dg.computeUVFromPotential()
+    xyzs = [numpy.array([(x, y, 0.) for x, y in p]) for p in polys]
+    with contextlib.redirect_stdout(io.StringIO()):
+        fld = Field.fromArrays(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, u, v, xyzs, readback=False)
+    tot, segs = fld.computeAll()
+    tot2, segs2 = fld.computeAll()
+    assert numpy.array_equal(tot, tot2) and numpy.array_equal(segs, segs2)      # fixed summation tree
+    off = fld._tr_off.copy()
+    nrec = fld.getWeights()[0].size // 4
+    del fld, dg, u, v
+    gc.collect()
+    torch.cuda.empty_cache()
+    return tot, segs, off, nrec
+
+
+def _check(psi, polys, real, tot, segs, off):
+    from nemoflux_amd.fluxexact import exactFlux
+    assert tot.shape == (NT, len(polys)) and segs.shape == (NT, sum(len(p) - 1 for p in polys))
+    exact_segs = exact_segment_fluxes(psi, polys, NZ, NT)
+    # float64: rounding of the weighted sums only (generator and engine share the arc-length routine on un-rotated grids,
+    # SURVEY 7 "Hard parts").  float32: u, v carry 6e-8 relative rounding each, independent from edge to edge.
+    unit = 6.0 * (numpy.arange(NT) + 1)                     # sum_k dz (1+10 z_k) (t+1): the amplitude of step t
+    tol = (2e-12 if real == 'float64' else 5e-7) * unit
+    worst_seg = worst_tot = 0.0
+    for p, pts in enumerate(polys):
+        got = segs[:, off[p]:off[p + 1]]
+        err = numpy.abs(got - exact_segs[p])
+        assert numpy.all(err <= tol[:, None]), (p, float(err.max()))
+        worst_seg = max(worst_seg, float((err / unit[:, None]).max()))
+        ex = numpy.array(exactFlux(psi, pts, NZ, NT))       # the reference's closed form for the whole polyline
+        e2 = numpy.abs(tot[:, p] - ex)
+        assert numpy.all(e2 <= tol * max(1.0, numpy.sqrt(len(pts)))), (p, float(e2.max()))
+        assert numpy.allclose(got.sum(axis=1), tot[:, p], rtol=0, atol=1e-13 * unit.max() * len(pts))
+        if pts[0] == pts[-1]:                               # closed loops: zero net flux
+            assert numpy.all(numpy.abs(tot[:, p]) <= tol * numpy.sqrt(len(pts)))
+        worst_tot = max(worst_tot, float((e2 / unit).max()))
+    return worst_seg, worst_tot
+
+
+@pytest.mark.parametrize('real', ['float64', 'float32'])
+def test_c4_c5_full_size_singular_batch(real):
+    """C4 + C5: psi = (1+10z)(t+1) arctan2(y, x+180)/(2 pi) (README.md:50 x the z,t modulation); README.md:51's singular
+    transect -> 0.5 * 6 (t+1) (README.md:56), plus the 64 seeded node-snapped polylines of the bench."""
+    from nemoflux_amd.datagen import STREAM_FUNCTIONS
+    psi = STREAM_FUNCTIONS[5]
+    polys = bench.make_transects(NX, NY, *BOX, 64)
+    assert len(polys) == 65
+    tot, segs, off, nrec = _run_case(psi, polys, real)
+    assert nrec > 3_000_000                                 # the seg-reduce stress of C5: millions of weight records
+    _check(psi, polys, real, tot, segs, off)
+    t = numpy.arange(NT)
+    assert numpy.all(numpy.abs(tot[:, 0] - 0.5 * 6.0 * (t + 1)) <= (1e-11 if real == 'float64' else 2e-6) * (t + 1))
+
+
+@pytest.mark.parametrize('real', ['float64', 'float32'])
+def test_c5_full_size_seam_crossing_batch(real):
+    """C5 "some crossing the +-180 seam": x-periodic psi (menu entry 3), polylines with longitudes from -270 to 270 that
+    cross the seam and column 0 in both directions, one running along the seam itself; same per-segment and per-transect
+    checks.  Column 0's west slot being the periodic copy of column nx-1 (field.py:223) is exactly right for this psi."""
+    from nemoflux_amd.datagen import STREAM_FUNCTIONS
+    psi = STREAM_FUNCTIONS[3]
+    polys = bench.make_transects(NX, NY, *BOX, 64, seed=20260402, seam=True)
+    lons = numpy.concatenate([numpy.array(p)[:, 0] for p in polys])
+    assert lons.min() < -260. and lons.max() > 260.
+    ncross = sum(1 for p in polys for a, b in zip(p[:-1], p[1:])
+                 if (a[0] - 180.) * (b[0] - 180.) < 0 or (a[0] + 180.) * (b[0] + 180.) < 0)
+    assert ncross > 200                                     # hundreds of target segments cut through the seam
+    tot, segs, off, nrec = _run_case(psi, polys, real)
+    _check(psi, polys, real, tot, segs, off)

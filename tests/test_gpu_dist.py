@@ -105,6 +105,12 @@ def test_bench_contract_small_workload():
     assert c['kind'] == 'port' and c['value'] > 0 and c['cores'] >= 1 and c['unit'] == d['unit']
     assert d['accuracy']['max_abs_err_vs_fluxexact'] <= 1e-11 * max(1.0, d['accuracy']['max_abs_exact'])
     assert abs(d['value'] - 144 * 72 * 9 * 3 * 2 / (d['ms_per_step'] * 2e-3)) <= 1e-6 * d['value']
+    assert d['scaling'] == 'strong' and 'legs' in c and c['legs']['a6_a7_all_cores_s'] > 0
+    assert r['traffic'] is None and r['traffic_source'] is None       # no PMC pass exists for this toy workload
+    f = d['f32']                                                      # float32 sub-record of the same workload
+    assert f['dtype'] == 'f32' and f['value'] > 0 and f['roofline']['frac'] > 0
+    assert abs(f['roofline']['algorithmic_bytes_per_unit'] - (8 + 64.0 / 9)) < 1e-3
+    assert f['accuracy']['max_abs_err_vs_fluxexact'] <= 1e-5 * max(1.0, f['accuracy']['max_abs_exact'])
 
 
 def test_readme_examples_script():
@@ -135,3 +141,55 @@ def test_plain_c_client_of_the_abi(tmp_path):
     r = subprocess.run([build_c_client(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'C client OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'level 2: 5 segments, flux = 360.0000' in r.stdout and 'level 1: 648 cells, flux = 360.0000' in r.stdout
+
+
+def _bench_json(extra, nproc=1):
+    """Run bench.py on a small grid -- directly (N=1) or under torch.distributed.run with `nproc` ranks that all use
+    GPU 0 and reduce over gloo (NF_FORCE_DEVICE / NF_DIST_BACKEND: the rehearsal hook of nemoflux_amd.dist) -- exactly
+    the way the driver launches it; returns the parsed JSON line."""
+    import json
+    import subprocess
+    small = ['--nx', '144', '--ny', '72', '--nz', '9', '--batch', '6', '--steps', '2', '--warmup', '1', '--no-cpu',
+             '--no-f32', '--dump-totals'] + extra
+    env = dict(os.environ)
+    if nproc == 1:
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + small
+    else:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        env.update(NF_FORCE_DEVICE='0', NF_DIST_BACKEND='gloo')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+               '--gpus', str(nproc)] + small
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('scaling', ['strong', 'weak', 'default'])
+def test_bench_two_ranks_rehearsal(scaling):
+    """bench.py's own N>1 branch end to end (slab windows, virtual base, reduce, barrier, MAX of the elapsed time, the
+    JSON line from rank 0) with 2 ranks on the one GPU of this box: the transect totals must equal the N=1 run of the
+    same global problem to 1e-13 (the summation order differs), n_gpus == 2, and the default scaling is strong."""
+    nt = 3
+    args = [] if scaling == 'default' else ['--scaling', scaling]
+    two = _bench_json(['--nt', str(nt)] + args, nproc=2)
+    nt_global = 2 * nt if scaling == 'weak' else nt
+    one = _bench_json(['--nt', str(nt_global)])
+    assert two['n_gpus'] == 2 and one['n_gpus'] == 1
+    assert two['scaling'] == ('weak' if scaling == 'weak' else 'strong') and one['scaling'] == 'strong'
+    assert two['config']['nt_global'] == nt_global and ('strong' if scaling != 'weak' else 'weak') in two['config']['workload']
+    a, b = numpy.array(two['totals']), numpy.array(one['totals'])
+    assert a.shape == b.shape == (nt_global, 7)
+    assert numpy.abs(a - b).max() <= 1e-13 * numpy.abs(b).max()
+    assert two['accuracy']['max_abs_err_vs_fluxexact'] <= 1e-11 * max(1.0, two['accuracy']['max_abs_exact'])
+    red = two['reduce']
+    assert red['message_bytes'] == nt_global * (two['config']['target_segments'] + 7) * 8 and red['allreduce_ms'] > 0
+    assert red['backend'] == 'gloo' and 'cpu_baseline' not in two and 'reduce' not in one
+    units = 144 * 72 * 9 * nt_global
+    assert abs(two['value'] - units * 2 / (two['ms_per_step'] * 2e-3)) <= 1e-6 * two['value']
+    r = two['roofline']            # rank 0's kernel: half of the slabs
+    assert r['frac'] > 0 and r['launches'] >= 2

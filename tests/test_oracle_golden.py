@@ -269,3 +269,29 @@ def test_oracle_path_independence_random_psi(oracle):
         w = oracle.polyline_weights(pts, xyz)
         got = oracle.get_integral(w, data)
         assert abs(got - (psi[jb, ib] - psi[ja, ia])) <= 1e-11, trial
+
+
+def test_oracle_seam_crossing_batch_per_segment(oracle):
+    """SURVEY 8d C5 on a small grid, CPU only: a seeded batch of node-snapped polylines whose longitudes run from
+    -270 to 270 (crossing the +-180 seam and column 0, one of them running ALONG the seam) on an x-periodic psi: every
+    target segment must integrate to psi(node s+1) - psi(node s) summed over the levels (README.md:45,58; field.py:219-223
+    make column 0's west slot the periodic copy of column nx-1's east edge, which is what an x-periodic psi needs)."""
+    import bench
+    from conftest import exact_segment_fluxes
+    nx, ny, nz, nt = 72, 36, 3, 2
+    psi = "(1+10*z)*(t+1)*(cos(2*pi*y/360) + sin(2*pi*x/360))"
+    o = oracle.DataGen(nx, ny, nz, nt)
+    u, v = o.computeUV(psi)
+    pts = oracle.assemble_points(o.bounds_lon, o.bounds_lat)
+    arc = oracle.np_arc_lengths(pts)
+    polys = bench.make_transects(nx, ny, -180., 180., -90., 90., 12, seed=7, seam=True)
+    assert min(min(x for x, _ in p) for p in polys) < -200. and max(max(x for x, _ in p) for p in polys) > 200.
+    exact = exact_segment_fluxes(psi, polys, nz, nt)
+    weights = [oracle.polyline_weights(pts, numpy.array([(x, y, 0.) for x, y in p])) for p in polys]
+    st = oracle.EdgeFluxState(ny, nx)
+    for t in range(nt):
+        oracle.edge_flux(st, oracle.vertical_integral(u[t], o.thickness), oracle.vertical_integral(v[t], o.thickness), arc)
+        for p, w in enumerate(weights):
+            tot, segs = oracle.get_integral(w, st.integratedVelocity, True)
+            assert numpy.abs(segs - exact[p][t]).max() <= 2e-12 * 6 * (t + 1), (p, t)
+            assert abs(tot - exact[p][t].sum()) <= 2e-12 * 6 * (t + 1) * len(segs), (p, t)
