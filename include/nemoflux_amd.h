@@ -166,6 +166,13 @@ int nf_field_num_segments(nf_field **self, int *nseg_total);             /* over
 int nf_field_segment_offsets(nf_field **self, int *offsets /* ntransect+1 */);
 int nf_field_num_weights(nf_field **self, size_t *n);
 int nf_field_get_weights(nf_field **self, int64_t *cell_edge, double *weight, int *seg_global);
+/* The same weights as the engine's own reduction uses them: folded onto the unique edges of the resident signed planes.
+ * The south / west slots of integratedVelocity are copies of the neighbours' north / east values (field.py:219-223, row 0's
+ * south slot is never written), so each (cell, edge) weight belongs to one element of [eU | eV] (elem in [0, 2*ncell):
+ * eU[c] = c, eV[c] = ncell + c) and the weights that meet on an element are summed per target segment.  Sorted by
+ * (segment, elem).  mint has no counterpart; nf_field_get_weights above stays the mint-shaped view. */
+int nf_field_num_edge_weights(nf_field **self, size_t *n);
+int nf_field_get_edge_weights(nf_field **self, int *elem, int *seg_global, double *weight);
 /* Length of one output row: nseg_total + ntransect doubles = [per-segment sums | per-transect sums]. */
 int nf_field_row_length(nf_field **self, int *n);
 

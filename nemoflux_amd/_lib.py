@@ -99,6 +99,8 @@ _sig('nf_field_num_segments', [_pp, c_int_p])
 _sig('nf_field_segment_offsets', [_pp, c_int_p])
 _sig('nf_field_num_weights', [_pp, ctypes.POINTER(ctypes.c_size_t)])
 _sig('nf_field_get_weights', [_pp, c_int64_p, c_double_p, c_int_p])
+_sig('nf_field_num_edge_weights', [_pp, ctypes.POINTER(ctypes.c_size_t)])
+_sig('nf_field_get_edge_weights', [_pp, c_int_p, c_int_p, c_double_p])
 _sig('nf_field_row_length', [_pp, c_int_p])
 _sig('nf_field_compute_flux', [_pp, ctypes.c_long, c_double_p])
 _sig('nf_field_compute_all_async', [_pp, ctypes.c_void_p])

@@ -862,7 +862,7 @@ static int field_all_steps_batched(nf_field *f, double *rows_dev)
     }
     if (f->batch_version != f->version) {  // scratch follows the weight set, z ranges follow the slab ownership
         dev_free(f->d_scratchb);
-        NF_TRY(dev_alloc(&f->d_scratchb, (size_t)f->ws.nrec * f->nt));
+        NF_TRY(dev_alloc(&f->d_scratchb, (size_t)std::max(f->ws.nrec, f->ws.nent) * f->nt));
         std::vector<int> zr((size_t)2 * f->nt);
         const long s_end = f->s_end < 0 ? f->nt * f->nz : f->s_end;
         for (long t = 0; t < f->nt; ++t) {
@@ -1101,11 +1101,14 @@ try {
         f->tr_off.push_back((int)cc.size());
     }
     NF_TRY(build_weights(f->d_xy, f->ncell, segs.data(), cc.data(), (int)cc.size(), periodX, &f->ws, f->stream));
+    // the engine reduces its own planes: fold the (cell, edge) weights onto the unique edges of (eU, eV) (field.py:219-223)
+    static const bool fold = !(getenv("NF_FOLD_WEIGHTS") && atoi(getenv("NF_FOLD_WEIGHTS")) == 0);
+    if (fold) NF_TRY(fold_weights(&f->ws, f->ncell, f->nx, f->stream));
     dev_free(f->d_tr_off);
     dev_free(f->d_scratch);
     dev_free(f->d_row);
     NF_TRY(dev_alloc(&f->d_tr_off, f->tr_off.size()));
-    NF_TRY(dev_alloc(&f->d_scratch, (size_t)f->ws.nrec));
+    NF_TRY(dev_alloc(&f->d_scratch, (size_t)std::max(f->ws.nrec, f->ws.nent)));
     NF_TRY(dev_alloc(&f->d_row, (size_t)field_row_length(f)));
     NF_HIP(hipMemcpy(f->d_tr_off, f->tr_off.data(), sizeof(int) * f->tr_off.size(), hipMemcpyHostToDevice));
     f->weights_built = true;
@@ -1150,6 +1153,29 @@ try {
     if ((*self)->ws.nrec == 0) return NF_OK;
     NF_NEED_DEVICE();
     return weights_to_host((*self)->ws, cell_edge, weight, seg_global);
+}
+NF_API_CATCH
+int nf_field_num_edge_weights(nf_field **self, size_t *n)
+try {
+    NF_REQUIRE(self && *self && n, NF_ERR_ARG, "nf_field_num_edge_weights: null argument");
+    *n = (size_t)(*self)->ws.nent;
+    return NF_OK;
+}
+NF_API_CATCH
+int nf_field_get_edge_weights(nf_field **self, int *elem, int *seg_global, double *weight)
+try {
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_get_edge_weights: null field");
+    const WeightSet &ws = (*self)->ws;
+    if (ws.nent == 0) return NF_OK;
+    NF_NEED_DEVICE();
+    std::vector<WeightSet::EdgeEntry> h((size_t)ws.nent);
+    NF_HIP(hipMemcpy(h.data(), ws.ent, sizeof(WeightSet::EdgeEntry) * h.size(), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < h.size(); ++k) {   // pure re-indexing of the device result for the caller
+        if (elem) elem[k] = h[k].elem;
+        if (seg_global) seg_global[k] = h[k].seg;
+        if (weight) weight[k] = h[k].w;
+    }
+    return NF_OK;
 }
 NF_API_CATCH
 int nf_field_row_length(nf_field **self, int *n)

@@ -93,9 +93,23 @@ struct WeightSet {  // device-resident result: one record per (target segment, c
     int *seg = nullptr;        // global segment id of the record
     int nseg = 0;              // total target segments
     int *seg_start = nullptr;  // (nseg+1) CSR over records
+    // Unique-edge form for the engine's own planes (fold_weights): the south / west slots of integratedVelocity are copies
+    // of the neighbours' north / east values (field.py:219-223), so every (cell, edge) weight is folded onto the element
+    // of the two signed planes that really carries it and duplicates are merged per target segment (adjacent cells
+    // share an edge): about half as many entries as 4 per record, ONE gather each.
+    struct EdgeEntry {
+        int elem;   // index into [eU | eV] = planes 1 and 2 taken as one array of 2*ncell values
+        int seg;    // global target segment
+        double w;   // summed weight
+    };
+    long nent = 0;
+    EdgeEntry *ent = nullptr;    // sorted by (segment, elem)
+    int *ent_start = nullptr;    // (nseg+1) CSR over entries
     long entries() const { return 4 * nrec; }  // mint's view: (cell*4+edge, weight) entries
     void release();
 };
+// builds ws.ent / ws.ent_start from the records, for a grid of nx columns (row-0 south slots carry no flux: dropped)
+int fold_weights(WeightSet *ws, long ncell, long nx, hipStream_t s);
 // expands records into mint-style entries (host arrays): cell_edge = cell*4+edge, weight, seg
 int weights_to_host(const WeightSet &ws, int64_t *cell_edge, double *weight, int *seg);
 // segs_host: (nseg,4) = x0,y0,dx,dy ; seg_cc_host: counterclock flag per segment
@@ -108,6 +122,7 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
 // data: (ncell,4) AoS (planes = 0), [4][ncell] planes (planes = 1), or the engine's own planes read through their two
 // signed members only (planes = 2; needs nx for the neighbour indexing).
 // nsteps > 1: step tb gathers from data + tb*data_stride and writes row + tb*row_stride (scratch: nsteps*ws.nrec).
+// planes = 2 uses the unique-edge entries when fold_weights built them (scratch: nsteps * max(ws.nrec, ws.nent)).
 int launch_integral(const WeightSet &ws, const double *data, long ncell, int planes, long nx,
                     const int *tr_offsets_dev, int ntransect, double *scratch, double *row, hipStream_t s,
                     int nsteps = 1, long data_stride = 0, long row_stride = 0);

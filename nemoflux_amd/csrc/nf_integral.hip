@@ -3,6 +3,9 @@
 // Replaces  mint.PolylineIntegral.getIntegral(data, mint.CELL_BY_CELL_DATA) as driven by
 //           nemoflux/field.py:102 and nemoflux/fluxplot.py:56, for ALL transects of a Field at once.
 //
+// Two forms of stage A.  For the engine's own resident planes the weights come folded onto the unique edges
+// (k_gather_edges, below: one gather per entry); for caller-supplied (ncell,4) data -- mint's getIntegral -- the records
+// are used as they are:
 // Records (cell, 4 edge weights, global segment id) are sorted by segment (K2).  Stage A: one lane per
 // record gathers the cell's 4 edge values (either the reference's (ncell,4) AoS: one 32-B read, or the engine's
 // resident [4][ncell] planes), forms the weighted sum and runs a WAVEFRONT SEGMENTED SCAN keyed by the
@@ -70,6 +73,38 @@ __global__ __launch_bounds__(kBlock) void k_gather_segscan(const int *__restrict
     if (k < n && (lane == kWave - 1 || k == n - 1 || nk != key)) runsum[k] = val;
 }
 
+// Unique-edge form of stage A for the engine's own planes (WeightSet::EdgeEntry): one lane per (segment, plane element)
+// entry -- ONE 16-byte record load and ONE 8-byte gather from [eU | eV] -- then the same wavefront segmented scan.
+// Entries are sorted by (segment, element), so the gathers of neighbouring lanes walk the planes in ascending order.
+__global__ __launch_bounds__(kBlock) void k_gather_edges(const WeightSet::EdgeEntry *__restrict__ ent, long n,
+                                                         const double *__restrict__ data, long ncell,
+                                                         double *__restrict__ runsum, long data_stride)
+{
+    data += (long)blockIdx.y * data_stride + ncell;   // planes 1 (eU) and 2 (eV) are contiguous: one array of 2*ncell
+    runsum += (long)blockIdx.y * n;
+    const long k = (long)blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    double val = 0.0;
+    int key = -1;
+    if (k < n) {
+        typedef int ivec4 __attribute__((ext_vector_type(4)));
+        const ivec4 r = __builtin_nontemporal_load(reinterpret_cast<const ivec4 *>(ent + k));   // read-once stream
+        double w;
+        const int wbits[2] = {r.z, r.w};
+        __builtin_memcpy(&w, wbits, 8);
+        val = w * data[(unsigned)r.x];
+        key = r.y;
+    }
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const double pv = __shfl_up(val, o, kWave);
+        const int pk = __shfl_up(key, o, kWave);
+        if (lane >= o && pk == key) val += pv;
+    }
+    const int nk = __shfl_down(key, 1, kWave);
+    if (k < n && (lane == kWave - 1 || k == n - 1 || nk != key)) runsum[k] = val;
+}
+
 // one wavefront per target segment: stitch the per-wave run sums of the segment (one per 64-record wave it
 // spans) with a lane-strided sum and a butterfly
 __global__ __launch_bounds__(kBlock) void k_finalize_seg(const double *__restrict__ runsum,
@@ -114,6 +149,23 @@ int launch_integral(const WeightSet &ws, const double *data, long ncell, int pla
                     long data_stride, long row_stride)
 {
     const unsigned ny = (unsigned)(nsteps > 1 ? nsteps : 1);
+    if (planes == 2 && ws.ent_start) {   // the engine's own planes through the unique-edge entries
+        if (ws.nent > 0)
+            hipLaunchKernelGGL(k_gather_edges, dim3((unsigned)((ws.nent + kBlock - 1) / kBlock), ny), dim3(kBlock), 0, s,
+                               ws.ent, ws.nent, data, ncell, scratch, data_stride);
+        if (ws.nseg > 0) {
+            const unsigned nb = (unsigned)(((long)ws.nseg * kWave + kBlock - 1) / kBlock);
+            hipLaunchKernelGGL(k_finalize_seg, dim3(nb, ny), dim3(kBlock), 0, s, scratch, ws.ent_start, ws.nseg, row,
+                               ws.nent, row_stride);
+        }
+        if (ntransect > 0) {
+            const unsigned nb = (unsigned)(((long)ntransect * kWave + kBlock - 1) / kBlock);
+            hipLaunchKernelGGL(k_finalize_tr, dim3(nb, ny), dim3(kBlock), 0, s, tr_offsets_dev, ntransect, ws.nseg, row,
+                               row_stride);
+        }
+        NF_HIP(hipGetLastError());
+        return NF_OK;
+    }
     if (ws.nrec > 0) {
         hipLaunchKernelGGL(k_gather_segscan, dim3((unsigned)((ws.nrec + kBlock - 1) / kBlock), ny), dim3(kBlock), 0, s,
                            ws.cell, ws.w4, ws.seg, ws.nrec, data, ncell, planes, (unsigned)(nx > 0 ? nx : 1), scratch,

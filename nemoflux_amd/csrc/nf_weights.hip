@@ -26,6 +26,7 @@
 // No atomics, so the result is bitwise reproducible run to run.
 #include <cstring>  // rocprim's texture iterator needs host memset declared first
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <vector>
 
 #include "nf_common.h"
@@ -354,8 +355,77 @@ __global__ __launch_bounds__(kBlock) void k_expand(const unsigned long long *__r
 }
 
 
+// ---- unique-edge folding (see WeightSet::EdgeEntry) ---------------------------------------------------------------
+constexpr unsigned kNoElem = 0xffffffffu;   // row-0 south slot: never written, carries no flux (field.py:219)
+
+// 4 (key, weight) pairs per record: key = (segment << 32) | element of [eU | eV] that carries the slot
+__global__ __launch_bounds__(kBlock) void k_fold_keys(const int *__restrict__ cell, const double *__restrict__ w4,
+                                                      const int *__restrict__ seg, long nrec, long ncell, unsigned nx,
+                                                      unsigned long long *__restrict__ key, double *__restrict__ val)
+{
+    const long idx = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= 4 * nrec) return;
+    const long i = idx >> 2;
+    const int e = (int)(idx & 3);
+    const long c = cell[i];
+    const unsigned j = (unsigned)(c / nx), col = (unsigned)(c - (long)j * nx);
+    unsigned elem;
+    if (e == 0) elem = j > 0 ? (unsigned)(ncell + c - nx) : kNoElem;        // south = eV of the row below
+    else if (e == 1) elem = (unsigned)c;                                     // east  = eU
+    else if (e == 2) elem = (unsigned)(ncell + c);                           // north = eV
+    else elem = (unsigned)(col > 0 ? c - 1 : c - 1 + nx);                    // west  = eU of the left neighbour (periodic)
+    key[idx] = ((unsigned long long)(unsigned)seg[i] << 32) | elem;
+    val[idx] = w4[idx];
+}
+
+__global__ __launch_bounds__(kBlock) void k_fold_heads(const unsigned long long *__restrict__ key, long n,
+                                                       int *__restrict__ head)
+{
+    const long k = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    const unsigned long long me = key[k];
+    head[k] = ((unsigned)me != kNoElem) && (k == 0 || key[k - 1] != me);
+}
+
+// the first pair of every run of equal keys adds up its run (in sorted order: a fixed summation order) and writes the entry
+__global__ __launch_bounds__(kBlock) void k_fold_merge(const unsigned long long *__restrict__ key,
+                                                       const double *__restrict__ val, const int *__restrict__ head,
+                                                       const int *__restrict__ pos, long n,
+                                                       WeightSet::EdgeEntry *__restrict__ ent)
+{
+    const long k = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n || !head[k]) return;
+    const unsigned long long me = key[k];
+    double acc = val[k];
+    for (long m = k + 1; m < n && key[m] == me; ++m) acc += val[m];
+    WeightSet::EdgeEntry o;
+    o.elem = (int)(unsigned)me;
+    o.seg = (int)(me >> 32);
+    o.w = acc;
+    ent[pos[k]] = o;
+}
+
+__global__ __launch_bounds__(kBlock) void k_ent_bounds(const WeightSet::EdgeEntry *__restrict__ ent, long nent, int nseg,
+                                                       int *__restrict__ ent_start)
+{
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s > nseg) return;
+    long lo = 0, hi = nent;
+    while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if (ent[mid].seg < s) lo = mid + 1;
+        else hi = mid;
+    }
+    ent_start[s] = (int)lo;
+}
+
 void WeightSet::release()
 {
+    if (ent) (void)hipFree(ent);
+    if (ent_start) (void)hipFree(ent_start);
+    ent = nullptr;
+    ent_start = nullptr;
+    nent = 0;
     if (cell) (void)hipFree(cell);
     if (w4) (void)hipFree(w4);
     if (seg) (void)hipFree(seg);
@@ -391,6 +461,60 @@ struct DevBuf {  // frees on scope exit
     template <typename T> T *as() { return reinterpret_cast<T *>(p); }
 };
 }  // namespace
+
+int fold_weights(WeightSet *ws, long ncell, long nx, hipStream_t s)
+{
+    if (ws->ent) (void)hipFree(ws->ent);
+    if (ws->ent_start) (void)hipFree(ws->ent_start);
+    ws->ent = nullptr;
+    ws->ent_start = nullptr;
+    ws->nent = 0;
+    NF_REQUIRE(nx > 0 && ncell > 0 && ncell % nx == 0 && 2 * ncell < (long)kNoElem, NF_ERR_ARG, "fold_weights: bad grid sizes");
+    NF_REQUIRE(ws->nrec < (1l << 29), NF_ERR_ARG, "fold_weights: too many records");
+    NF_HIP(hipMalloc((void **)&ws->ent_start, sizeof(int) * (size_t)(ws->nseg + 1)));
+    if (ws->nrec == 0) {
+        NF_HIP(hipMemsetAsync(ws->ent_start, 0, sizeof(int) * (size_t)(ws->nseg + 1), s));
+        return NF_OK;
+    }
+    const long n = 4 * ws->nrec;
+    const unsigned nb = (unsigned)((n + kBlock - 1) / kBlock);
+    DevBuf k_in, k_out, v_in, v_out, tmp, head, pos;
+    NF_HIP(k_in.alloc(sizeof(unsigned long long) * n));
+    NF_HIP(k_out.alloc(sizeof(unsigned long long) * n));
+    NF_HIP(v_in.alloc(sizeof(double) * n));
+    NF_HIP(v_out.alloc(sizeof(double) * n));
+    hipLaunchKernelGGL(k_fold_keys, dim3(nb), dim3(kBlock), 0, s, ws->cell, ws->w4, ws->seg, ws->nrec, ncell, (unsigned)nx,
+                       k_in.as<unsigned long long>(), v_in.as<double>());
+    int bits = 1;
+    while ((1l << bits) < (long)ws->nseg + 1 && bits < 24) ++bits;
+    size_t tmp_bytes = 0;
+    NF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned long long *)k_in.p, k_out.as<unsigned long long>(),
+                                     (const double *)v_in.p, v_out.as<double>(), (size_t)n, 0u, (unsigned)(32 + bits), s));
+    NF_HIP(tmp.alloc(tmp_bytes));
+    NF_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (const unsigned long long *)k_in.p, k_out.as<unsigned long long>(),
+                                     (const double *)v_in.p, v_out.as<double>(), (size_t)n, 0u, (unsigned)(32 + bits), s));
+    NF_HIP(head.alloc(sizeof(int) * n));
+    NF_HIP(pos.alloc(sizeof(int) * n));
+    hipLaunchKernelGGL(k_fold_heads, dim3(nb), dim3(kBlock), 0, s, k_out.as<unsigned long long>(), n, head.as<int>());
+    DevBuf tmp2;
+    size_t tmp2_bytes = 0;
+    NF_HIP(rocprim::exclusive_scan(nullptr, tmp2_bytes, head.as<int>(), pos.as<int>(), 0, (size_t)n, rocprim::plus<int>(), s));
+    NF_HIP(tmp2.alloc(tmp2_bytes));
+    NF_HIP(rocprim::exclusive_scan(tmp2.p, tmp2_bytes, head.as<int>(), pos.as<int>(), 0, (size_t)n, rocprim::plus<int>(), s));
+    int last_pos = 0, last_head = 0;
+    NF_HIP(hipMemcpyAsync(&last_pos, pos.as<int>() + (n - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+    NF_HIP(hipMemcpyAsync(&last_head, head.as<int>() + (n - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+    NF_HIP(hipStreamSynchronize(s));
+    ws->nent = (long)last_pos + last_head;
+    NF_HIP(hipMalloc((void **)&ws->ent, sizeof(WeightSet::EdgeEntry) * (size_t)(ws->nent ? ws->nent : 1)));
+    hipLaunchKernelGGL(k_fold_merge, dim3(nb), dim3(kBlock), 0, s, k_out.as<unsigned long long>(), v_out.as<double>(),
+                       head.as<int>(), pos.as<int>(), n, ws->ent);
+    hipLaunchKernelGGL(k_ent_bounds, dim3((unsigned)((ws->nseg + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, ws->ent,
+                       ws->nent, ws->nseg, ws->ent_start);
+    NF_HIP(hipGetLastError());
+    NF_HIP(hipStreamSynchronize(s));
+    return NF_OK;
+}
 
 int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
                   double periodX, WeightSet *out, hipStream_t s)

@@ -450,6 +450,18 @@ class Field(object):
                                        sg.ctypes.data_as(_lib.c_int_p)))
         return ce, w, sg
 
+    def getEdgeWeights(self):
+        """(element of [eU | eV], weight, global segment id): the weights folded onto the unique edges of the two signed
+        planes, which is what the on-device reduction gathers (one value per entry)."""
+        n = ctypes.c_size_t()
+        check(lib.nf_field_num_edge_weights(ctypes.byref(self._h), ctypes.byref(n)))
+        el = numpy.empty(n.value, numpy.int32)
+        sg = numpy.empty(n.value, numpy.int32)
+        w = numpy.empty(n.value, numpy.float64)
+        check(lib.nf_field_get_edge_weights(ctypes.byref(self._h), el.ctypes.data_as(_lib.c_int_p),
+                                            sg.ctypes.data_as(_lib.c_int_p), _lib.dptr(w)))
+        return el, w, sg
+
     # timing hooks for bench.py
     def enableKernelTiming(self, on=True, reserve=0):
         """reserve: number of launches whose events are created now, outside the timed region"""

@@ -813,3 +813,50 @@ def test_kernel_timing_split(real):
     assert (expand == 0.0) == (real == 'float64')
     assert fld.readKernelTiming() == (0, 0.0)          # reading resets
     fld.enableKernelTiming(False)
+
+
+@pytest.mark.parametrize('rotated', [False, True])
+def test_unique_edge_weights_are_the_folded_mint_weights(rotated):
+    """K3 gathers ONE value per entry: the (cell, edge) weights folded onto the element of (eU, eV) that carries the slot
+    (S of row j -> eV of row j-1, W -> eU of the left neighbour incl. the periodic wrap, row 0's south slot dropped:
+    field.py:219-223) and merged per target segment.  The folded set must be exactly that re-indexing of the mint-shaped
+    weights, and the rows it produces must agree with the record form run on the (ncell,4) array (mint's getIntegral)."""
+    import bench
+    from nemoflux_amd import mint
+    nx, ny, nz, nt = 72, 36, 3, 2
+    dg = device_case(nx, ny, nz, nt, PSI_ZT, (20., 30.) if rotated else (0., 0.))
+    polys = bench.make_transects(nx, ny, -180., 180., -90., 90., 10, seed=11, seam=True)
+    polys.append([(-180., -90.), (180., -90.), (180., -85.), (-175., -85.)])      # row 0: south slots carry nothing
+    xyzs = [numpy.array([(x, y, 0.) for x, y in p]) for p in polys]
+    fld = quiet_field(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, xyzs)
+    ce, w, sg = fld.getWeights()
+    el, we, sge = fld.getEdgeWeights()
+    ncell = nx * ny
+    cell, edge = ce // 4, ce % 4
+    j, i = cell // nx, cell % nx
+    elem = numpy.where(edge == 0, ncell + cell - nx, numpy.where(edge == 1, cell, numpy.where(edge == 2, ncell + cell,
+                       numpy.where(i > 0, cell - 1, cell - 1 + nx))))
+    keep = ~((edge == 0) & (j == 0))
+    want = {}
+    for s_, e_, w_ in zip(sg[keep].tolist(), elem[keep].tolist(), w[keep].tolist()):
+        want[(s_, e_)] = want.get((s_, e_), 0.0) + w_
+    got = dict(zip(zip(sge.tolist(), el.tolist()), we.tolist()))
+    assert len(got) == el.size and set(got) == set(want)                 # merged: every (segment, element) once
+    assert max(abs(got[k] - want[k]) for k in want) <= 4 * EPS
+    assert el.size < 0.75 * ce.size                                       # adjacent cells share their edge
+    order = numpy.lexsort((el, sge))
+    assert numpy.array_equal(order, numpy.arange(el.size))               # sorted by (segment, element)
+    for t in range(nt):
+        tot = fld.computeFlux(t, readback=True)
+        segs = numpy.concatenate(fld.getSegmentFluxes())
+        iv = fld.integratedVelocity
+        bound = 1e-12 * numpy.abs(w * iv.reshape(-1)[ce]).sum()
+        for p, xyz in enumerate(xyzs):
+            pli = mint.PolylineIntegral()
+            pli.setGrid(fld.gr.getMintGrid())
+            pli.buildLocator(numCellsPerBucket=128, periodX=360., enableFolding=False)
+            pli.computeWeights(xyz, counterclock=False)
+            assert abs(pli.getIntegral(iv, mint.CELL_BY_CELL_DATA) - tot[p]) <= bound
+        direct = numpy.zeros(fld._nseg)
+        numpy.add.at(direct, sg, w * iv.reshape(-1)[ce])
+        assert numpy.abs(direct - segs).max() <= bound
