@@ -189,6 +189,11 @@ try {
         g_batch_steps = value;
         return NF_OK;
     }
+    if (!strcmp(name, "edge_weights")) {   // K3 on the engine's planes: 1 = unique-edge entries (built by the next
+                                           // nf_field_build_weights), 0 = (cell, 4 weights) records (default)
+        integral_use_edges(value);
+        return NF_OK;
+    }
     int rc = tuning_set(name, value);
     NF_REQUIRE(rc == NF_OK, NF_ERR_ARG, std::string("nf_tuning_set: unknown knob ") + name);
     return NF_OK;
@@ -1102,8 +1107,8 @@ try {
     }
     NF_TRY(build_weights(f->d_xy, f->ncell, segs.data(), cc.data(), (int)cc.size(), periodX, &f->ws, f->stream));
     // the engine reduces its own planes: fold the (cell, edge) weights onto the unique edges of (eU, eV) (field.py:219-223)
-    static const bool fold = !(getenv("NF_FOLD_WEIGHTS") && atoi(getenv("NF_FOLD_WEIGHTS")) == 0);
-    if (fold) NF_TRY(fold_weights(&f->ws, f->ncell, f->nx, f->stream));
+    // (only on request -- nf_tuning_set("edge_weights", 1) -- because the records measure faster: see nf_integral.hip)
+    if (integral_uses_edges()) NF_TRY(fold_weights(&f->ws, f->ncell, f->nx, f->stream));
     dev_free(f->d_tr_off);
     dev_free(f->d_scratch);
     dev_free(f->d_row);

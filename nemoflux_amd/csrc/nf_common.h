@@ -123,6 +123,8 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
 // signed members only (planes = 2; needs nx for the neighbour indexing).
 // nsteps > 1: step tb gathers from data + tb*data_stride and writes row + tb*row_stride (scratch: nsteps*ws.nrec).
 // planes = 2 uses the unique-edge entries when fold_weights built them (scratch: nsteps * max(ws.nrec, ws.nent)).
+void integral_use_edges(int on);
+int integral_uses_edges();
 int launch_integral(const WeightSet &ws, const double *data, long ncell, int planes, long nx,
                     const int *tr_offsets_dev, int ntransect, double *scratch, double *row, hipStream_t s,
                     int nsteps = 1, long data_stride = 0, long row_stride = 0);

@@ -144,12 +144,20 @@ __global__ __launch_bounds__(kBlock) void k_finalize_tr(const int *__restrict__ 
     if (lane == 0) row[nseg + p] = part;
 }
 
+// "edge_weights" tuning knob.  Default 0: measured in-process on the 65-transect bench batch (tools/ab_pass.py,
+// profiles/r02_ab_pass_edges.txt) the unique-edge form is 0.4 % SLOWER per pass than the records (90 vs 85.5 us per step): a
+// line shares only the edge it crosses with the next cell, so folding leaves 3 entries per record, not 2 -- 48 B of stream
+// instead of 40 B -- and the 64-B sectors the gathers pull are the same ones either way.
+static int g_use_edges = 0;
+void integral_use_edges(int on) { g_use_edges = on; }
+int integral_uses_edges() { return g_use_edges; }
+
 int launch_integral(const WeightSet &ws, const double *data, long ncell, int planes, long nx,
                     const int *tr_offsets_dev, int ntransect, double *scratch, double *row, hipStream_t s, int nsteps,
                     long data_stride, long row_stride)
 {
     const unsigned ny = (unsigned)(nsteps > 1 ? nsteps : 1);
-    if (planes == 2 && ws.ent_start) {   // the engine's own planes through the unique-edge entries
+    if (planes == 2 && ws.ent_start && g_use_edges) {   // the engine's own planes through the unique-edge entries
         if (ws.nent > 0)
             hipLaunchKernelGGL(k_gather_edges, dim3((unsigned)((ws.nent + kBlock - 1) / kBlock), ny), dim3(kBlock), 0, s,
                                ws.ent, ws.nent, data, ncell, scratch, data_stride);

@@ -823,11 +823,23 @@ def test_unique_edge_weights_are_the_folded_mint_weights(rotated):
     weights, and the rows it produces must agree with the record form run on the (ncell,4) array (mint's getIntegral)."""
     import bench
     from nemoflux_amd import mint
+    from nemoflux_amd._lib import lib, check
     nx, ny, nz, nt = 72, 36, 3, 2
     dg = device_case(nx, ny, nz, nt, PSI_ZT, (20., 30.) if rotated else (0., 0.))
     polys = bench.make_transects(nx, ny, -180., 180., -90., 90., 10, seed=11, seam=True)
     polys.append([(-180., -90.), (180., -90.), (180., -85.), (-175., -85.)])      # row 0: south slots carry nothing
     xyzs = [numpy.array([(x, y, 0.) for x, y in p]) for p in polys]
+    ref = quiet_field(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, xyzs)     # default: record form
+    assert ref.getEdgeWeights()[0].size == 0
+    check(lib.nf_tuning_set(b'edge_weights', 1))       # optional form (measured 0.4 % slower per pass: not the default)
+    try:
+        _edge_form_checks(dg, xyzs, ref, nx, ny, nt)
+    finally:
+        check(lib.nf_tuning_set(b'edge_weights', 0))
+
+
+def _edge_form_checks(dg, xyzs, ref, nx, ny, nt):
+    from nemoflux_amd import mint
     fld = quiet_field(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, xyzs)
     ce, w, sg = fld.getWeights()
     el, we, sge = fld.getEdgeWeights()
@@ -860,3 +872,4 @@ def test_unique_edge_weights_are_the_folded_mint_weights(rotated):
         direct = numpy.zeros(fld._nseg)
         numpy.add.at(direct, sg, w * iv.reshape(-1)[ce])
         assert numpy.abs(direct - segs).max() <= bound
+        assert numpy.abs(numpy.array(ref.computeFlux(t)) - numpy.array(tot)).max() <= bound     # record form, same planes
