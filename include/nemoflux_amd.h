@@ -94,7 +94,10 @@ int mnt_polylineintegral_setGrid(PolylineIntegral_t **self, Grid_t *grid);
  * is rejected (nemoflux never enables it). */
 int mnt_polylineintegral_buildLocator(PolylineIntegral_t **self, int numCellsPerBucket, double periodX,
                                       int enableFolding);
-/* .computeWeights(xyz (npoints,3), counterclock=False)   field.py:48 */
+/* .computeWeights(xyz (npoints,3), counterclock=False)   field.py:48
+ * NF_ERR_ARG (with the cell id in nf_last_error) when a target segment overlaps, over a positive length, a cell the
+ * weights are not defined on: a quad that is not convex in the (lon,lat) plane, or one with a corner AT a geographic
+ * pole (the cells around the pole of a rotated grid) -- never a silent number. */
 int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, const double xyz[],
                                         int counterclock);
 /* .getIntegral(data (ncell,4) float64 HOST, placement) -> *result   field.py:102, fluxplot.py:56
@@ -104,6 +107,9 @@ int mnt_polylineintegral_getIntegral(PolylineIntegral_t **self, const double dat
 /* extensions (not in mint): device-resident data, per-target-segment sums, weight read-back */
 int mnt_polylineintegral_getIntegralDev(PolylineIntegral_t **self, const double *data_dev, int placement,
                                         double *result, double *seg_totals_host /* nseg or NULL */);
+/* coverage[s] = fraction of target segment s that lies inside cells of the grid (1 = inside, counted once); see
+ * nf_field_get_coverage.  npoints-1 values. */
+int mnt_polylineintegral_getCoverage(PolylineIntegral_t **self, double *coverage);
 int mnt_polylineintegral_getNumberOfWeights(PolylineIntegral_t **self, size_t *n);
 int mnt_polylineintegral_getWeights(PolylineIntegral_t **self, int64_t *cell_edge, double *weight, int *seg);
 
@@ -171,6 +177,10 @@ int nf_field_get_weights(nf_field **self, int64_t *cell_edge, double *weight, in
  * south slot is never written), so each (cell, edge) weight belongs to one element of [eU | eV] (elem in [0, 2*ncell):
  * eU[c] = c, eV[c] = ncell + c) and the weights that meet on an element are summed per target segment.  Sorted by
  * (segment, elem).  mint has no counterpart; nf_field_get_weights above stays the mint-shaped view. */
+/* Fraction of every target segment (nseg_total values, transect after transect) that lies inside cells of the grid: 1 =
+ * inside, each point counted once; less = part of the segment is outside the grid and contributes nothing (mint warns
+ * when its own sum of coefficient * (tb - ta) is not 1 [recall]; here the caller can look). */
+int nf_field_get_coverage(nf_field **self, double *coverage);
 int nf_field_num_edge_weights(nf_field **self, size_t *n);
 int nf_field_get_edge_weights(nf_field **self, int *elem, int *seg_global, double *weight);
 /* Length of one output row: nseg_total + ntransect doubles = [per-segment sums | per-transect sums]. */

@@ -68,6 +68,7 @@ _sig('mnt_polylineintegral_buildLocator', [_pp, ctypes.c_int, ctypes.c_double, c
 _sig('mnt_polylineintegral_computeWeights', [_pp, ctypes.c_int, c_double_p, ctypes.c_int])
 _sig('mnt_polylineintegral_getIntegral', [_pp, c_double_p, ctypes.c_int, c_double_p])
 _sig('mnt_polylineintegral_getIntegralDev', [_pp, ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p])
+_sig('mnt_polylineintegral_getCoverage', [_pp, c_double_p])
 _sig('mnt_polylineintegral_getNumberOfWeights', [_pp, ctypes.POINTER(ctypes.c_size_t)])
 _sig('mnt_polylineintegral_getWeights', [_pp, c_int64_p, c_double_p, c_int_p])
 
@@ -99,6 +100,7 @@ _sig('nf_field_num_segments', [_pp, c_int_p])
 _sig('nf_field_segment_offsets', [_pp, c_int_p])
 _sig('nf_field_num_weights', [_pp, ctypes.POINTER(ctypes.c_size_t)])
 _sig('nf_field_get_weights', [_pp, c_int64_p, c_double_p, c_int_p])
+_sig('nf_field_get_coverage', [_pp, c_double_p])
 _sig('nf_field_num_edge_weights', [_pp, ctypes.POINTER(ctypes.c_size_t)])
 _sig('nf_field_get_edge_weights', [_pp, c_int_p, c_int_p, c_double_p])
 _sig('nf_field_row_length', [_pp, c_int_p])

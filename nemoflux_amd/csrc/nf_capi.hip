@@ -429,6 +429,15 @@ try {
 }
 NF_API_CATCH
 
+int mnt_polylineintegral_getCoverage(PolylineIntegral_t **self, double *coverage)
+try {
+    NF_REQUIRE(self && *self && coverage, NF_ERR_ARG, "mnt_polylineintegral_getCoverage: null argument");
+    NF_REQUIRE((*self)->d_row, NF_ERR_STATE, "mnt_polylineintegral_getCoverage: computeWeights first");
+    const std::vector<double> &c = (*self)->ws.coverage;
+    if (!c.empty()) memcpy(coverage, c.data(), sizeof(double) * c.size());
+    return NF_OK;
+}
+NF_API_CATCH
 int mnt_polylineintegral_getNumberOfWeights(PolylineIntegral_t **self, size_t *n)
 try {
     NF_REQUIRE(self && *self && n, NF_ERR_ARG, "mnt_polylineintegral_getNumberOfWeights: null argument");
@@ -1158,6 +1167,15 @@ try {
     if ((*self)->ws.nrec == 0) return NF_OK;
     NF_NEED_DEVICE();
     return weights_to_host((*self)->ws, cell_edge, weight, seg_global);
+}
+NF_API_CATCH
+int nf_field_get_coverage(nf_field **self, double *coverage)
+try {
+    NF_REQUIRE(self && *self && coverage, NF_ERR_ARG, "nf_field_get_coverage: null argument");
+    NF_REQUIRE((*self)->weights_built, NF_ERR_STATE, "nf_field_get_coverage: build_weights first");
+    const std::vector<double> &c = (*self)->ws.coverage;
+    if (!c.empty()) memcpy(coverage, c.data(), sizeof(double) * c.size());
+    return NF_OK;
 }
 NF_API_CATCH
 int nf_field_num_edge_weights(nf_field **self, size_t *n)

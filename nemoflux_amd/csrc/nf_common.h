@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/nemoflux_amd.h"
 
@@ -93,6 +94,9 @@ struct WeightSet {  // device-resident result: one record per (target segment, c
     int *seg = nullptr;        // global segment id of the record
     int nseg = 0;              // total target segments
     int *seg_start = nullptr;  // (nseg+1) CSR over records
+    // host: fraction of every target segment that lies inside cells of the grid (sum of coef*(tb-ta) over its records);
+    // 1 = inside the grid, each point counted once; < 1 = part of the segment is outside (contributes 0, like mint)
+    std::vector<double> coverage;
     // Unique-edge form for the engine's own planes (fold_weights): the south / west slots of integratedVelocity are copies
     // of the neighbours' north / east values (field.py:219-223), so every (cell, edge) weight is folded onto the element
     // of the two signed planes that really carries it and duplicates are merged per target segment (adjacent cells

@@ -83,7 +83,8 @@ __device__ inline bool clip_cell(const double *v, double qx, double qy, double d
     return true;
 }
 
-__device__ inline void inv_bilinear(const double *v, double px, double py, double &xi0, double &xi1)
+// true when the Newton iteration converged to a point of the cell that maps onto p
+__device__ inline bool inv_bilinear(const double *v, double px, double py, double &xi0, double &xi1)
 {
     const double ax = v[0], ay = v[1];
     const double e1x = v[2] - v[0], e1y = v[3] - v[1];
@@ -105,6 +106,98 @@ __device__ inline void inv_bilinear(const double *v, double px, double py, doubl
     }
     xi0 = s;
     xi1 = t;
+    const double fx = ((ax + s * e1x) + t * e3x) + (s * t) * hx - px;
+    const double fy = ((ay + s * e1y) + t * e3y) + (s * t) * hy - py;
+    double size = dmax2(dmax2(fabs(e1x), fabs(e1y)), dmax2(fabs(e3x), fabs(e3y)));
+    size = dmax2(size, dmax2(fabs(v[4] - v[0]), fabs(v[5] - v[1])));
+    return (fabs(fx) + fabs(fy) <= 1.e-9 * size) && s > -1.e-6 && s < 1.0 + 1.e-6 && t > -1.e-6 && t < 1.0 + 1.e-6;
+}
+
+// ---- cells the algorithm is not defined on ----------------------------------------------------------------------
+// The clip assumes a convex quad and the weights need the inverse of the cell's bilinear map, which is not one-to-one in a
+// quad with a reflex corner or a bow-tie (the lon-lat images of the cells that touch a geographic pole on a rotated grid
+// are such quads: datagen.py:116-166 leaves the pole's longitude arbitrary).  mint's behaviour there is pinned by nothing
+// in the reference, so the engine refuses: a target segment that overlaps such a cell over a positive length makes
+// computeWeights fail with NF_ERR_ARG (never a silent number); a non-convex cell the line does not touch is ignored.
+__device__ inline bool quad_is_nonconvex(const double *v)
+{
+    // a corner AT a geographic pole that is not the end of an edge lying on the pole line (|lat| = 90 along a whole edge,
+    // as in the top row of an un-rotated lon-lat grid, is fine): the pole's longitude is arbitrary, so the planar quad is
+    // not the image of the cell, convex or not
+    int npole = 0, first = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (fabs(v[2 * k + 1]) >= 90.0 - 1.e-9) {
+            ++npole;
+            if (first < 0) first = k;
+        }
+    if (npole == 1 || npole == 3) return true;
+    if (npole == 2 && !(fabs(v[2 * ((first + 1) & 3) + 1]) >= 90.0 - 1.e-9 || (first == 0 && fabs(v[2 * 3 + 1]) >= 90.0 - 1.e-9)))
+        return true;   // opposite corners
+    double cmin = 0.0, cmax = 0.0, scale = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int k1 = (k + 1) & 3, k2 = (k + 2) & 3;
+        const double ex = v[2 * k1] - v[2 * k], ey = v[2 * k1 + 1] - v[2 * k + 1];
+        const double fx = v[2 * k2] - v[2 * k1], fy = v[2 * k2 + 1] - v[2 * k1 + 1];
+        const double cr = ex * fy - ey * fx;
+        cmin = fmin(cmin, cr);
+        cmax = fmax(cmax, cr);
+        scale = dmax2(scale, ex * ex + ey * ey);
+    }
+    return cmin < -1.e-12 * scale && cmax > 1.e-12 * scale;
+}
+
+__device__ inline bool point_in_quad_evenodd(const double *v, double px, double py)
+{
+    bool in = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int k1 = (k + 1) & 3;
+        const double ax = v[2 * k], ay = v[2 * k + 1], bx = v[2 * k1], by = v[2 * k1 + 1];
+        if ((ay > py) != (by > py)) {
+            const double xc = ax + (py - ay) * (bx - ax) / (by - ay);
+            if (px < xc) in = !in;
+        }
+    }
+    return in;
+}
+
+// does q + t d, t in [0,1], overlap the (possibly non-convex) quad over more than kTolT in t?
+__device__ inline bool segment_overlaps_quad(const double *v, double qx, double qy, double dx, double dy)
+{
+    double ts[6];
+    int n = 0;
+    ts[n++] = 0.0;
+    ts[n++] = 1.0;
+    for (int k = 0; k < 4; ++k) {
+        const int k1 = (k + 1) & 3;
+        const double ax = v[2 * k], ay = v[2 * k + 1];
+        const double gx = v[2 * k1] - ax, gy = v[2 * k1 + 1] - ay;
+        const double den = dx * gy - dy * gx;
+        if (den == 0.0) continue;
+        const double t = ((ax - qx) * gy - (ay - qy) * gx) / den;
+        const double u = ((ax - qx) * dy - (ay - qy) * dx) / den;
+        if (t > 0.0 && t < 1.0 && u >= 0.0 && u <= 1.0) ts[n++] = t;
+    }
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && ts[j] < ts[j - 1]; --j) {
+            const double x = ts[j];
+            ts[j] = ts[j - 1];
+            ts[j - 1] = x;
+        }
+    for (int i = 0; i + 1 < n; ++i) {
+        if (!(ts[i + 1] - ts[i] > kTolT)) continue;
+        const double tm = 0.5 * (ts[i] + ts[i + 1]);
+        if (point_in_quad_evenodd(v, qx + tm * dx, qy + tm * dy)) return true;
+    }
+    return false;
+}
+
+// error word of a weight build: the smallest offending (cell, kind, segment), ~0 = none
+__device__ inline void flag_cell(unsigned long long *err, long cell, int kind, int seg)
+{
+    atomicMin(err, ((unsigned long long)cell << 32) | ((unsigned long long)kind << 24) | (unsigned)(seg & 0xffffff));
 }
 
 __device__ inline double wmin(double x)
@@ -132,7 +225,8 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
                                                  const double *__restrict__ segs,
                                                  const int *__restrict__ seg_cc, int nseg, int nshift,
                                                  double periodX, const int *__restrict__ wave_off,
-                                                 int *__restrict__ wave_cnt, Records rec)
+                                                 int *__restrict__ wave_cnt, Records rec,
+                                                 unsigned long long *__restrict__ err)
 {
     __shared__ double s_xy[kBlock * 8];
     const int tid = threadIdx.x;
@@ -161,6 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
         }
     }
     const double slack = valid ? 1.e-9 * (fabs(cxmin) + fabs(cxmax) + fabs(cymin) + fabs(cymax) + 1.0) : 0.0;
+    const bool nonconvex = valid && quad_is_nonconvex(v);
     // wave tile bounding box (the locator bucket)
     const double wslack = wmax(slack);
     const double wxmin = wmin(cxmin) - wslack, wxmax = wmax(cxmax) + wslack;
@@ -244,14 +339,19 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
             bool hit = valid && !(cxmin > sxmax + slack || cxmax < sxmin - slack || cymin > symax + slack ||
                                   cymax < symin - slack);
             double ta = 0.0, tb = 0.0;
+            if (hit && nonconvex) {   // not a cell the weights are defined on: refuse if the line really crosses it
+                if (!FILL && segment_overlaps_quad(v, qx, qy, dx, dy)) flag_cell(err, c, 1, s);
+                hit = false;
+            }
             if (hit) hit = clip_cell(v, qx, qy, dx, dy, ta, tb);
             const unsigned long long mask = __ballot(hit);
             if (mask == 0ull) continue;
             if (FILL && hit) {
                 const long pos = (long)base + count + __popcll(mask & lt_mask);
                 double a0, a1, b0, b1;
-                inv_bilinear(v, qx + ta * dx, qy + ta * dy, a0, a1);
-                inv_bilinear(v, qx + tb * dx, qy + tb * dy, b0, b1);
+                bool ok = inv_bilinear(v, qx + ta * dx, qy + ta * dy, a0, a1);
+                ok = inv_bilinear(v, qx + tb * dx, qy + tb * dy, b0, b1) && ok;
+                if (!ok) flag_cell(err, c, 2, s);
                 const double d0 = b0 - a0, d1 = b1 - a1;
                 const double m0 = 0.5 * (a0 + b0), m1 = 0.5 * (a1 + b1);
                 double w0 = d0 * (1.0 - m1), w1 = d1 * m0, w2 = d0 * m1, w3 = d1 * (1.0 - m0);
@@ -326,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void k_seg_bounds(const unsigned long long 
 __global__ __launch_bounds__(kBlock) void k_expand(const unsigned long long *__restrict__ keys,
                                                    const unsigned *__restrict__ perm, long nrec, Records rec,
                                                    int *__restrict__ cell_out, double *__restrict__ w4_out,
-                                                   int *__restrict__ seg_out)
+                                                   int *__restrict__ seg_out, double *__restrict__ len_out)
 {
     long i = (long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= nrec) return;
@@ -352,6 +452,21 @@ __global__ __launch_bounds__(kBlock) void k_expand(const unsigned long long *__r
     po[1] = make_double2(b.x * coef, b.y * coef);
     cell_out[i] = rec.cell[r];
     seg_out[i] = (int)s;
+    len_out[i] = coef * (tb - ta);   // the piece of the target segment this record accounts for
+}
+
+// coverage of every target segment: sum of coef * (tb - ta) over its records = the fraction of the segment that lies in
+// cells of the grid (1 when it is inside, counted once).  One wavefront per segment, fixed summation order.
+__global__ __launch_bounds__(kBlock) void k_seg_coverage(const double *__restrict__ len, const int *__restrict__ rec_start,
+                                                         int nseg, double *__restrict__ cov)
+{
+    const int s = (blockIdx.x * kBlock + threadIdx.x) / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    if (s >= nseg) return;
+    double acc = 0.0;
+    for (long k = rec_start[s] + lane; k < rec_start[s + 1]; k += kWave) acc += len[k];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, kWave);
+    if (lane == 0) cov[s] = acc;
 }
 
 
@@ -430,6 +545,7 @@ void WeightSet::release()
     if (w4) (void)hipFree(w4);
     if (seg) (void)hipFree(seg);
     if (seg_start) (void)hipFree(seg_start);
+    coverage.clear();
     cell = nullptr;
     w4 = nullptr;
     seg = nullptr;
@@ -521,13 +637,31 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
 {
     out->release();
     out->nseg = nseg;
+    out->coverage.assign((size_t)nseg, 0.0);
     NF_REQUIRE(ncell > 0 && ncell < (1l << 31), NF_ERR_ARG, "weights: ncell out of range");
     NF_REQUIRE(nseg >= 0 && nseg < (1 << 23), NF_ERR_ARG, "weights: segment count out of range");
     const int nshift = periodX > 0.0 ? 3 : 1;
     const long nwaves = (ncell + kWave - 1) / kWave;
     const unsigned nblocks = (unsigned)((ncell + kBlock - 1) / kBlock);
 
-    DevBuf d_segs, d_cc, d_cnt, d_off;
+    DevBuf d_segs, d_cc, d_cnt, d_off, d_err;
+    NF_HIP(d_err.alloc(sizeof(unsigned long long)));
+    NF_HIP(hipMemsetAsync(d_err.p, 0xff, sizeof(unsigned long long), s));
+    unsigned long long err_word = ~0ull;
+    auto refuse = [&](unsigned long long w) {
+        char buf[256];
+        const long cell = (long)(w >> 32);
+        const int kind = (int)((w >> 24) & 0xff), seg = (int)(w & 0xffffff);
+        snprintf(buf, sizeof buf,
+                 kind == 1 ? "computeWeights: target segment %d crosses cell %ld, which is not convex in the (lon,lat) plane "
+                             "(a reflex corner or a bow-tie, e.g. a cell touching the pole of a rotated grid): the weights "
+                             "are not defined there"
+                           : "computeWeights: target segment %d: the inverse bilinear map did not converge in cell %ld",
+                 seg, cell);
+        set_error(buf);
+        out->release();
+        return NF_ERR_ARG;
+    };
     NF_HIP(d_segs.alloc(sizeof(double) * 4 * (size_t)nseg));
     NF_HIP(d_cc.alloc(sizeof(int) * (size_t)nseg));
     NF_HIP(d_cnt.alloc(sizeof(int) * (size_t)nwaves));
@@ -540,11 +674,14 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
 
     Records none{};
     hipLaunchKernelGGL(k_clip<false>, dim3(nblocks), dim3(kBlock), 0, s, xy, ncell, d_segs.as<double>(),
-                       d_cc.as<int>(), nseg, nshift, periodX, (const int *)nullptr, d_cnt.as<int>(), none);
+                       d_cc.as<int>(), nseg, nshift, periodX, (const int *)nullptr, d_cnt.as<int>(), none,
+                       d_err.as<unsigned long long>());
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_cnt.as<int>(), nwaves, d_off.as<int>());
     int nrec_i = 0;
     NF_HIP(hipMemcpyAsync(&nrec_i, d_off.as<int>() + nwaves, sizeof(int), hipMemcpyDeviceToHost, s));
+    NF_HIP(hipMemcpyAsync(&err_word, d_err.p, sizeof err_word, hipMemcpyDeviceToHost, s));
     NF_HIP(hipStreamSynchronize(s));
+    if (err_word != ~0ull) return refuse(err_word);
     NF_REQUIRE(nrec_i >= 0, NF_ERR_ARG, "weights: more than 2^31 (segment, cell) records; split the transect set");
     const long nrec = nrec_i;
 
@@ -564,7 +701,8 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     Records rec{r_key.as<unsigned long long>(), r_cell.as<int>(), r_ta.as<double>(), r_tb.as<double>(),
                 r_w.as<double>()};
     hipLaunchKernelGGL(k_clip<true>, dim3(nblocks), dim3(kBlock), 0, s, xy, ncell, d_segs.as<double>(),
-                       d_cc.as<int>(), nseg, nshift, periodX, d_off.as<int>(), (int *)nullptr, rec);
+                       d_cc.as<int>(), nseg, nshift, periodX, d_off.as<int>(), (int *)nullptr, rec,
+                       d_err.as<unsigned long long>());
     NF_HIP(hipGetLastError());
 
     // stable sort of record indices by global segment id
@@ -592,11 +730,21 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     NF_HIP(hipMalloc((void **)&out->cell, sizeof(int) * (size_t)nrec));
     NF_HIP(hipMalloc((void **)&out->w4, sizeof(double) * 4 * (size_t)nrec));
     NF_HIP(hipMalloc((void **)&out->seg, sizeof(int) * (size_t)nrec));
+    DevBuf d_len, d_cov;
+    NF_HIP(d_len.alloc(sizeof(double) * (size_t)nrec));
+    NF_HIP(d_cov.alloc(sizeof(double) * (size_t)(nseg + 1)));
     hipLaunchKernelGGL(k_expand, dim3(nb_rec), dim3(kBlock), 0, s, k_out.as<unsigned long long>(),
-                       v_out.as<unsigned>(), nrec, rec, out->cell, out->w4, out->seg);
+                       v_out.as<unsigned>(), nrec, rec, out->cell, out->w4, out->seg, d_len.as<double>());
+    if (nseg > 0) {
+        hipLaunchKernelGGL(k_seg_coverage, dim3((unsigned)(((long)nseg * kWave + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                           d_len.as<double>(), rstart.as<int>(), nseg, d_cov.as<double>());
+        NF_HIP(hipMemcpyAsync(out->coverage.data(), d_cov.p, sizeof(double) * (size_t)nseg, hipMemcpyDeviceToHost, s));
+    }
     NF_HIP(hipMemcpyAsync(out->seg_start, rstart.p, sizeof(int) * (size_t)(nseg + 1), hipMemcpyDeviceToDevice, s));
+    NF_HIP(hipMemcpyAsync(&err_word, d_err.p, sizeof err_word, hipMemcpyDeviceToHost, s));
     NF_HIP(hipGetLastError());
     NF_HIP(hipStreamSynchronize(s));
+    if (err_word != ~0ull) return refuse(err_word);   // Newton did not converge somewhere (fill pass)
     return NF_OK;
 }
 

@@ -247,6 +247,13 @@ class Field(object):
         self._rowlen = n.value
         self._row = numpy.zeros(max(self._rowlen, 1), numpy.float64)
         self._row_valid = False
+        for i, cov in enumerate(self.getCoverage()):   # mint warns when part of a target line is outside the grid [recall]
+            bad = numpy.nonzero(numpy.abs(cov - 1.0) > 1.e-8)[0]
+            if bad.size:
+                import warnings
+                warnings.warn(f'transect {i}: {bad.size} of {cov.size} target segments are not fully inside the grid '
+                              f'(covered fraction {cov[bad].min():.6g} .. {cov[bad].max():.6g}); the parts outside '
+                              f'contribute no flux', RuntimeWarning, stacklevel=3)
 
         numCells = self.ny * self.nx
         self.dx = min((self.lonmax - self.lonmin) / float(self.nx), (self.latmax - self.latmin) / float(self.ny))
@@ -449,6 +456,13 @@ class Field(object):
         check(lib.nf_field_get_weights(ctypes.byref(self._h), ce.ctypes.data_as(_lib.c_int64_p), _lib.dptr(w),
                                        sg.ctypes.data_as(_lib.c_int_p)))
         return ce, w, sg
+
+    def getCoverage(self):
+        """Per transect: the fraction of each of its target segments that lies inside cells of the grid (1 = inside, each
+        point counted once; less = part of the line is outside the grid and contributes no flux)."""
+        cov = numpy.zeros(max(self._nseg, 1), numpy.float64)
+        check(lib.nf_field_get_coverage(ctypes.byref(self._h), _lib.dptr(cov)))
+        return [cov[self._tr_off[i]:self._tr_off[i + 1]].copy() for i in range(len(self.plis))]
 
     def getEdgeWeights(self):
         """(element of [eU | eV], weight, global segment id): the weights folded onto the unique edges of the two signed

@@ -115,6 +115,12 @@ class PolylineIntegral(object):
         return res.value
 
     # ---- extensions beyond mint
+    def getCoverage(self):
+        """Fraction of every target segment that lies inside cells of the grid (1 = inside, each point counted once)."""
+        cov = numpy.zeros(max(self.numSegments, 1), numpy.float64)
+        check(lib.mnt_polylineintegral_getCoverage(ctypes.byref(self.obj), _lib.dptr(cov)))
+        return cov[:self.numSegments]
+
     def getSegmentIntegrals(self, data):
         """Per-target-segment sums (numSegments,) and the total."""
         res = ctypes.c_double()

@@ -194,7 +194,7 @@ static int clip_cell(const double *v, double qx, double qy, double dx, double dy
 }
 
 /* Inverse of the bilinear map of quad v at point p (Newton from the cell centre). */
-static void inv_bilinear(const double *v, double px, double py, double *xi0, double *xi1)
+static int inv_bilinear(const double *v, double px, double py, double *xi0, double *xi1)
 {
     double ax = v[0], ay = v[1];
     double e1x = v[2] - v[0], e1y = v[3] - v[1];
@@ -216,6 +216,84 @@ static void inv_bilinear(const double *v, double px, double py, double *xi0, dou
     }
     *xi0 = s;
     *xi1 = t;
+    /* converged?  residual of the map against the size of the cell */
+    double fx = ((ax + s * e1x) + t * e3x) + (s * t) * hx - px;
+    double fy = ((ay + s * e1y) + t * e3y) + (s * t) * hy - py;
+    double size = max2(max2(fabs(e1x), fabs(e1y)), max2(fabs(e3x), fabs(e3y)));
+    size = max2(size, max2(fabs(v[4] - v[0]), fabs(v[5] - v[1])));
+    return (fabs(fx) + fabs(fy) <= 1.e-9 * size) && s > -1.e-6 && s < 1.0 + 1.e-6 && t > -1.e-6 && t < 1.0 + 1.e-6;
+}
+
+/* ---- cells the algorithm is not defined on ---------------------------------------------------------------
+ * The clip assumes a convex quad and the weights need the inverse of the cell's bilinear map, which is not one-to-one
+ * in a quad with a reflex corner or a bow-tie (the lon-lat images of the cells that touch a geographic pole on a
+ * rotated grid are such quads: datagen.py:116-166 leaves the pole's longitude arbitrary).  mint's behaviour there is
+ * not pinned by anything in the reference, so the restatement refuses: a target segment that overlaps such a cell over
+ * a positive length is an ERROR (status 1), never a silent number; a non-convex cell the line does not touch is
+ * ignored.  Status 2: the Newton iteration of the inverse map did not converge in a (convex) cell. */
+static int quad_is_nonconvex(const double *v)
+{
+    /* a corner AT a geographic pole that is not the end of an edge lying on the pole line (|lat| = 90 along a whole edge,
+     * as in the top row of an un-rotated lon-lat grid, is fine): the pole's longitude is arbitrary, so the planar quad is
+     * not the image of the cell, convex or not */
+    int npole = 0, first = -1;
+    for (int k = 0; k < 4; ++k)
+        if (fabs(v[2 * k + 1]) >= 90.0 - 1.e-9) { ++npole; if (first < 0) first = k; }
+    if (npole == 1 || npole == 3) return 1;
+    if (npole == 2 && !(fabs(v[2 * ((first + 1) & 3) + 1]) >= 90.0 - 1.e-9 ||
+                        (first == 0 && fabs(v[2 * 3 + 1]) >= 90.0 - 1.e-9))) return 1;   /* opposite corners */
+    double cmin = 0.0, cmax = 0.0, scale = 0.0;
+    for (int k = 0; k < 4; ++k) {
+        int k1 = (k + 1) & 3, k2 = (k + 2) & 3;
+        double ex = v[2 * k1] - v[2 * k], ey = v[2 * k1 + 1] - v[2 * k + 1];
+        double fx = v[2 * k2] - v[2 * k1], fy = v[2 * k2 + 1] - v[2 * k1 + 1];
+        double cr = ex * fy - ey * fx;
+        if (cr < cmin) cmin = cr;
+        if (cr > cmax) cmax = cr;
+        scale = max2(scale, ex * ex + ey * ey);
+    }
+    return cmin < -1.e-12 * scale && cmax > 1.e-12 * scale;
+}
+
+static int point_in_quad_evenodd(const double *v, double px, double py)
+{
+    int in = 0;
+    for (int k = 0; k < 4; ++k) {
+        int k1 = (k + 1) & 3;
+        double ax = v[2 * k], ay = v[2 * k + 1], bx = v[2 * k1], by = v[2 * k1 + 1];
+        if ((ay > py) != (by > py)) {
+            double xc = ax + (py - ay) * (bx - ax) / (by - ay);
+            if (px < xc) in = !in;
+        }
+    }
+    return in;
+}
+
+/* does q + t d, t in [0,1], overlap the (possibly non-convex) quad over a length of more than NFO_TOL_T in t? */
+static int segment_overlaps_quad(const double *v, double qx, double qy, double dx, double dy)
+{
+    double ts[6];
+    int n = 0;
+    ts[n++] = 0.0;
+    ts[n++] = 1.0;
+    for (int k = 0; k < 4; ++k) {
+        int k1 = (k + 1) & 3;
+        double ax = v[2 * k], ay = v[2 * k + 1];
+        double gx = v[2 * k1] - ax, gy = v[2 * k1 + 1] - ay;
+        double den = dx * gy - dy * gx;
+        if (den == 0.0) continue;
+        double t = ((ax - qx) * gy - (ay - qy) * gx) / den;
+        double u = ((ax - qx) * dy - (ay - qy) * dx) / den;
+        if (t > 0.0 && t < 1.0 && u >= 0.0 && u <= 1.0) ts[n++] = t;
+    }
+    for (int i = 1; i < n; ++i)   /* insertion sort of at most 6 values */
+        for (int j = i; j > 0 && ts[j] < ts[j - 1]; --j) { double x = ts[j]; ts[j] = ts[j - 1]; ts[j - 1] = x; }
+    for (int i = 0; i + 1 < n; ++i) {
+        if (!(ts[i + 1] - ts[i] > NFO_TOL_T)) continue;
+        double tm = 0.5 * (ts[i] + ts[i + 1]);
+        if (point_in_quad_evenodd(v, qx + tm * dx, qy + tm * dy)) return 1;
+    }
+    return 0;
 }
 
 static int rec_cmp(const void *a, const void *b)
@@ -234,11 +312,15 @@ static int rec_cmp(const void *a, const void *b)
  * computeWeights' flag (field.py:48 passes False = all edges oriented in +xi).
  * Output (sorted by segment, ta, cell): cell_edge[k] = cell*4 + edge, weight[k], seg[k] (0-based target
  * segment).  Returns the number of entries (4 per crossed cell), or -(needed) if cap is too small.
+ * status[0]: 0 = fine; 1 = a target segment overlaps a non-convex cell; 2 = the inverse bilinear map did not converge;
+ * status[1] = the smallest offending cell id, status[2] = its first segment.  On an error no weights are returned (0).
  */
 long nfo_polyline_weights(const double *points, long ncell, const double *xyz, int npts, double periodX,
-                          int counterclock, long cap, int64_t *cell_edge, double *weight, int *seg)
+                          int counterclock, long cap, int64_t *cell_edge, double *weight, int *seg, long *status,
+                          double *coverage /* npts-1 values or NULL: sum of coef*(tb-ta) per segment */)
 {
     long nrec = 0, rcap = 1024;
+    long err = 0, err_cell = -1, err_seg = -1;
     nfo_rec *recs = (nfo_rec *)malloc(rcap * sizeof(nfo_rec));
     int nshift = periodX > 0.0 ? 3 : 1;
     for (int s = 0; s + 1 < npts; ++s) {
@@ -265,11 +347,18 @@ long nfo_polyline_weights(const double *points, long ncell, const double *xyz, i
                 double slack = 1.e-9 * (fabs(cxmin) + fabs(cxmax) + fabs(cymin) + fabs(cymax) + 1.0);
                 if (cxmin > sxmax + slack || cxmax < sxmin - slack || cymin > symax + slack || cymax < symin - slack)
                     continue;
+                if (quad_is_nonconvex(v)) {
+                    if (segment_overlaps_quad(v, qx, qy, dx, dy) && (err_cell < 0 || c < err_cell)) {
+                        err = 1; err_cell = c; err_seg = s;
+                    }
+                    continue;
+                }
                 double ta, tb;
                 if (!clip_cell(v, qx, qy, dx, dy, &ta, &tb)) continue;
                 double a0, a1, b0, b1;
-                inv_bilinear(v, qx + ta * dx, qy + ta * dy, &a0, &a1);
-                inv_bilinear(v, qx + tb * dx, qy + tb * dy, &b0, &b1);
+                int ok = inv_bilinear(v, qx + ta * dx, qy + ta * dy, &a0, &a1);
+                ok &= inv_bilinear(v, qx + tb * dx, qy + tb * dy, &b0, &b1);
+                if (!ok && (err_cell < 0 || c < err_cell)) { err = 2; err_cell = c; err_seg = s; }
                 double d0 = b0 - a0, d1 = b1 - a1;
                 double m0 = 0.5 * (a0 + b0), m1 = 0.5 * (a1 + b1);
                 if (nrec == rcap) {
@@ -291,6 +380,8 @@ long nfo_polyline_weights(const double *points, long ncell, const double *xyz, i
             }
         }
     }
+    if (status) { status[0] = err; status[1] = err_cell; status[2] = err_seg; }
+    if (err) { free(recs); return 0; }
     qsort(recs, nrec, sizeof(nfo_rec), rec_cmp);
     /* multiplicity: a sub-segment found with the same [ta,tb] in n cells counts 1/n in each */
     for (long i = 0; i < nrec; ++i) {
@@ -300,6 +391,10 @@ long nfo_polyline_weights(const double *points, long ncell, const double *xyz, i
         for (long j = i + 1; j < nrec && recs[j].seg == recs[i].seg && recs[j].ta - recs[i].ta <= NFO_TOL_T; ++j)
             if (fabs(recs[j].tb - recs[i].tb) <= NFO_TOL_T) ++n;
         recs[i].coef = 1.0 / (double)n;
+    }
+    if (coverage) {
+        for (int q = 0; q + 1 < npts; ++q) coverage[q] = 0.0;
+        for (long i = 0; i < nrec; ++i) coverage[recs[i].seg] += recs[i].coef * (recs[i].tb - recs[i].ta);
     }
     long need = nrec * 4;
     if (need > cap) { free(recs); return -need; }

@@ -47,7 +47,7 @@ def lib():
         L.nfo_edge_flux.argtypes = [dp, dp, dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, dp, dp, dp, dp]
         L.nfo_polyline_weights.argtypes = [dp, ctypes.c_long, dp, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                            ctypes.c_long, ctypes.POINTER(ctypes.c_int64), dp,
-                                           ctypes.POINTER(ctypes.c_int)]
+                                           ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_long), dp]
         L.nfo_polyline_weights.restype = ctypes.c_long
         L.nfo_get_integral.argtypes = [dp, ctypes.c_long, ctypes.POINTER(ctypes.c_int64), dp,
                                        ctypes.POINTER(ctypes.c_int), ctypes.c_int, dp]
@@ -124,8 +124,9 @@ def edge_flux(state, uInt, vInt, arc, sverdrup=False):
 
 
 class Weights(object):
-    def __init__(self, cell_edge, weight, seg, nseg):
+    def __init__(self, cell_edge, weight, seg, nseg, coverage=None):
         self.cell_edge, self.weight, self.seg, self.nseg = cell_edge, weight, seg, nseg
+        self.coverage = coverage    # fraction of every target segment found inside cells of the grid
 
     def as_dict(self):
         d = {}
@@ -134,8 +135,18 @@ class Weights(object):
         return d
 
 
+class UnsupportedCell(ValueError):
+    """A target segment overlaps a cell the algorithm is not defined on (non-convex quad / no inverse bilinear map)."""
+
+    def __init__(self, kind, cell, seg):
+        self.kind, self.cell, self.seg = int(kind), int(cell), int(seg)
+        what = 'overlaps non-convex cell' if kind == 1 else 'inverse bilinear map did not converge in cell'
+        super().__init__(f'target segment {seg} {what} {cell}')
+
+
 def polyline_weights(points, xyz, periodX=360., counterclock=False):
-    """A6 mint.PolylineIntegral.computeWeights (field.py:45-48)."""
+    """A6 mint.PolylineIntegral.computeWeights (field.py:45-48).  Raises UnsupportedCell instead of returning numbers
+    for a line that crosses a non-convex cell."""
     pts = _c64(points)
     ncell = pts.shape[0]
     xyz = _c64(xyz).reshape(-1, 3)
@@ -144,11 +155,15 @@ def polyline_weights(points, xyz, periodX=360., counterclock=False):
         ce = numpy.empty(cap, numpy.int64)
         w = numpy.empty(cap, numpy.float64)
         sg = numpy.empty(cap, numpy.int32)
+        status = (ctypes.c_long * 3)(0, -1, -1)
+        cov = numpy.zeros(max(xyz.shape[0] - 1, 1), numpy.float64)
         n = lib().nfo_polyline_weights(_dp(pts), ncell, _dp(xyz), xyz.shape[0], float(periodX), int(counterclock),
                                        cap, ce.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _dp(w),
-                                       sg.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+                                       sg.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), status, _dp(cov))
+        if status[0]:
+            raise UnsupportedCell(status[0], status[1], status[2])
         if n >= 0:
-            return Weights(ce[:n].copy(), w[:n].copy(), sg[:n].copy(), xyz.shape[0] - 1)
+            return Weights(ce[:n].copy(), w[:n].copy(), sg[:n].copy(), xyz.shape[0] - 1, cov[:xyz.shape[0] - 1])
         cap = -n
 
 

@@ -16,6 +16,10 @@ PSI_CS = "cos(2*pi*y/360) + sin(2*pi*x/360)"
 PSI_ZT = "(1+10*z)*(t+1)*(cos(2*pi*y/360) + sin(2*pi*x/360))"
 T_TRI = "(-100,-80),(100,-80),(0,80),(-100,-80)"
 T_OPEN = "(-100,-80),(100,-80),(0,80)"
+# coarse ROTATED grids: the cells that touch a geographic pole reach far down in latitude and are refused by the weight
+# build; these stay clear of them
+T_TRI50 = "(-100,-50),(100,-50),(0,50),(-100,-50)"
+T_OPEN50 = "(-100,-50),(100,-50),(0,50)"
 
 
 def quiet_field(*a, **kw):
@@ -214,7 +218,7 @@ def test_host_staged_fields_equal_resident(oracle):
     import torch
     m_name = 'rot36_zt'
     g = load_golden(m_name)
-    tr = [transect_xyz(T_TRI)]
+    tr = [transect_xyz(T_TRI50)]
     a = quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], g['u'], g['v'], tr)
     b = quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], torch.from_numpy(g['u']).cuda(),
                     torch.from_numpy(g['v']).cuda(), tr)
@@ -579,7 +583,7 @@ def test_all_steps_in_one_launch_equals_step_by_step(real):
     from nemoflux_amd._lib import lib, check
     from nemoflux_amd.dist import slab_range
     dg = device_case(90, 45, 6, 7, PSI_ZT, (20., 30.), real=real)
-    tr = [transect_xyz(T_OPEN), transect_xyz(T_TRI)]
+    tr = [transect_xyz(T_OPEN50), transect_xyz(T_TRI50)]
     args = (dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, tr)
     for sr in (None, slab_range(7, 6, 1, 3), slab_range(7, 6, 0, 4)):
         f = quiet_field(*args, slab_range=sr)
@@ -613,6 +617,7 @@ def test_weights_randomised_against_oracle(grid_kind, oracle):
     coverage property holds (planar lon/lat are bilinear per cell, so segments that lie inside the grid integrate the
     lon/lat "edge data" to their own end-point differences)."""
     from nemoflux_amd import mint
+    from nemoflux_amd._lib import NemofluxError
     if grid_kind == 'orca025':
         b = load_golden('sa_T_bounds')
         blon, blat = b['bounds_lon'].astype(numpy.float64), b['bounds_lat'].astype(numpy.float64)
@@ -633,6 +638,7 @@ def test_weights_randomised_against_oracle(grid_kind, oracle):
     data = [numpy.stack([f[:, 1] - f[:, 0], f[:, 2] - f[:, 1], f[:, 2] - f[:, 3], f[:, 3] - f[:, 0]], axis=1) for f in lonlat]
     rng = numpy.random.default_rng({'regular': 1, 'rotated': 2, 'regional': 3, 'orca025': 4}[grid_kind])
     nodes_x, nodes_y = numpy.unique(pts[:, :, 0]), numpy.unique(pts[:, :, 1])
+    refused = 0
     for trial in range(12):
         n = int(rng.integers(2, 9))
         x = rng.uniform(box[0] - 8, box[1] + 8, n)
@@ -649,9 +655,17 @@ def test_weights_randomised_against_oracle(grid_kind, oracle):
         pli = mint.PolylineIntegral()
         pli.setGrid(grid)
         pli.buildLocator(numCellsPerBucket=128, periodX=periodX, enableFolding=False)
+        try:
+            ow = oracle.polyline_weights(pts, xyz, periodX=periodX)
+        except oracle.UnsupportedCell as e:      # rotated grid: the line runs through a cell that touches a pole
+            assert grid_kind == 'rotated'
+            with pytest.raises(NemofluxError, match=rf'cell {e.cell}\b'):
+                pli.computeWeights(xyz, counterclock=False)
+            refused += 1
+            continue
         pli.computeWeights(xyz, counterclock=False)
         ce, w, sg = pli.getWeights()
-        ow = oracle.polyline_weights(pts, xyz, periodX=periodX)
+        assert numpy.allclose(pli.getCoverage(), ow.coverage, rtol=0, atol=1e-12)
         assert ce.size == ow.weight.size, (grid_kind, trial)
         gd = {}
         for a, b_, c in zip(sg.tolist(), ce.tolist(), w.tolist()):
@@ -667,6 +681,8 @@ def test_weights_randomised_against_oracle(grid_kind, oracle):
                     segs, tot = pli.getSegmentIntegrals(data[k])
                     want = numpy.diff(xyz[:, k])
                     assert numpy.allclose(segs, want, rtol=0, atol=1e-9), (grid_kind, trial, k)
+                assert numpy.allclose(pli.getCoverage(), 1.0, rtol=0, atol=1e-9)      # inside the grid, counted once
+    assert (refused > 0) == (grid_kind == 'rotated') and refused < 12
 
 
 @pytest.mark.parametrize('rotated', [False, True])
@@ -827,7 +843,10 @@ def test_unique_edge_weights_are_the_folded_mint_weights(rotated):
     nx, ny, nz, nt = 72, 36, 3, 2
     dg = device_case(nx, ny, nz, nt, PSI_ZT, (20., 30.) if rotated else (0., 0.))
     polys = bench.make_transects(nx, ny, -180., 180., -90., 90., 10, seed=11, seam=True)
-    polys.append([(-180., -90.), (180., -90.), (180., -85.), (-175., -85.)])      # row 0: south slots carry nothing
+    if rotated:      # stay clear of the cells that touch the poles of the rotated grid (refused by the weight build)
+        polys = [[(x, 0.6 * y) for x, y in p] for p in polys]
+    else:
+        polys.append([(-180., -90.), (180., -90.), (180., -85.), (-175., -85.)])      # row 0: south slots carry nothing
     xyzs = [numpy.array([(x, y, 0.) for x, y in p]) for p in polys]
     ref = quiet_field(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, xyzs)     # default: record form
     assert ref.getEdgeWeights()[0].size == 0
@@ -873,3 +892,68 @@ def _edge_form_checks(dg, xyzs, ref, nx, ny, nt):
         numpy.add.at(direct, sg, w * iv.reshape(-1)[ce])
         assert numpy.abs(direct - segs).max() <= bound
         assert numpy.abs(numpy.array(ref.computeFlux(t)) - numpy.array(tot)).max() <= bound     # record form, same planes
+
+
+def test_refuses_nonconvex_and_pole_cells(oracle):
+    """GPU counterpart of test_oracle_refuses_nonconvex_and_pole_cells: a target line that overlaps a cell whose
+    (lon,lat) image is not a convex quad (reflex corner, bow-tie, a corner AT a geographic pole of a rotated grid) makes
+    computeWeights / Field fail with NF_ERR_ARG naming the same cell as the oracle -- never a silent number; lines clear
+    of such cells are unaffected; the covered fraction of every target segment is reported."""
+    import warnings
+    from nemoflux_amd import mint
+    from nemoflux_amd._lib import NemofluxError
+    from test_oracle_golden import dart_grid
+
+    def pli_for(pts, periodX):
+        grid = mint.Grid()
+        grid.setPoints(pts)
+        p = mint.PolylineIntegral()
+        p.setGrid(grid)
+        p.buildLocator(numCellsPerBucket=128, periodX=periodX, enableFolding=False)
+        return p
+
+    bad, good = dart_grid()
+    line_through = numpy.array([(0.2, 1.4, 0.), (2.8, 1.6, 0.)])
+    line_clear = numpy.array([(0.2, 0.4, 0.), (2.8, 0.6, 0.), (2.5, 2.7, 0.)])
+    p = pli_for(bad, 0.)
+    with pytest.raises(NemofluxError, match=r'cell 4\b.*not convex'):
+        p.computeWeights(line_through)
+    p.computeWeights(line_clear)                      # the handle stays usable after a refusal
+    q = pli_for(good, 0.)
+    q.computeWeights(line_clear)
+    for a, b in zip(p.getWeights(), q.getWeights()):
+        assert numpy.array_equal(a, b)
+    assert numpy.allclose(p.getCoverage(), 1.0, rtol=0, atol=1e-12)
+    bow = good.copy()
+    bow[4, [1, 2]] = bow[4, [2, 1]]
+    with pytest.raises(NemofluxError, match='not convex'):
+        pli_for(bow, 0.).computeWeights(line_through)
+    # rotated pole
+    o = oracle.DataGen(72, 36, 1, 1)
+    o.rotatePole((20., 30.))
+    pts = oracle.assemble_points(o.bounds_lon, o.bounds_lat)
+    near_pole = numpy.array([(100., 70., 0.), (175., 86., 0.)])
+    with pytest.raises(oracle.UnsupportedCell) as ei:
+        oracle.polyline_weights(pts, near_pole)
+    with pytest.raises(NemofluxError, match=rf'cell {ei.value.cell}\b'):
+        pli_for(pts, 360.).computeWeights(near_pole)
+    dg = device_case(72, 36, 2, 1, PSI_ZT, (20., 30.))
+    with pytest.raises(RuntimeError, match='not convex'):                 # the Field surface raises like the reference
+        quiet_field(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, [near_pole])
+    # the closed loop that used to return 0.97 on this grid class through such a cell (rot36: apex at 80 N) is refused too
+    g = load_golden('rot36_zt')
+    with pytest.raises(RuntimeError, match='not convex'):
+        quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], g['u'], g['v'], [transect_xyz(T_TRI)])
+    f = quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], g['u'], g['v'], [transect_xyz(T_TRI50)])
+    assert numpy.abs(f.computeAll()[0]).max() <= 1e-11 and numpy.allclose(f.getCoverage()[0], 1.0, rtol=0, atol=1e-10)
+    # coverage: a transect that leaves a regional grid half way -> reported (and warned about), not an error
+    c = load_golden('cossin36')
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        fr = quiet_field(numpy.ascontiguousarray(c['bounds_lon'][:, :12]), numpy.ascontiguousarray(c['bounds_lat'][:, :12]),
+                         c['deptht_bounds'], numpy.ascontiguousarray(c['u'][..., :12]), numpy.ascontiguousarray(c['v'][..., :12]),
+                         [numpy.array([(-120., 0., 0.), (0., 0., 0.)]), numpy.array([(-170., -20., 0.), (-70., 30., 0.)])],
+                         periodX=0.)
+    cov = fr.getCoverage()
+    assert abs(cov[0][0] - 0.5) <= 1e-12 and abs(cov[1][0] - 1.0) <= 1e-12
+    assert any('not fully inside the grid' in str(w.message) for w in rec)

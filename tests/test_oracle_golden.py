@@ -295,3 +295,68 @@ def test_oracle_seam_crossing_batch_per_segment(oracle):
             tot, segs = oracle.get_integral(w, st.integratedVelocity, True)
             assert numpy.abs(segs - exact[p][t]).max() <= 2e-12 * 6 * (t + 1), (p, t)
             assert abs(tot - exact[p][t].sum()) <= 2e-12 * 6 * (t + 1) * len(segs), (p, t)
+
+
+# ------------------------------------------------------------------------------------------ cells A6 is not defined on
+def dart_grid():
+    """3 x 3 unit squares as independent quads; the middle cell's NE corner is pulled inside -> a reflex corner (dart)."""
+    o_pts = numpy.zeros((9, 4, 3))
+    for j in range(3):
+        for i in range(3):
+            o_pts[j * 3 + i, :, :2] = [(i, j), (i + 1, j), (i + 1, j + 1), (i, j + 1)]
+    good = o_pts.copy()
+    o_pts[4, 2, :2] = (1.3, 1.3)
+    return o_pts, good
+
+
+def test_oracle_refuses_nonconvex_and_pole_cells(oracle):
+    """SURVEY 7 "hard parts": cells whose (lon,lat) image is not a convex quad.  mint's behaviour there is pinned by
+    nothing in the reference, so the restatement never returns a number for a line that overlaps such a cell: it raises;
+    lines that stay clear of it are unaffected."""
+    bad, good = dart_grid()
+    line_through = numpy.array([(0.2, 1.4, 0.), (2.8, 1.6, 0.)])
+    line_clear = numpy.array([(0.2, 0.4, 0.), (2.8, 0.6, 0.), (2.5, 2.7, 0.)])
+    with pytest.raises(oracle.UnsupportedCell) as ei:
+        oracle.polyline_weights(bad, line_through, periodX=0.)
+    assert ei.value.cell == 4 and ei.value.kind == 1
+    a, b = oracle.polyline_weights(bad, line_clear, periodX=0.), oracle.polyline_weights(good, line_clear, periodX=0.)
+    assert a.as_dict() == b.as_dict() and numpy.allclose(a.coverage, 1.0, rtol=0, atol=1e-12)
+    # a line that only touches the dart in one point (its SW corner) carries no weight there: accepted
+    touch = numpy.array([(0.5, 1.5, 0.), (1.0, 1.0, 0.), (1.5, 0.5, 0.)])
+    assert numpy.allclose(oracle.polyline_weights(bad, touch, periodX=0.).coverage, 1.0, rtol=0, atol=1e-12)
+    # bow-tie (two corners swapped)
+    bow = good.copy()
+    bow[4, [1, 2]] = bow[4, [2, 1]]
+    with pytest.raises(oracle.UnsupportedCell):
+        oracle.polyline_weights(bow, line_through, periodX=0.)
+    # rotated pole: the four cells around each geographic pole have a corner AT the pole (arbitrary longitude)
+    o = oracle.DataGen(72, 36, 1, 1)
+    o.rotatePole((20., 30.))
+    pts = oracle.assemble_points(o.bounds_lon, o.bounds_lat)
+    pole_cells = set(numpy.nonzero((numpy.abs(pts[:, :, 1]) >= 90 - 1e-9).any(axis=1))[0].tolist())
+    assert len(pole_cells) == 8
+    with pytest.raises(oracle.UnsupportedCell) as ei:
+        oracle.polyline_weights(pts, numpy.array([(100., 70., 0.), (175., 86., 0.)]))
+    assert ei.value.cell in pole_cells
+    # away from them the planar tiling is consistent: coverage 1 and the lon / lat "edge data" integrate to the end-point
+    # differences (the coverage property), on closed and open lines
+    lonlat = [pts[:, :, 0], pts[:, :, 1]]
+    data = [numpy.stack([f[:, 1] - f[:, 0], f[:, 2] - f[:, 1], f[:, 2] - f[:, 3], f[:, 3] - f[:, 0]], axis=1) for f in lonlat]
+    rng = numpy.random.default_rng(3)
+    for trial in range(10):
+        n = int(rng.integers(2, 7))
+        xyz = numpy.zeros((n, 3))
+        xyz[:, 0], xyz[:, 1] = rng.uniform(-200, 200, n), rng.uniform(-75, 75, n)
+        w = oracle.polyline_weights(pts, xyz)
+        assert numpy.allclose(w.coverage, 1.0, rtol=0, atol=1e-10)
+        for k in (0, 1):
+            assert numpy.allclose(oracle.get_integral(w, data[k], True)[1], numpy.diff(xyz[:, k]), rtol=0, atol=1e-10)
+    # un-rotated grid: the top row has a whole EDGE on the pole line -- an ordinary rectangle in the plane, accepted
+    o0 = oracle.DataGen(36, 18, 1, 1)
+    p0 = oracle.assemble_points(o0.bounds_lon, o0.bounds_lat)
+    w = oracle.polyline_weights(p0, numpy.array([(-100., 85., 0.), (100., 88., 0.)]))
+    assert numpy.allclose(w.coverage, 1.0, rtol=0, atol=1e-12)
+    # partly outside a regional grid: coverage < 1 tells how much of the segment was found (mint only warns [recall])
+    reg = oracle.assemble_points(numpy.ascontiguousarray(o0.bounds_lon[:, :12]), numpy.ascontiguousarray(o0.bounds_lat[:, :12]))
+    w = oracle.polyline_weights(reg, numpy.array([(-120., 0., 0.), (0., 0., 0.)]), periodX=0.)
+    assert abs(w.coverage[0] - 0.5) <= 1e-12
