@@ -682,7 +682,7 @@ def test_weights_randomised_against_oracle(grid_kind, oracle):
                     want = numpy.diff(xyz[:, k])
                     assert numpy.allclose(segs, want, rtol=0, atol=1e-9), (grid_kind, trial, k)
                 assert numpy.allclose(pli.getCoverage(), 1.0, rtol=0, atol=1e-9)      # inside the grid, counted once
-    assert (refused > 0) == (grid_kind == 'rotated') and refused < 12
+    assert refused < 12 and (refused == 0 or grid_kind == 'rotated')
 
 
 @pytest.mark.parametrize('rotated', [False, True])
@@ -874,7 +874,7 @@ def _edge_form_checks(dg, xyzs, ref, nx, ny, nt):
     got = dict(zip(zip(sge.tolist(), el.tolist()), we.tolist()))
     assert len(got) == el.size and set(got) == set(want)                 # merged: every (segment, element) once
     assert max(abs(got[k] - want[k]) for k in want) <= 4 * EPS
-    assert el.size < 0.75 * ce.size                                       # adjacent cells share their edge
+    assert el.size < 0.8 * ce.size               # ~3 entries per crossed cell: consecutive cells share the edge the line crosses
     order = numpy.lexsort((el, sge))
     assert numpy.array_equal(order, numpy.arange(el.size))               # sorted by (segment, element)
     for t in range(nt):
