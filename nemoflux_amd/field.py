@@ -152,7 +152,7 @@ class Field(object):
     # ------------------------------------------------------------------------------------------
     def _setup(self, bounds_lon, bounds_lat, deptht_bounds, uo, vo, lonLatZPoints, sverdrup,
                fill_value=numpy.nan, periodX=360., numCellsPerBucket=128, slab_range=None, readback=True,
-               timeValues=None, stream=None, timeObj=None, compact=False):
+               timeValues=None, stream=None, timeObj=None, compact=False, prefetch=True):
         _lib.require_gpu()
         self.sverdrup = sverdrup
         self.periodX = periodX
@@ -200,7 +200,13 @@ class Field(object):
             self._lazy_dtype = numpy.dtype(uo.dtype).newbyteorder('=')
             self._uv_code, self._fill = _dtype_code(uo), float(fill_value)
             self._lazy_step = (-1, None, None)
-            self._lazy_buf = None
+            # two slots of pinned (u, v) step buffers: while the GPU works on the step in one slot, a background thread
+            # inflates the next step of the file into the other (_stage_step / _prefetch below)
+            self._lazy_slots = [None, None]
+            self._lazy_slot_step = [-1, -1]
+            self._lazy_pending = None          # (future, step, slot) of the running prefetch
+            self._lazy_pool = None
+            self._lazy_prefetch = bool(prefetch)
             pu = pv = None
             uv_dev = 0
         elif pu is None:
@@ -318,6 +324,8 @@ class Field(object):
 
     def __del__(self):
         try:
+            if getattr(self, '_lazy_pool', None) is not None:
+                self._lazy_pool.shutdown(wait=True)      # the prefetch thread writes into buffers this object owns
             if getattr(self, '_h', None):
                 lib.nf_field_del(ctypes.byref(self._h))
         except Exception:
@@ -362,29 +370,74 @@ class Field(object):
         return int(nt), int(nz), int(ny), int(nx)
 
     # ------------------------------------------------------------------------------------------
-    def _compute(self, tIndex, readback=None):
+    # ---- file-backed fields: double-buffered staging -------------------------------------------------------------
+    def _stage_step(self, tIndex, slot):
+        """Inflate / copy time step tIndex of (uo, vo) into the pinned buffers of `slot` (runs on the prefetch thread or
+        on the caller's; zlib, the native un-shuffle and numpy's copies all release the GIL)."""
+        self._lazy_alloc(slot)
+
+        def step_of(src, buf):   # LazyVariable / StepView, or a plain / memory-mapped array (either file may be either)
+            if hasattr(src, 'read_step'):
+                if numpy.dtype(src.dtype) == self._lazy_dtype:
+                    return src.read_step(tIndex, out=buf)
+                numpy.copyto(buf, src.read_step(tIndex))
+                return buf
+            numpy.copyto(buf, src[tIndex] if len(src.shape) == 4 else src)
+            return buf
+        bu, bv = self._lazy_slots[slot]
+        self._lazy_slot_step[slot] = -1
+        step_of(self._lazy[0], bu)
+        step_of(self._lazy[1], bv)
+        self._lazy_slot_step[slot] = tIndex
+        return bu, bv
+
+    def _lazy_alloc(self, slot):
+        if self._lazy_slots[slot] is None:   # pinned, re-used for every step: no page faults per step, pinned H2D
+            shp = (self.nz, self.ny, self.nx)
+            self._lazy_slots[slot] = (self._host_array(shp, self._lazy_dtype), self._host_array(shp, self._lazy_dtype))
+
+    def _lazy_wait(self):
+        if self._lazy_pending is not None:
+            fut = self._lazy_pending[0]
+            self._lazy_pending = None
+            fut.result()        # re-raises a read error of the background thread here, in the caller
+
+    def _lazy_get(self, tIndex):
+        """Pinned (u, v) buffers holding step tIndex: prefetched already, being prefetched, or read now."""
+        self._lazy_wait()
+        for slot in (0, 1):
+            if self._lazy_slot_step[slot] == tIndex:
+                self._lazy_cur = slot
+                return self._lazy_slots[slot]
+        slot = 1 - getattr(self, '_lazy_cur', 1)      # never the slot the engine may still be copying from
+        self._lazy_cur = slot
+        return self._stage_step(tIndex, slot)
+
+    def _prefetch(self, tIndex):
+        if not (0 <= tIndex < self.nt) or tIndex in self._lazy_slot_step:
+            return
+        if self._lazy_pool is None:
+            import concurrent.futures
+            self._lazy_pool = concurrent.futures.ThreadPoolExecutor(1, thread_name_prefix='nf-prefetch')
+        slot = 1 - self._lazy_cur
+        self._lazy_alloc(slot)       # HIP calls stay on the caller's thread; the worker only fills the buffers
+        self._lazy_pending = (self._lazy_pool.submit(self._stage_step, tIndex, slot), tIndex, slot)
+
+    def _compute(self, tIndex, readback=None, prefetch_next=None):
         if not (0 <= tIndex < self.nt):
             raise RuntimeError(f'ERROR: time index {tIndex} out of range [0, {self.nt})')
         if self._lazy is not None and self._lazy_step[0] != tIndex:
             # one time step from the file; the engine sees a virtual (nt, nz, ny, nx) base that it only
             # dereferences at step tIndex
-            if self._lazy_buf is None:   # two pinned step buffers, re-used for every time step (no page faults per
-                shp = (self.nz, self.ny, self.nx)   # step, and the H2D copy of the engine runs from pinned memory)
-                self._lazy_buf = [self._host_array(shp, self._lazy_dtype), self._host_array(shp, self._lazy_dtype)]
-
-            def step_of(src, buf):   # LazyVariable / StepView, or a plain / memory-mapped array (either file may be either)
-                if hasattr(src, 'read_step'):
-                    if numpy.dtype(src.dtype) == self._lazy_dtype:
-                        return src.read_step(tIndex, out=buf)
-                    numpy.copyto(buf, src.read_step(tIndex))
-                    return buf
-                numpy.copyto(buf, src[tIndex] if len(src.shape) == 4 else src)
-                return buf
-            au, av = step_of(self._lazy[0], self._lazy_buf[0]), step_of(self._lazy[1], self._lazy_buf[1])
+            au, av = self._lazy_get(tIndex)
             self._lazy_step = (tIndex, au, av)
             off = tIndex * au.nbytes
             check(lib.nf_field_set_uv(ctypes.byref(self._h), au.ctypes.data - off, av.ctypes.data - off, self.nt,
                                       self._uv_code, 0, self._fill))
+            if self._lazy_prefetch and self.nt > 1:
+                # the next step (fluxviz's 't' key, fluxplot's loop) inflates on host threads while the GPU works on
+                # this one: the blocking C call below releases the GIL
+                self._prefetch((tIndex + 1) % self.nt if prefetch_next is None else prefetch_next)
         check(lib.nf_field_compute_flux(ctypes.byref(self._h), int(tIndex), _lib.dptr(self._row)))
         self._row_valid = True
         if self._readback if readback is None else readback:
@@ -422,8 +475,10 @@ class Field(object):
         totals and (nt, nseg) per-segment sums.  `out`: optional torch CUDA tensor (nt, row_length) to
         receive the raw rows in HBM (for the RCCL reduce of nemoflux_amd.dist)."""
         import torch
-        if self._lazy is not None:   # file-backed, one step in memory at a time
-            rows = numpy.array([self._compute(t, readback=False).copy() for t in range(self.nt)])
+        if self._lazy is not None:
+            # file-backed: one step on the GPU, the next one inflating into the other pinned slot (no wrap-around prefetch
+            # after the last step)
+            rows = numpy.array([self._compute(t, readback=False, prefetch_next=t + 1).copy() for t in range(self.nt)])
             if out is not None:
                 out.copy_(torch.from_numpy(rows))
             return rows[:, self._nseg:self._nseg + len(self.plis)], rows[:, :self._nseg]

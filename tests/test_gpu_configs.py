@@ -957,3 +957,51 @@ def test_refuses_nonconvex_and_pole_cells(oracle):
     cov = fr.getCoverage()
     assert abs(cov[0][0] - 0.5) <= 1e-12 and abs(cov[1][0] - 1.0) <= 1e-12
     assert any('not fully inside the grid' in str(w.message) for w in rec)
+
+
+@pytest.mark.parametrize('prefetch', [True, False])
+def test_file_backed_field_against_the_oracle(prefetch, oracle):
+    """File-backed Field (NetCDF-4-style HDF5: float32, uo chunked + shuffled + deflated, _FillValue 1e20 / NaN land)
+    against the CPU ORACLE on the values the file decodes to -- not against another HIP run: every step's full fields bit
+    for bit, every transect / segment total to rounding, with the double-buffered prefetch (next step inflating on host
+    threads while the GPU works on this one) and without it, in file order, out of order and through computeAll."""
+    import contextlib
+    import io as _io
+    from nemoflux_amd import hdf5min
+    from nemoflux_amd.field import Field
+    h5 = os.path.join(GOLDEN, 'h5')
+    tr = [transect_xyz(T_OPEN), transect_xyz("(-180,-70),(-160,-10),(-35,40),(20,-50),(60,50),(180,40)")]
+    with contextlib.redirect_stdout(_io.StringIO()):
+        ff = Field(os.path.join(h5, 'nemo_T.h5'), os.path.join(h5, 'nemo_U.h5'), os.path.join(h5, 'nemo_V.h5'), tr,
+                   prefetch=prefetch)
+    # the decoded values, straight from the parser (pinned to h5py's own read-back in tests/test_hdf5min.py)
+    with hdf5min.File(os.path.join(h5, 'nemo_T.h5')) as f:
+        blon, blat = f.datasets['bounds_lon'].read(), f.datasets['bounds_lat'].read()
+        db = f.datasets['deptht_bounds'].read()
+    with hdf5min.File(os.path.join(h5, 'nemo_U.h5')) as f:
+        u = numpy.array(f.datasets['uo'].read())
+        fill = float(f.datasets['uo'].fill_value)
+    with hdf5min.File(os.path.join(h5, 'nemo_V.h5')) as f:
+        v = numpy.array(f.datasets['vo'].read())
+    assert u.dtype == numpy.float32 and (u == numpy.float32(1.e20)).any() and numpy.isnan(v).any()
+    nt, nz, ny, nx = u.shape
+    pts = oracle.assemble_points(blon.astype(numpy.float64), blat.astype(numpy.float64))
+    th = (db[:, 1] - db[:, 0]).astype(numpy.float64)
+    ows = [oracle.polyline_weights(pts, xyz) for xyz in tr]
+    want_rows = []
+    st = oracle.EdgeFluxState(ny, nx)
+    fields = []
+    for t in range(nt):
+        oracle.edge_flux(st, oracle.vertical_integral(u[t], th, fill), oracle.vertical_integral(v[t], th, fill), ff.arcLengths)
+        fields.append(st.integratedVelocity.copy())
+        want_rows.append([oracle.get_integral(w, st.integratedVelocity) for w in ows])
+    want_rows = numpy.array(want_rows)
+    bound = 1e-12 * max(numpy.abs(w.weight * fields[-1].reshape(-1)[w.cell_edge]).sum() for w in ows) * nt
+    for t in (0, 1, 2, 1, 0, 2):                                    # in order, backwards, repeated
+        got = ff.computeFlux(t, readback=True)
+        assert numpy.array_equal(ff.integratedVelocity, fields[t]), t
+        assert numpy.abs(numpy.array(got) - want_rows[t]).max() <= bound
+    tot, segs = ff.computeAll()
+    assert numpy.abs(tot - want_rows).max() <= bound
+    tot2, _ = ff.computeAll()
+    assert numpy.array_equal(tot, tot2)
