@@ -98,3 +98,46 @@ def test_c5_full_size_seam_crossing_batch(real):
     assert ncross > 200                                     # hundreds of target segments cut through the seam
     tot, segs, off, nrec = _run_case(psi, polys, real)
     _check(psi, polys, real, tot, segs, off)
+
+
+@pytest.mark.parametrize('real', ['float64', 'float32'])
+def test_c4_size_land_block_is_filled_with_zero(real):
+    """SURVEY 8d "land / missing variant" at the C4 grid size (2 time steps): a rectangular block of u, v overwritten with
+    NaN and with the _FillValue 1e20 must give bit-for-bit the rows and fields of the same data with zeros in the block
+    (field.py:157 fillna(0.0); README.md:118), through the full-size vector path of the flux kernel."""
+    import contextlib
+    import io
+    import torch
+    from nemoflux_amd.datagen import DataGen, STREAM_FUNCTIONS
+    from nemoflux_amd.field import Field
+    nt = 2
+    dg = DataGen(real=real)
+    dg.setSizes(NX, NY, NZ, nt)
+    dg.setBoundingBox(*BOX, 0., 1.)
+    dg.build()
+    dg.applyStreamFunction(STREAM_FUNCTIONS[3])
+    u, v = dg.computeUVFromPotential()
+    polys = bench.make_transects(NX, NY, *BOX, 8, seed=5, seam=True)
+    xyzs = [numpy.array([(x, y, 0.) for x, y in p]) for p in polys]
+    blk = (slice(None), slice(10, 60), slice(700, 1100), slice(1500, 2301))      # odd width: unaligned block edges
+
+    def rows_and_field(fill_u, fill_v, fill_value):
+        u[blk] = fill_u
+        v[blk] = fill_v
+        with contextlib.redirect_stdout(io.StringIO()):
+            fld = Field.fromArrays(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, u, v, xyzs, fill_value=fill_value)
+        tot, segs = fld.computeAll()
+        fld.timeIndex = 1
+        fld.update()
+        return tot, segs, fld.integratedVelocity.copy(), fld.edgeFluxesUArray.copy(), fld.maxAbsFlux
+
+    ref = rows_and_field(0.0, 0.0, float('nan'))
+    for fu, fv, fval in ((float('nan'), float('nan'), float('nan')), (1.e20, float('nan'), 1.e20), (float('nan'), 1.e20, 1.e20)):
+        got = rows_and_field(fu, fv, fval)
+        for a, b in zip(ref, got):
+            assert numpy.array_equal(a, b)
+    iv = ref[2].reshape(NY, NX, 4)
+    assert numpy.all(iv[800:1000, 1600:2200, 1:3] != 0)          # levels 0-9 and 60-74 still carry flux through the block
+    del dg, u, v
+    gc.collect()
+    torch.cuda.empty_cache()
