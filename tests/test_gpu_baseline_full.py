@@ -125,10 +125,10 @@ def test_c4_size_land_block_is_filled_with_zero(real):
         u[blk] = fill_u
         v[blk] = fill_v
         with contextlib.redirect_stdout(io.StringIO()):
-            fld = Field.fromArrays(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, u, v, xyzs, fill_value=fill_value)
+            fld = Field.fromArrays(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, u, v, xyzs, fill_value=fill_value,
+                                   readback=False)
         tot, segs = fld.computeAll()
-        fld.timeIndex = 1
-        fld.update()
+        fld.computeFlux(1, readback=True)
         return tot, segs, fld.integratedVelocity.copy(), fld.edgeFluxesUArray.copy(), fld.maxAbsFlux
 
     ref = rows_and_field(0.0, 0.0, float('nan'))
