@@ -215,6 +215,29 @@ int nf_field_timing_read(nf_field **self, long *launches, double *total_ms);
 /* how the total of the last nf_field_timing_read splits between the flux kernel and the expansion kernel behind it */
 int nf_field_timing_split(nf_field **self, double *flux_ms, double *expand_ms);
 
+/* ------------------------------------------------------------------ file ingest straight to HBM (field.py:149) */
+/* Real NEMO files are NetCDF-4 = HDF5 with uo / vo stored as byte-shuffled, deflated chunks; the reference has netCDF4 /
+ * xarray inflate one time step on the host at every update (field.py:149: nc[name][timeIndex, :, :, :]).  Here the
+ * compressed chunks are handed over as they sit in the file and are inflated on the device, one wavefront per chunk
+ * (RFC 1950/1951 decoder with the Adler-32 check, then the inverse of HDF5's shuffle filter), into out_dev.
+ *   comp_host  : host buffer (pinned for an asynchronous copy) holding the compressed chunks, comp_bytes long
+ *   in_off/in_len[i] : where chunk i's zlib stream sits in comp_host
+ *   chunk_bytes      : decoded size of every chunk = cz*cy*cx*elem_size (checked against what each stream inflates to)
+ *   elem_size        : 4 or 8 (1 for raw bytes); shuffled != 0: the chunks went through HDF5's shuffle filter
+ *   chunk_dims (3)   : (cz, cy, cx) of a chunk; slab_dims (3): (nz, ny, nx) of the time step; origin (nchunks x 3): where
+ *                      each chunk starts in the slab -- chunks may tile y and x, edge chunks may hang over the slab
+ *   out_dev          : the slab in HBM, nz*ny*nx*elem_size bytes
+ *   status_host (nchunks ints or NULL): 0 = fine, else the decoder's error code per chunk
+ * Synchronous on hip_stream.  NF_ERR_ARG (message names the first bad chunk) if any stream is malformed -- the slab is
+ * then undefined; nothing outside it is ever written. */
+typedef struct nf_inflater nf_inflater;
+int nf_inflater_new(nf_inflater **self);
+int nf_inflater_del(nf_inflater **self);
+int nf_inflater_run(nf_inflater **self, const void *comp_host, size_t comp_bytes, const long long *in_off,
+                    const long long *in_len, int nchunks, long long chunk_bytes, int elem_size, int shuffled,
+                    const long long *chunk_dims, const long long *slab_dims, const long long *origin, void *out_dev,
+                    void *hip_stream, int *status_host);
+
 /* ------------------------------------------------------------------ synthetic data (datagen.py) */
 /* Stream functions offered on device (no eval on the GPU): psi = g(z,t) * h(x,y)
  *   0 "x"                                                    README.md:26

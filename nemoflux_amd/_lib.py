@@ -116,6 +116,11 @@ _sig('nf_field_grid', [_pp, _pp])
 _sig('nf_field_timing', [_pp, ctypes.c_int])
 _sig('nf_field_timing_read', [_pp, ctypes.POINTER(ctypes.c_long), c_double_p])
 _sig('nf_field_timing_split', [_pp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)])
+c_ll_p = ctypes.POINTER(ctypes.c_longlong)
+_sig('nf_inflater_new', [_pp])
+_sig('nf_inflater_del', [_pp])
+_sig('nf_inflater_run', [_pp, ctypes.c_void_p, ctypes.c_size_t, c_ll_p, c_ll_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int,
+                         ctypes.c_int, c_ll_p, c_ll_p, c_ll_p, ctypes.c_void_p, ctypes.c_void_p, c_int_p])
 _sig('nf_datagen_bounds', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_long] + [ctypes.c_double] * 6 +
      [ctypes.c_int, ctypes.c_void_p])
 _sig('nf_datagen_uv', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_long] * 6 + [ctypes.c_double] * 6 +

@@ -1,0 +1,257 @@
+// nf_inflate.hip -- file ingest straight to HBM: the deflated (and byte-shuffled) HDF5 chunks of one time step of uo / vo
+// are copied to the device as they sit in the NetCDF-4 file and inflated there, one wavefront per chunk, into the staging
+// slab the flux kernel reads.
+//
+// Replaces  nemoflux/field.py:149   nc[name][timeIndex, :, :, :]   -- the lazy NetCDF read, i.e. HDF5's filter pipeline
+//           (deflate, then un-shuffle) that netCDF4/xarray run on the host for every time step.
+//
+// The decoder itself is nf_inflate_core.h (RFC 1950/1951, Adler-32 checked).  One workgroup = one wavefront = one stream;
+// its 47 KiB state (32 KiB window, input ring, lookup tables) lives in LDS, so three streams run per CU and several hundred
+// at once on the chip -- the format is serial inside a stream, the parallelism is across the chunks (75 levels x 2 fields
+// per time step in XIOS output).  HDF5's shuffle filter stored the bytes of every element de-interleaved (all first bytes,
+// then all second bytes, ...): k_place gathers them back, one element per lane, coalesced on both sides, and puts the
+// chunk where it belongs in the (nz, ny, nx) slab (chunks may tile y and x, edge chunks hang over).
+#include <vector>
+
+#include "nf_common.h"
+#include "nf_inflate_core.h"
+
+namespace nf {
+
+struct InflateJob {
+    unsigned long long in_off;    // first byte of the zlib stream in the compressed buffer
+    unsigned in_len;
+    unsigned z0, y0, x0;          // origin of the chunk in the slab (elements)
+};
+
+// inflate chunk i into slot i of tmp (chunk_bytes each)
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp, unsigned long long comp_bytes,
+                                                const InflateJob *__restrict__ jobs, int njobs, uint8_t *__restrict__ tmp,
+                                                unsigned chunk_bytes, int *__restrict__ status)
+{
+    __shared__ NfiCtx ctx;
+    const int i = blockIdx.x;
+    if (i >= njobs) return;
+    const InflateJob job = jobs[i];
+    const unsigned long long first = job.in_off & ~3ull;                 // the word that holds the stream's first byte
+    unsigned long long readable = comp_bytes - first;                    // comp_bytes is a multiple of 4 (padded by the host)
+    const unsigned long long want = (job.in_off - first) + job.in_len + 16ull;
+    if (readable > want) readable = want & ~3ull;
+    const int rc = nfi_inflate_stream(ctx, comp + job.in_off, job.in_len, (uint32_t)readable,
+                                      tmp + (unsigned long long)i * chunk_bytes, chunk_bytes);
+    if (threadIdx.x == 0) status[i] = rc;
+}
+
+// Inverse of HDF5's shuffle filter + placement of the chunk in the slab, one chunk per blockIdx.y.  A shuffled chunk holds
+// the ES byte planes of its n elements one after the other; an element of the chunk at (a, b, c) of its (cz, cy, cx) box
+// goes to ((z0+a)*ny + y0+b)*nx + x0+c of the (nz, ny, nx) slab; the parts of an edge chunk that hang over the slab are
+// dropped.  One element per lane: byte-plane reads and element writes are both coalesced along x.
+struct SlabGeom {
+    unsigned cz, cy, cx, nz, ny, nx;
+};
+template <int ES, bool SHUFFLED>
+__global__ __launch_bounds__(kBlock) void k_place(const uint8_t *__restrict__ tmp, unsigned chunk_bytes,
+                                                  const InflateJob *__restrict__ jobs, SlabGeom g, uint8_t *__restrict__ dst)
+{
+    const InflateJob job = jobs[blockIdx.y];
+    const unsigned long long n = (unsigned long long)g.cz * g.cy * g.cx;
+    const uint8_t *s = tmp + (unsigned long long)blockIdx.y * chunk_bytes;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; e < n;
+         e += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned c = (unsigned)(e % g.cx);
+        const unsigned long long r = e / g.cx;
+        const unsigned b = (unsigned)(r % g.cy), a = (unsigned)(r / g.cy);
+        const unsigned z = job.z0 + a, y = job.y0 + b, x = job.x0 + c;
+        if (z >= g.nz || y >= g.ny || x >= g.nx) continue;
+        const unsigned long long o = ((unsigned long long)z * g.ny + y) * g.nx + x;
+        if (ES == 1) {
+            dst[o] = s[e];
+        } else if (ES == 4) {
+            uint32_t v;
+            if (SHUFFLED) v = (uint32_t)s[e] | ((uint32_t)s[n + e] << 8) | ((uint32_t)s[2 * n + e] << 16) | ((uint32_t)s[3 * n + e] << 24);
+            else v = reinterpret_cast<const uint32_t *>(s)[e];
+            reinterpret_cast<uint32_t *>(dst)[o] = v;
+        } else {
+            uint64_t v = 0;
+            if (SHUFFLED) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v |= (uint64_t)s[(unsigned long long)k * n + e] << (8 * k);
+            } else {
+                v = reinterpret_cast<const uint64_t *>(s)[e];
+            }
+            reinterpret_cast<uint64_t *>(dst)[o] = v;
+        }
+    }
+}
+
+struct Inflater {
+    uint8_t *d_comp = nullptr, *d_tmp = nullptr;
+    InflateJob *d_jobs = nullptr;
+    int *d_status = nullptr;
+    size_t comp_cap = 0, tmp_cap = 0, jobs_cap = 0;
+    void release()
+    {
+        for (void *p : {(void *)d_comp, (void *)d_tmp, (void *)d_jobs, (void *)d_status})
+            if (p) (void)hipFree(p);
+        d_comp = d_tmp = nullptr;
+        d_jobs = nullptr;
+        d_status = nullptr;
+        comp_cap = tmp_cap = jobs_cap = 0;
+    }
+};
+
+static const char *inflate_error_name(int rc)
+{
+    switch (rc) {
+        case NFI_ERR_HEADER: return "not a zlib stream";
+        case NFI_ERR_BLOCK: return "bad block header";
+        case NFI_ERR_CODES: return "invalid Huffman code set";
+        case NFI_ERR_SYMBOL: return "invalid code in the data";
+        case NFI_ERR_DISTANCE: return "match distance before the start of the chunk";
+        case NFI_ERR_OUTPUT: return "decoded length differs from the chunk size";
+        case NFI_ERR_INPUT: return "compressed stream is truncated";
+        case NFI_ERR_CHECKSUM: return "Adler-32 mismatch";
+        default: return "unknown error";
+    }
+}
+
+int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const long long *in_off, const long long *in_len,
+                 int n, long long chunk_bytes, int elem_size, int shuffled, const long long *chunk_dims,
+                 const long long *slab_dims, const long long *origin, void *out_dev, hipStream_t s, int *status_host)
+{
+    NF_REQUIRE(h && chunk_dims && slab_dims && (n == 0 || (comp_host && in_off && in_len && origin && out_dev)), NF_ERR_ARG,
+               "inflate: null argument");
+    NF_REQUIRE(elem_size == 1 || elem_size == 4 || elem_size == 8, NF_ERR_ARG, "inflate: element size must be 1, 4 or 8");
+    NF_REQUIRE(!(shuffled && elem_size == 1), NF_ERR_ARG, "inflate: single bytes cannot be shuffled");
+    for (int k = 0; k < 3; ++k)
+        NF_REQUIRE(chunk_dims[k] > 0 && slab_dims[k] > 0 && chunk_dims[k] < (1ll << 31) && slab_dims[k] < (1ll << 31), NF_ERR_ARG,
+                   "inflate: bad chunk / slab dimensions");
+    NF_REQUIRE(chunk_bytes == chunk_dims[0] * chunk_dims[1] * chunk_dims[2] * elem_size && chunk_bytes < (1ll << 31), NF_ERR_ARG,
+               "inflate: chunk_bytes does not match the chunk dimensions (chunks of up to 2 GiB)");
+    if (n == 0) return NF_OK;
+    std::vector<InflateJob> jobs((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        NF_REQUIRE(in_off[i] >= 0 && in_len[i] >= 0 && (size_t)(in_off[i] + in_len[i]) <= comp_bytes && in_len[i] < (1ll << 31),
+                   NF_ERR_ARG, "inflate: a compressed chunk lies outside the buffer");
+        for (int k = 0; k < 3; ++k)
+            NF_REQUIRE(origin[3 * i + k] >= 0 && origin[3 * i + k] < slab_dims[k], NF_ERR_ARG,
+                       "inflate: a chunk starts outside the slab");
+        jobs[i] = InflateJob{(unsigned long long)in_off[i], (unsigned)in_len[i], (unsigned)origin[3 * i], (unsigned)origin[3 * i + 1],
+                             (unsigned)origin[3 * i + 2]};
+    }
+    const size_t comp_pad = ((comp_bytes + 3) & ~(size_t)3) + 32;      // whole words + slack the ring may read (never interprets)
+    const size_t tmp_bytes = (size_t)chunk_bytes * (size_t)n;
+    if (h->comp_cap < comp_pad) {
+        if (h->d_comp) (void)hipFree(h->d_comp);
+        h->d_comp = nullptr;
+        h->comp_cap = 0;
+        NF_HIP(hipMalloc((void **)&h->d_comp, comp_pad));
+        h->comp_cap = comp_pad;
+    }
+    if (h->tmp_cap < tmp_bytes) {
+        if (h->d_tmp) (void)hipFree(h->d_tmp);
+        h->d_tmp = nullptr;
+        h->tmp_cap = 0;
+        NF_HIP(hipMalloc((void **)&h->d_tmp, tmp_bytes));
+        h->tmp_cap = tmp_bytes;
+    }
+    if (h->jobs_cap < (size_t)n) {
+        if (h->d_jobs) (void)hipFree(h->d_jobs);
+        if (h->d_status) (void)hipFree(h->d_status);
+        h->d_jobs = nullptr;
+        h->d_status = nullptr;
+        h->jobs_cap = 0;
+        NF_HIP(hipMalloc((void **)&h->d_jobs, sizeof(InflateJob) * (size_t)n));
+        NF_HIP(hipMalloc((void **)&h->d_status, sizeof(int) * (size_t)n));
+        h->jobs_cap = (size_t)n;
+    }
+    NF_HIP(hipMemsetAsync(h->d_comp + (comp_pad - 64), 0, 64, s));      // the padding behind the data
+    NF_HIP(hipMemcpyAsync(h->d_comp, comp_host, comp_bytes, hipMemcpyHostToDevice, s));
+    NF_HIP(hipMemcpyAsync(h->d_jobs, jobs.data(), sizeof(InflateJob) * (size_t)n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)n), dim3(64), 0, s, h->d_comp, (unsigned long long)(comp_pad - 32),
+                       h->d_jobs, n, h->d_tmp, (unsigned)chunk_bytes, h->d_status);
+    const SlabGeom g{(unsigned)chunk_dims[0], (unsigned)chunk_dims[1], (unsigned)chunk_dims[2], (unsigned)slab_dims[0],
+                     (unsigned)slab_dims[1], (unsigned)slab_dims[2]};
+    const long long nelem = chunk_bytes / elem_size;
+    unsigned gx = (unsigned)std::min<long long>(4096, (nelem + kBlock - 1) / kBlock);
+    if (gx == 0) gx = 1;
+    const dim3 grid(gx, (unsigned)n), block(kBlock);
+    uint8_t *dst = (uint8_t *)out_dev;
+    if (elem_size == 1) hipLaunchKernelGGL((k_place<1, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, g, dst);
+    else if (elem_size == 4 && shuffled) hipLaunchKernelGGL((k_place<4, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, g, dst);
+    else if (elem_size == 4) hipLaunchKernelGGL((k_place<4, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, g, dst);
+    else if (shuffled) hipLaunchKernelGGL((k_place<8, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, g, dst);
+    else hipLaunchKernelGGL((k_place<8, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, g, dst);
+    NF_HIP(hipGetLastError());
+    std::vector<int> status((size_t)n, 0);
+    NF_HIP(hipMemcpyAsync(status.data(), h->d_status, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+    NF_HIP(hipStreamSynchronize(s));    // jobs / status vectors are pageable host memory: the copies above are done now
+    int bad = -1;
+    for (int i = 0; i < n; ++i) {
+        if (status_host) status_host[i] = status[i];
+        if (status[i] != 0 && bad < 0) bad = i;
+    }
+    if (bad >= 0) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "inflate: chunk %d of %d: %s (code %d)", bad, n, inflate_error_name(status[bad]), status[bad]);
+        set_error(buf);
+        return NF_ERR_ARG;
+    }
+    return NF_OK;
+}
+
+}  // namespace nf
+
+// ------------------------------------------------------------------------------------------------------- C ABI
+using namespace nf;
+extern "C" {
+
+int nf_inflater_new(nf_inflater **self)
+{
+    if (!self) {
+        set_error("nf_inflater_new: null argument");
+        return NF_ERR_ARG;
+    }
+    *self = reinterpret_cast<nf_inflater *>(new (std::nothrow) Inflater());
+    if (!*self) {
+        set_error("out of host memory");
+        return NF_ERR_HOST;
+    }
+    return NF_OK;
+}
+
+int nf_inflater_del(nf_inflater **self)
+{
+    if (self && *self) {
+        Inflater *h = reinterpret_cast<Inflater *>(*self);
+        h->release();
+        delete h;
+        *self = nullptr;
+    }
+    return NF_OK;
+}
+
+int nf_inflater_run(nf_inflater **self, const void *comp_host, size_t comp_bytes, const long long *in_off,
+                    const long long *in_len, int nchunks, long long chunk_bytes, int elem_size, int shuffled,
+                    const long long *chunk_dims, const long long *slab_dims, const long long *origin, void *out_dev,
+                    void *hip_stream, int *status_host)
+{
+    if (!self || !*self) {
+        set_error("nf_inflater_run: null handle");
+        return NF_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no usable AMD GPU (hipGetDeviceCount); nemoflux_amd has no CPU fallback");
+        return NF_ERR_NO_DEVICE;
+    }
+    try {
+        return inflater_run(reinterpret_cast<Inflater *>(*self), comp_host, comp_bytes, in_off, in_len, nchunks, chunk_bytes,
+                            elem_size, shuffled, chunk_dims, slab_dims, origin, out_dev, (hipStream_t)hip_stream, status_host);
+    } catch (...) {
+        set_error("nf_inflater_run: out of host memory");
+        return NF_ERR_HOST;
+    }
+}
+
+}  // extern "C"

@@ -152,7 +152,7 @@ class Field(object):
     # ------------------------------------------------------------------------------------------
     def _setup(self, bounds_lon, bounds_lat, deptht_bounds, uo, vo, lonLatZPoints, sverdrup,
                fill_value=numpy.nan, periodX=360., numCellsPerBucket=128, slab_range=None, readback=True,
-               timeValues=None, stream=None, timeObj=None, compact=False, prefetch=True):
+               timeValues=None, stream=None, timeObj=None, compact=False, prefetch=True, gpu_decode=True):
         _lib.require_gpu()
         self.sverdrup = sverdrup
         self.periodX = periodX
@@ -207,6 +207,17 @@ class Field(object):
             self._lazy_pending = None          # (future, step, slot) of the running prefetch
             self._lazy_pool = None
             self._lazy_prefetch = bool(prefetch)
+            # Deflated chunks the device can take (hdf5min.Dataset.device_plan: what netCDF-4 / XIOS write) are copied to HBM
+            # compressed and inflated THERE (nemoflux_amd.ingest, nf_inflate.hip) instead of by zlib on the host cores;
+            # anything else keeps the host path.  comp_bytes[k]: staging size for variable k, None = host path.
+            self._lazy_dev = None
+            import os
+            if gpu_decode and os.environ.get('NF_GPU_INFLATE', '1') != '0':
+                from .ingest import ChunkDecoder
+                need = [ChunkDecoder.staging_bytes(src, self.nt) if hasattr(src, 'device_plan') else None for src in (uo, vo)]
+                if any(n is not None for n in need):
+                    self._lazy_dev = dict(decoder=ChunkDecoder(), comp_bytes=need, comp=[None, None], slab=[None, None],
+                                          staged=[None, None], uploaded=[-1, -1])
             pu = pv = None
             uv_dev = 0
         elif pu is None:
@@ -372,8 +383,9 @@ class Field(object):
     # ------------------------------------------------------------------------------------------
     # ---- file-backed fields: double-buffered staging -------------------------------------------------------------
     def _stage_step(self, tIndex, slot):
-        """Inflate / copy time step tIndex of (uo, vo) into the pinned buffers of `slot` (runs on the prefetch thread or
-        on the caller's; zlib, the native un-shuffle and numpy's copies all release the GIL)."""
+        """Host half of staging time step tIndex into `slot` (runs on the prefetch thread or on the caller's; zlib, the native
+        un-shuffle, memcpy and numpy's copies all release the GIL): a variable the device can decode only has its compressed
+        chunks gathered into pinned memory, any other one is inflated / copied into the slot's pinned step buffer."""
         self._lazy_alloc(slot)
 
         def step_of(src, buf):   # LazyVariable / StepView, or a plain / memory-mapped array (either file may be either)
@@ -384,17 +396,48 @@ class Field(object):
                 return buf
             numpy.copyto(buf, src[tIndex] if len(src.shape) == 4 else src)
             return buf
-        bu, bv = self._lazy_slots[slot]
         self._lazy_slot_step[slot] = -1
-        step_of(self._lazy[0], bu)
-        step_of(self._lazy[1], bv)
+        dev = self._lazy_dev
+        for k in (0, 1):
+            if dev is not None and dev['comp_bytes'][k] is not None:
+                src = self._lazy[k]
+                dev['staged'][slot][k] = dev['decoder'].gather(src.raw_bytes(), src.device_plan(tIndex), dev['comp'][slot][k])
+            else:
+                step_of(self._lazy[k], self._lazy_slots[slot][k])
+        if dev is not None:
+            dev['uploaded'][slot] = -1
         self._lazy_slot_step[slot] = tIndex
-        return bu, bv
+        return self._lazy_slots[slot]
+
+    def _lazy_upload(self, tIndex, slot):
+        """Device half (caller's thread): compressed chunks -> HBM -> inflate + un-shuffle + placement there; host-decoded
+        variables are copied into their slab.  Returns the two slabs' HBM addresses."""
+        dev = self._lazy_dev
+        if dev['uploaded'][slot] != tIndex:
+            for k in (0, 1):
+                slab = dev['slab'][slot][k]
+                if dev['comp_bytes'][k] is not None:
+                    dev['decoder'].decode(dev['staged'][slot][k], slab.ptr)
+                else:
+                    buf = self._lazy_slots[slot][k]
+                    check(lib.nf_memcpy_h2d(slab.ptr, buf.ctypes.data, buf.nbytes))
+            dev['uploaded'][slot] = tIndex
+        return dev['slab'][slot][0].ptr, dev['slab'][slot][1].ptr
 
     def _lazy_alloc(self, slot):
-        if self._lazy_slots[slot] is None:   # pinned, re-used for every step: no page faults per step, pinned H2D
+        """Buffers of a slot, allocated once on the caller's thread (HIP calls stay off the prefetch thread) and re-used for
+        every step: no page faults per step, pinned H2D."""
+        dev = self._lazy_dev
+        if self._lazy_slots[slot] is None:
             shp = (self.nz, self.ny, self.nx)
-            self._lazy_slots[slot] = (self._host_array(shp, self._lazy_dtype), self._host_array(shp, self._lazy_dtype))
+            host_decoded = [dev is None or dev['comp_bytes'][k] is None for k in (0, 1)]
+            self._lazy_slots[slot] = tuple(self._host_array(shp, self._lazy_dtype) if h else None for h in host_decoded)
+            if dev is not None:
+                from .ingest import ChunkDecoder
+                nbytes = self.nz * self.ny * self.nx * self._lazy_dtype.itemsize
+                dev['comp'][slot] = [None if n is None else ChunkDecoder.new_pinned(n + 64) for n in dev['comp_bytes']]
+                dev['slab'][slot] = [_lib.DeviceBuffer(nbytes), _lib.DeviceBuffer(nbytes)]
+                dev['staged'][slot] = [None, None]
 
     def _lazy_wait(self):
         if self._lazy_pending is not None:
@@ -431,9 +474,13 @@ class Field(object):
             # dereferences at step tIndex
             au, av = self._lazy_get(tIndex)
             self._lazy_step = (tIndex, au, av)
-            off = tIndex * au.nbytes
-            check(lib.nf_field_set_uv(ctypes.byref(self._h), au.ctypes.data - off, av.ctypes.data - off, self.nt,
-                                      self._uv_code, 0, self._fill))
+            off = tIndex * self.nz * self.ny * self.nx * self._lazy_dtype.itemsize
+            if self._lazy_dev is not None:      # decoded (or copied) into HBM slabs: the engine reads them in place
+                pu, pv = self._lazy_upload(tIndex, self._lazy_cur)
+                check(lib.nf_field_set_uv(ctypes.byref(self._h), pu - off, pv - off, self.nt, self._uv_code, 1, self._fill))
+            else:
+                check(lib.nf_field_set_uv(ctypes.byref(self._h), au.ctypes.data - off, av.ctypes.data - off, self.nt,
+                                          self._uv_code, 0, self._fill))
             if self._lazy_prefetch and self.nt > 1:
                 # the next step (fluxviz's 't' key, fluxplot's loop) inflates on host threads while the GPU works on
                 # this one: the blocking C call below releases the GIL

@@ -143,13 +143,13 @@ class Dataset(object):
             raise Hdf5Error(f'{self.name}: short chunk')
         return raw
 
-    def _read_chunked(self, lead=None, out=None):
-        _, btree, cdims, single = self._layout
-        rank = len(self.shape)
-        cshape = tuple(cdims[:rank])
-        shape = self.shape if lead is None else (1,) + self.shape[1:]
-        nbytes = int(numpy.prod(cshape)) * self.dtype.itemsize
+    def _ensure_chunks(self):
+        """self._chunks = [(offsets, compressed size, filter mask, file address)] of every chunk that was written."""
         if getattr(self, '_chunks', None) is None:
+            _, btree, cdims, single = self._layout
+            rank = len(self.shape)
+            cshape = tuple(cdims[:rank])
+            nbytes = int(numpy.prod(cshape)) * self.dtype.itemsize
             if single is not None:
                 self._chunks = [single]
             elif isinstance(btree, tuple):      # layout version 4 indexes
@@ -157,6 +157,50 @@ class Dataset(object):
                                                              btree[2] if len(btree) > 2 else None))
             else:
                 self._chunks = list(self._h5._chunk_btree(btree, rank))
+        return self._chunks
+
+    def device_plan(self, lead):
+        """How the slab [lead] of the leading axis can be decoded ON THE DEVICE (nemoflux_amd.ingest.ChunkDecoder), or None
+        when it has to go through the host path: {'chunks': [(byte offset in the mapped file, compressed size, (z0, y0, x0)
+        origin in the slab)], 'chunk_dims': (cz, cy, cx), 'slab_dims': (nz, ny, nx), 'chunk_bytes', 'elem_size', 'shuffled'}.
+        Taken: what netCDF-4 / XIOS write for NEMO output -- deflate, optionally behind the shuffle filter, native 4- or
+        8-byte elements, one leading index per chunk, every chunk of the slab written with the whole pipeline applied."""
+        rank = len(self.shape)
+        if self._layout[0] != 'chunked' or not (2 <= rank <= 4):
+            return None
+        fids = [f[0] for f in self._filters]
+        if fids not in ([1], [2, 1]):             # order of application when writing: shuffle, then deflate
+            return None
+        es = self.dtype.itemsize
+        if es not in (4, 8) or not self.dtype.isnative:
+            return None
+        shuffled = fids[0] == 2
+        if shuffled:
+            cd = self._filters[0][1]
+            if (cd[0] if cd else es) != es:
+                return None
+        cshape = tuple(int(c) for c in self._layout[2][:rank])
+        if cshape[0] != 1:
+            return None
+        pad = 4 - rank                            # slab seen as (nz, ny, nx) with leading ones
+        slab = (1,) * pad + tuple(int(x) for x in self.shape[1:])
+        cdim = (1,) * pad + cshape[1:]
+        todo = [c for c in self._ensure_chunks() if c[0][0] == lead]
+        expected = int(numpy.prod([-(-n // c) for n, c in zip(slab, cdim)]))
+        if len(todo) != expected or any(c[2] != 0 or c[3] == UNDEF for c in todo):
+            return None                           # chunks never written / stored unfiltered: the host path fills them in
+        chunks = [(self._h5._base + c[3], c[1], (0,) * pad + tuple(int(o) for o in c[0][1:rank])) for c in todo]
+        chunks.sort(key=lambda c: c[2])
+        return dict(chunks=chunks, chunk_dims=cdim, slab_dims=slab, chunk_bytes=int(numpy.prod(cdim)) * es, elem_size=es,
+                    shuffled=1 if shuffled else 0)
+
+    def _read_chunked(self, lead=None, out=None):
+        _, btree, cdims, single = self._layout
+        rank = len(self.shape)
+        cshape = tuple(cdims[:rank])
+        shape = self.shape if lead is None else (1,) + self.shape[1:]
+        nbytes = int(numpy.prod(cshape)) * self.dtype.itemsize
+        self._ensure_chunks()
         todo = [c for c in self._chunks if c[3] != UNDEF and
                 (lead is None or c[0][0] <= lead < c[0][0] + cshape[0])]
         expected = int(numpy.prod([-(-s // c) for s, c in zip(shape, cshape)]))
@@ -200,6 +244,13 @@ class LazyVariable(object):
     def __init__(self, dataset):
         self.dataset, self.shape = dataset, dataset.shape
         self.dtype = numpy.dtype(dataset.dtype.newbyteorder('='))
+
+    def device_plan(self, t):
+        return self.dataset.device_plan(t)
+
+    def raw_bytes(self):
+        """The mapped file (chunk addresses of device_plan index into it)."""
+        return self.dataset._h5._m
 
     def read_step(self, t, out=None):
         """Time step t in native byte order, C-contiguous; into `out` (same shape, native dtype) when given."""

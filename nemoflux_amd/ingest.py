@@ -1,0 +1,140 @@
+"""File ingest straight to HBM (replaces the lazy NetCDF read of nemoflux/field.py:149): the
+deflated, byte-shuffled HDF5 chunks of one time step are copied to the device as they sit in the file and inflated there
+by nf_inflate.hip, one wavefront per chunk -- instead of zlib on the host cores, which is what bounds a file-backed pass.
+
+    dec = ChunkDecoder()
+    plan = lazy_variable.device_plan(t)            # nemoflux_amd.hdf5min: None when the layout needs the host path
+    staged = dec.gather(lazy_variable.raw_bytes(), plan)     # host only (runs on the prefetch thread)
+    dec.decode(staged, device_pointer, nbytes)     # H2D of the compressed bytes + inflate + un-shuffle, synchronous
+"""
+import concurrent.futures
+import ctypes
+
+import numpy
+
+from . import _lib
+from ._lib import lib, check
+
+
+class _Pinned(object):
+    def __init__(self, nbytes):
+        p = ctypes.c_void_p()
+        check(lib.nf_host_alloc(ctypes.byref(p), max(int(nbytes), 64)))
+        self.ptr, self.nbytes = p.value, max(int(nbytes), 64)
+        self.array = numpy.ctypeslib.as_array((ctypes.c_ubyte * self.nbytes).from_address(self.ptr))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib.nf_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class StagedChunks(object):
+    """Compressed chunks of one slab, gathered into pinned host memory, with their placement."""
+
+    def __init__(self, pinned, used, in_off, in_len, origin, plan):
+        self.pinned, self.used, self.in_off, self.in_len, self.origin, self.plan = pinned, used, in_off, in_len, origin, plan
+
+
+class ChunkDecoder(object):
+    def __init__(self, threads=8):
+        _lib.require_gpu()
+        self._h = ctypes.c_void_p()
+        check(lib.nf_inflater_new(ctypes.byref(self._h)))
+        self._threads = threads
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                lib.nf_inflater_del(ctypes.byref(self._h))
+        except Exception:
+            pass
+
+    @staticmethod
+    def new_pinned(nbytes):
+        """Pinned staging buffer; allocate on the thread that owns the GPU context, fill (gather) on any thread."""
+        return _Pinned(nbytes)
+
+    def gather(self, raw, plan, pinned):
+        """Copy the compressed chunks of `plan` out of the mapped file `raw` into `pinned`, back to back (8-byte aligned).
+        Pure host work (memcpy releases the GIL): meant for the prefetch thread."""
+        chunks = plan['chunks']
+        n = len(chunks)
+        in_off = numpy.zeros(n, numpy.int64)
+        in_len = numpy.array([c[1] for c in chunks], numpy.int64)
+        origin = numpy.ascontiguousarray(numpy.array([c[2] for c in chunks], numpy.int64).reshape(n, 3))
+        pos = 0
+        for i in range(n):
+            in_off[i] = pos
+            pos += (int(in_len[i]) + 7) & ~7
+        if pos > pinned.nbytes:
+            raise RuntimeError('ERROR: staging buffer too small for the compressed chunks of this time step')
+        src = numpy.frombuffer(raw, numpy.uint8)
+
+        def copy(i):
+            a, ln = chunks[i][0], int(in_len[i])
+            pinned.array[in_off[i]:in_off[i] + ln] = src[a:a + ln]
+        if n > 1 and self._threads > 1:
+            with concurrent.futures.ThreadPoolExecutor(min(self._threads, n)) as pool:
+                list(pool.map(copy, range(n)))
+        else:
+            for i in range(n):
+                copy(i)
+        return StagedChunks(pinned, pos, in_off, in_len, origin, plan)
+
+    @staticmethod
+    def staging_bytes(lazy, nt):
+        """Largest compressed size of any time step of `lazy` (padded the way gather lays the chunks out), or None when
+        some step cannot be decoded on the device."""
+        worst = 0
+        for t in range(nt):
+            plan = lazy.device_plan(t)
+            if plan is None:
+                return None
+            worst = max(worst, sum((c[1] + 7) & ~7 for c in plan['chunks']))
+        return worst
+
+    def decode(self, staged, out_ptr, stream=None):
+        """H2D of the gathered bytes, inflate + un-shuffle + placement on the device into the slab at out_ptr.  Synchronous;
+        raises NemofluxError naming the first malformed chunk."""
+        n = len(staged.in_len)
+        plan = staged.plan
+        status = numpy.zeros(max(n, 1), numpy.int32)
+        ll = _lib.c_ll_p
+        cd = numpy.array(plan['chunk_dims'], numpy.int64)
+        sd = numpy.array(plan['slab_dims'], numpy.int64)
+        check(lib.nf_inflater_run(ctypes.byref(self._h), ctypes.c_void_p(staged.pinned.ptr), int(staged.used),
+                                  staged.in_off.ctypes.data_as(ll), staged.in_len.ctypes.data_as(ll), n,
+                                  int(plan['chunk_bytes']), int(plan['elem_size']), int(plan['shuffled']),
+                                  cd.ctypes.data_as(ll), sd.ctypes.data_as(ll), staged.origin.ctypes.data_as(ll),
+                                  ctypes.c_void_p(int(out_ptr)), ctypes.c_void_p(stream) if stream else None,
+                                  status.ctypes.data_as(_lib.c_int_p)))
+        return status[:n]
+
+    def decode_streams(self, streams, out_len, elem_size=1, shuffled=0):
+        """Convenience for tests / tools: inflate a list of zlib streams that all decode to out_len bytes, one per row of a
+        (n, 1, out_len / elem_size) slab; returns the decoded rows (host numpy uint8, shape (n, out_len))."""
+        n = len(streams)
+        total_in = sum((len(s) + 7) & ~7 for s in streams)
+        pinned = _Pinned(total_in + 16)
+        in_off = numpy.zeros(n, numpy.int64)
+        pos = 0
+        for i, s in enumerate(streams):
+            in_off[i] = pos
+            pinned.array[pos:pos + len(s)] = numpy.frombuffer(s, numpy.uint8)
+            pos += (len(s) + 7) & ~7
+        ne = out_len // elem_size
+        plan = dict(chunk_dims=(1, 1, ne), slab_dims=(n, 1, ne), chunk_bytes=out_len, elem_size=elem_size, shuffled=shuffled)
+        origin = numpy.zeros((n, 3), numpy.int64)
+        origin[:, 0] = numpy.arange(n)
+        staged = StagedChunks(pinned, pos, in_off, numpy.array([len(s) for s in streams], numpy.int64), origin, plan)
+        buf = _lib.DeviceBuffer(max(n * out_len, 16))
+        try:
+            self.decode(staged, buf.ptr)
+            flat = buf.download((max(n * out_len, 16),), numpy.uint8)
+        finally:
+            buf.free()
+        return flat[:n * out_len].reshape(n, out_len)

@@ -959,12 +959,13 @@ def test_refuses_nonconvex_and_pole_cells(oracle):
     assert any('not fully inside the grid' in str(w.message) for w in rec)
 
 
-@pytest.mark.parametrize('prefetch', [True, False])
-def test_file_backed_field_against_the_oracle(prefetch, oracle):
+@pytest.mark.parametrize('prefetch,gpu_decode', [(True, True), (False, True), (True, False), (False, False)])
+def test_file_backed_field_against_the_oracle(prefetch, gpu_decode, oracle):
     """File-backed Field (NetCDF-4-style HDF5: float32, uo chunked + shuffled + deflated, _FillValue 1e20 / NaN land)
     against the CPU ORACLE on the values the file decodes to -- not against another HIP run: every step's full fields bit
-    for bit, every transect / segment total to rounding, with the double-buffered prefetch (next step inflating on host
-    threads while the GPU works on this one) and without it, in file order, out of order and through computeAll."""
+    for bit, every transect / segment total to rounding; with the chunks inflated on the device (nf_inflate.hip) and on the
+    host (zlib), with the double-buffered prefetch (next step staged on host threads while the GPU works on this one) and
+    without it, in file order, out of order and through computeAll."""
     import contextlib
     import io as _io
     from nemoflux_amd import hdf5min
@@ -973,7 +974,12 @@ def test_file_backed_field_against_the_oracle(prefetch, oracle):
     tr = [transect_xyz(T_OPEN), transect_xyz("(-180,-70),(-160,-10),(-35,40),(20,-50),(60,50),(180,40)")]
     with contextlib.redirect_stdout(_io.StringIO()):
         ff = Field(os.path.join(h5, 'nemo_T.h5'), os.path.join(h5, 'nemo_U.h5'), os.path.join(h5, 'nemo_V.h5'), tr,
-                   prefetch=prefetch)
+                   prefetch=prefetch, gpu_decode=gpu_decode)
+    # uo (8 shuffled + deflated chunks per step, tiling y and x) is inflated ON THE DEVICE when gpu_decode is on; vo is
+    # contiguous in its file and is staged from the mapped file either way
+    assert (ff._lazy_dev is not None) == gpu_decode
+    if gpu_decode:
+        assert ff._lazy_dev['comp_bytes'][0] is not None and ff._lazy_dev['comp_bytes'][1] is None
     # the decoded values, straight from the parser (pinned to h5py's own read-back in tests/test_hdf5min.py)
     with hdf5min.File(os.path.join(h5, 'nemo_T.h5')) as f:
         blon, blat = f.datasets['bounds_lon'].read(), f.datasets['bounds_lat'].read()

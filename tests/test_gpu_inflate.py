@@ -1,0 +1,125 @@
+"""GPU parity of the file-ingest decoder (nf_inflate.hip: one wavefront per deflated HDF5 chunk, through the C ABI
+nf_inflater_run): the device build of nf_inflate_core.h against zlib on the streams of tests/test_inflate_cpu.py, the inverse
+of HDF5's shuffle filter, placement of tiled / over-hanging chunks in the slab, and malformed streams (error code per chunk,
+nothing written outside the slab)."""
+import zlib
+
+import numpy
+import pytest
+
+from test_inflate_cpu import payloads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def decoder():
+    from nemoflux_amd.ingest import ChunkDecoder
+    return ChunkDecoder()
+
+
+@pytest.mark.parametrize('name', list(payloads()))
+def test_device_inflate_matches_zlib(name, decoder):
+    """every block type, level and strategy of zlib, 25 streams per launch (one wavefront each)"""
+    data = payloads()[name]
+    streams = []
+    for level in (0, 1, 4, 6, 9):
+        for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+            co = zlib.compressobj(level, zlib.DEFLATED, 15, 8, strategy)
+            streams.append(co.compress(data) + co.flush())
+    out = decoder.decode_streams(streams, len(data))
+    want = numpy.frombuffer(data, numpy.uint8)
+    for i in range(len(streams)):
+        assert numpy.array_equal(out[i], want), (name, i)
+
+
+@pytest.mark.parametrize('dtype', ['<f4', '<f8'])
+def test_device_unshuffle(dtype, decoder):
+    rng = numpy.random.default_rng(1)
+    rows = []
+    streams = []
+    for k in range(40):
+        a = (numpy.sin(numpy.arange(50000) * 1e-3 * (k + 1)) * (1 + 1e-3 * rng.standard_normal(50000))).astype(dtype)
+        rows.append(a)
+        es = a.dtype.itemsize
+        streams.append(zlib.compress(numpy.ascontiguousarray(a.view(numpy.uint8).reshape(-1, es).T).tobytes(), 4))
+    out = decoder.decode_streams(streams, rows[0].nbytes, elem_size=rows[0].dtype.itemsize, shuffled=1)
+    for k, a in enumerate(rows):
+        assert numpy.array_equal(out[k].view(dtype), a)
+
+
+def test_device_tiled_and_overhanging_chunks(decoder):
+    """chunks that tile y and x, with edge chunks hanging over the slab (HDF5 stores them whole), through
+    hdf5min.Dataset.device_plan and ChunkDecoder.gather / decode"""
+    from nemoflux_amd import hdf5min
+    from nemoflux_amd._lib import DeviceBuffer
+    rng = numpy.random.default_rng(2)
+    nt, nz, ny, nx = 2, 5, 18, 37
+    cz, cy, cx = 2, 7, 10
+    a = rng.standard_normal((nt, nz, ny, nx)).astype('<f4')
+    blobs, chunks, off = [], [], 0
+    for t in range(nt):
+        for z0 in range(0, nz, cz):
+            for y0 in range(0, ny, cy):
+                for x0 in range(0, nx, cx):
+                    blk = rng.standard_normal((cz, cy, cx)).astype('<f4')            # what lies beyond the edge is arbitrary
+                    sub = a[t, z0:z0 + cz, y0:y0 + cy, x0:x0 + cx]
+                    blk[:sub.shape[0], :sub.shape[1], :sub.shape[2]] = sub
+                    b = zlib.compress(numpy.ascontiguousarray(blk.view(numpy.uint8).reshape(-1, 4).T).tobytes(), 4)
+                    blobs.append(b)
+                    chunks.append(((t, z0, y0, x0, 0), len(b), 0, off))
+                    off += len(b)
+
+    class MemFile(object):
+        def __init__(self, blob):
+            self._m, self._base = blob, 0
+    ds = hdf5min.Dataset(MemFile(b''.join(blobs)), 'uo', a.shape, numpy.dtype('<f4'), ('chunked', None, (1, cz, cy, cx, 4), None),
+                         [(2, [4]), (1, [4])], {})
+    ds._chunks = chunks
+    lv = hdf5min.LazyVariable(ds)
+    assert numpy.array_equal(lv.read_step(1), a[1])                     # the host reader agrees with the construction
+    plan = lv.device_plan(1)
+    assert plan is not None and plan['chunk_dims'] == (cz, cy, cx) and plan['slab_dims'] == (nz, ny, nx) and len(plan['chunks']) == 36
+    pinned = decoder.new_pinned(decoder.staging_bytes(lv, nt) + 64)
+    slab = DeviceBuffer(a[1].nbytes)
+    for t in (1, 0):
+        staged = decoder.gather(lv.raw_bytes(), lv.device_plan(t), pinned)
+        decoder.decode(staged, slab.ptr)
+        assert numpy.array_equal(slab.download(a[t].shape, '<f4'), a[t])
+    # a dataset the device cannot take goes back to the host path: unfiltered chunk (filter mask), missing chunk
+    ds._chunks = [(c[0], c[1], 1, c[3]) if i == 3 else c for i, c in enumerate(chunks)]
+    assert lv.device_plan(0) is None and lv.device_plan(1) is not None
+    ds._chunks = chunks[1:]
+    assert lv.device_plan(0) is None
+
+
+def test_device_inflate_refuses_malformed_streams(decoder):
+    from nemoflux_amd._lib import NemofluxError
+    rng = numpy.random.default_rng(4)
+    data = rng.integers(0, 16, 50000, dtype=numpy.uint8).tobytes()
+    good = zlib.compress(data, 6)
+    assert numpy.array_equal(decoder.decode_streams([good, good], len(data))[1], numpy.frombuffer(data, numpy.uint8))
+    with pytest.raises(NemofluxError, match=r'chunk 1 of 3.*not a zlib stream'):
+        decoder.decode_streams([good, b'\x00\x00' + good[2:], good], len(data))
+    with pytest.raises(NemofluxError, match='chunk 0 of 1'):
+        decoder.decode_streams([good[:len(good) // 2]], len(data))
+    with pytest.raises(NemofluxError, match='decoded length differs'):
+        decoder.decode_streams([good], len(data) - 8)
+    flipped = 0
+    streams = []
+    for trial in range(64):                     # random bit flips: every one is noticed (structure, length or Adler-32)
+        c = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            c[int(rng.integers(2, len(c)))] ^= 1 << int(rng.integers(0, 8))
+        if bytes(c) != good:
+            streams.append(bytes(c))
+    for s in streams:
+        with pytest.raises(NemofluxError):
+            decoder.decode_streams([s], len(data))
+        flipped += 1
+    assert flipped > 50
+    for trial in range(16):                     # noise behind a valid header: an error, and the process survives
+        noise = b'\x78\x9c' + rng.integers(0, 256, 3000, dtype=numpy.uint8).tobytes()
+        with pytest.raises(NemofluxError):
+            decoder.decode_streams([noise], 10000)
+    assert numpy.array_equal(decoder.decode_streams([good], len(data))[0], numpy.frombuffer(data, numpy.uint8))
