@@ -55,14 +55,17 @@ print(f'deflated image: {su + sv} bytes of {raw} ({raw / (su + sv):.2f}x), built
 assert numpy.array_equal(lu.read_step(1), u[1])
 tri = [numpy.array([(-100., -80., 0.), (100., -80., 0.), (0., 80., 0.)])]
 blon, blat = dg.bounds_lon.cpu().numpy().astype(numpy.float32), dg.bounds_lat.cpu().numpy().astype(numpy.float32)
-for label, pf in (('serial (inflate, then H2D + kernels)', False), ('pipelined (next step inflates under the GPU work)', True)):
+for label, pf, gd in (('host zlib, serial (inflate, then H2D + kernels)', False, False),
+                      ('host zlib, pipelined (next step inflates under the GPU work)', True, False),
+                      ('device inflate, serial (gather, H2D of compressed chunks, inflate on the GPU)', False, True),
+                      ('device inflate, pipelined (next step gathered under the GPU work)', True, True)):
     with contextlib.redirect_stdout(io.StringIO()):
-        f = Field.fromArrays(blon, blat, dg.deptht_bounds, lu, lv, tri, prefetch=pf, readback=False, fill_value=1e20)
+        f = Field.fromArrays(blon, blat, dg.deptht_bounds, lu, lv, tri, prefetch=pf, gpu_decode=gd, readback=False, fill_value=1e20)
     f.computeAll()
     t0 = time.perf_counter()
     tot, _ = f.computeAll()
     dt = time.perf_counter() - t0
-    print(f'{label:52s}: {dt/nt*1e3:8.1f} ms per step = {nz*ny*nx*nt/dt:.3e} integrals/s  ({raw/dt/1e9:.2f} GB/s of decoded u,v)  flux {tot[:,0]}')
+    print(f'{label:84s}: {dt/nt*1e3:8.1f} ms per step = {nz*ny*nx*nt/dt:.3e} integrals/s  ({raw/dt/1e9:.2f} GB/s of decoded u,v)  flux {tot[:,0]}')
     del f
 # parts: inflate alone, H2D + kernels alone
 buf = numpy.empty(u.shape[1:], numpy.float32)
