@@ -87,7 +87,6 @@ struct NfiCtx {           // lives in LDS (44 KiB): one per wavefront
     int32_t err;
     int32_t nlit, ndist;
     uint32_t adler_a, adler_b;             // running Adler-32 of the flushed output
-    uint32_t red_a[64], red_b[64];         // per-lane partial sums of one flush
 };
 
 NFI_CONST uint16_t kNfiLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59,
@@ -365,31 +364,52 @@ NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
 }
 
 // ---------------------------------------------------------------------------------------------- phase C: all lanes
-NFI_FN void nfi_apply_queue(NfiCtx &c)
+// In queue order: a run of literals is written by as many lanes at once, a match is copied 64 bytes per step.  (Writing all
+// literals of the round first would be wrong: the window is a ring of exactly the maximum distance, so a literal further on
+// shares its slot with a byte that an earlier long-distance match of the same round still has to read.)
+NFI_FN void nfi_copy_match(NfiCtx &c, uint32_t pos, uint32_t len, uint32_t dist)
 {
-    // In queue order: a run of literals is written by as many lanes at once, a match is copied 64 bytes per step.  (Writing
-    // all literals of the round first would be wrong: the window is a ring of exactly the maximum distance, so a literal
-    // further on shares its slot with a byte that an earlier long-distance match of the same round still has to read.)
-    const int nq = c.nq;
-    int k = 0;
-    while (k < nq) {                               // uniform: the queue is read from LDS after a barrier
-        const uint32_t len = c.q_len[k];
-        if (!len) {
-            int e = k + 1;
-            while (e < nq && c.q_len[e] == 0) ++e;
-            NFI_FOR_LANES(j, e - k) c.window[c.q_pos[k + j] & (kNfiWindow - 1)] = c.q_lit[k + j];
-            k = e;
-        } else {
-            const uint32_t pos = c.q_pos[k], dist = c.q_dist[k];
-            NFI_FOR_LANES(j, len) {
-                const uint32_t off = (uint32_t)j < dist ? (uint32_t)j : (uint32_t)j % dist;   // overlapping copy: period = dist
-                c.window[(pos + j) & (kNfiWindow - 1)] = c.window[(pos - dist + off) & (kNfiWindow - 1)];
-            }
-            ++k;
-        }
-        NFI_SYNC();
+    NFI_FOR_LANES(j, len) {
+        const uint32_t off = (uint32_t)j < dist ? (uint32_t)j : (uint32_t)j % dist;   // overlapping copy: period = dist
+        c.window[(pos + j) & (kNfiWindow - 1)] = c.window[(pos - dist + off) & (kNfiWindow - 1)];
     }
 }
+#ifdef NFI_HOST
+NFI_FN void nfi_apply_queue(NfiCtx &c)
+{
+    for (int k = 0; k < c.nq; ++k) {
+        if (c.q_len[k] == 0) c.window[c.q_pos[k] & (kNfiWindow - 1)] = c.q_lit[k];
+        else nfi_copy_match(c, c.q_pos[k], c.q_len[k], c.q_dist[k]);
+    }
+}
+#else
+// device: lane k holds queue entry k; a ballot gives the positions of the matches, so the runs of literals between them are
+// found with scalar bit operations instead of LDS reads
+NFI_FN void nfi_apply_queue(NfiCtx &c)
+{
+    const int nq = c.nq, lane = NFI_LANE;
+    const bool mine = lane < nq;
+    const uint32_t mylen = mine ? c.q_len[lane] : 0u, mypos = mine ? c.q_pos[lane] : 0u;
+    const uint32_t mydist = mylen ? c.q_dist[lane] : 0u;
+    const uint8_t mylit = (mine && !mylen) ? c.q_lit[lane] : 0;
+    const unsigned long long matches = __ballot(mylen != 0);
+    int k = 0;
+    while (k < nq) {                                         // uniform
+        const unsigned long long rest = matches >> k;
+        const int nm = rest ? k + (int)__builtin_ctzll(rest) : nq;      // next match at or after k
+        if (nm > k) {
+            if (lane >= k && lane < nm) c.window[mypos & (kNfiWindow - 1)] = mylit;
+            NFI_SYNC();
+        }
+        if (nm < nq) {
+            const uint32_t pos = __shfl(mypos, nm, 64), len = __shfl(mylen, nm, 64), dist = __shfl(mydist, nm, 64);
+            nfi_copy_match(c, pos, len, dist);
+            NFI_SYNC();
+        }
+        k = nm + 1;
+    }
+}
+#endif
 
 // bytes of a stored block: straight from the input ring into the window (all lanes), at most one ring half per call
 NFI_FN void nfi_stored_round(NfiCtx &c, uint32_t out_len)
@@ -442,8 +462,10 @@ NFI_FN void nfi_stored_round(NfiCtx &c, uint32_t out_len)
 // write the finished part of the window to the output: whole 4-byte words (dst 4-byte aligned), the tail at the end;
 // the Adler-32 of the stream (RFC 1950) is carried along: for n new bytes b_0..b_{n-1}, a += sum b_i and
 // b += n*a_old + sum (n-i) b_i, both modulo 65521 -- per-lane partial sums, added up by lane 0
+constexpr uint32_t kNfiFlushBytes = 8192;   // + one round's output (<= 64 x 258) stays below the 32 KiB the ring holds
 NFI_FN void nfi_flush(NfiCtx &c, uint8_t *dst, bool final)
 {
+    if (!final && c.pos - c.flushed < kNfiFlushBytes) return;     // uniform: both are read after a barrier
     const uint32_t from = c.flushed, upto = final ? c.pos : (c.pos & ~3u);
     const uint32_t n = upto - from;
     uint32_t pa = 0;
@@ -473,15 +495,14 @@ NFI_FN void nfi_flush(NfiCtx &c, uint8_t *dst, bool final)
             pb += (n - (uint32_t)j) * v;
         }
     }
-    c.red_a[NFI_LANE] = pa;
-    c.red_b[NFI_LANE] = (uint32_t)(pb % 65521u);
-    NFI_SYNC();
+    uint32_t sa = pa, sb = (uint32_t)(pb % 65521u);
+#ifndef NFI_HOST
+    for (int o = 32; o > 0; o >>= 1) {          // wavefront sums (64 x 65520 and 64 x 16.5 KiB x 255 fit 32 bits)
+        sa += __shfl_xor(sa, o, 64);
+        sb += __shfl_xor(sb, o, 64);
+    }
+#endif
     if (NFI_LANE == 0) {
-        uint32_t sa = 0, sb = 0;
-        for (int l = 0; l < NFI_NLANE; ++l) {
-            sa += c.red_a[l];
-            sb += c.red_b[l];
-        }
         const uint32_t a_old = c.adler_a;
         c.adler_a = (a_old + sa) % 65521u;
         c.adler_b = (uint32_t)((c.adler_b + (uint64_t)n * a_old + sb) % 65521u);

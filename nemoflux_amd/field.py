@@ -199,25 +199,12 @@ class Field(object):
             self._lazy = (uo, vo)
             self._lazy_dtype = numpy.dtype(uo.dtype).newbyteorder('=')
             self._uv_code, self._fill = _dtype_code(uo), float(fill_value)
-            self._lazy_step = (-1, None, None)
-            # two slots of pinned (u, v) step buffers: while the GPU works on the step in one slot, a background thread
-            # inflates the next step of the file into the other (_stage_step / _prefetch below)
-            self._lazy_slots = [None, None]
-            self._lazy_slot_step = [-1, -1]
-            self._lazy_pending = None          # (future, step, slot) of the running prefetch
-            self._lazy_pool = None
-            self._lazy_prefetch = bool(prefetch)
-            # Deflated chunks the device can take (hdf5min.Dataset.device_plan: what netCDF-4 / XIOS write) are copied to HBM
-            # compressed and inflated THERE (nemoflux_amd.ingest, nf_inflate.hip) instead of by zlib on the host cores;
-            # anything else keeps the host path.  comp_bytes[k]: staging size for variable k, None = host path.
-            self._lazy_dev = None
-            import os
-            if gpu_decode and os.environ.get('NF_GPU_INFLATE', '1') != '0':
-                from .ingest import ChunkDecoder
-                need = [ChunkDecoder.staging_bytes(src, self.nt) if hasattr(src, 'device_plan') else None for src in (uo, vo)]
-                if any(n is not None for n in need):
-                    self._lazy_dev = dict(decoder=ChunkDecoder(), comp_bytes=need, comp=[None, None], slab=[None, None],
-                                          staged=[None, None], uploaded=[-1, -1])
+            self._lazy_step = -1
+            # two slots of staging buffers: while the GPU works on the steps of one, a background host thread prepares the
+            # next ones in the other; deflated HDF5 chunks are inflated on the device (nemoflux_amd.staging / ingest)
+            from .staging import StepStager
+            self._stager = StepStager((uo, vo), self.nt, self.nz, ny, nx, self._lazy_dtype, self._host_array,
+                                      prefetch=prefetch, gpu_decode=gpu_decode)
             pu = pv = None
             uv_dev = 0
         elif pu is None:
@@ -335,8 +322,8 @@ class Field(object):
 
     def __del__(self):
         try:
-            if getattr(self, '_lazy_pool', None) is not None:
-                self._lazy_pool.shutdown(wait=True)      # the prefetch thread writes into buffers this object owns
+            if getattr(self, '_stager', None) is not None:
+                self._stager.close()      # the prefetch thread writes into buffers this object owns
             if getattr(self, '_h', None):
                 lib.nf_field_del(ctypes.byref(self._h))
         except Exception:
@@ -381,110 +368,20 @@ class Field(object):
         return int(nt), int(nz), int(ny), int(nx)
 
     # ------------------------------------------------------------------------------------------
-    # ---- file-backed fields: double-buffered staging -------------------------------------------------------------
-    def _stage_step(self, tIndex, slot):
-        """Host half of staging time step tIndex into `slot` (runs on the prefetch thread or on the caller's; zlib, the native
-        un-shuffle, memcpy and numpy's copies all release the GIL): a variable the device can decode only has its compressed
-        chunks gathered into pinned memory, any other one is inflated / copied into the slot's pinned step buffer."""
-        self._lazy_alloc(slot)
-
-        def step_of(src, buf):   # LazyVariable / StepView, or a plain / memory-mapped array (either file may be either)
-            if hasattr(src, 'read_step'):
-                if numpy.dtype(src.dtype) == self._lazy_dtype:
-                    return src.read_step(tIndex, out=buf)
-                numpy.copyto(buf, src.read_step(tIndex))
-                return buf
-            numpy.copyto(buf, src[tIndex] if len(src.shape) == 4 else src)
-            return buf
-        self._lazy_slot_step[slot] = -1
-        dev = self._lazy_dev
-        for k in (0, 1):
-            if dev is not None and dev['comp_bytes'][k] is not None:
-                src = self._lazy[k]
-                dev['staged'][slot][k] = dev['decoder'].gather(src.raw_bytes(), src.device_plan(tIndex), dev['comp'][slot][k])
-            else:
-                step_of(self._lazy[k], self._lazy_slots[slot][k])
-        if dev is not None:
-            dev['uploaded'][slot] = -1
-        self._lazy_slot_step[slot] = tIndex
-        return self._lazy_slots[slot]
-
-    def _lazy_upload(self, tIndex, slot):
-        """Device half (caller's thread): compressed chunks -> HBM -> inflate + un-shuffle + placement there; host-decoded
-        variables are copied into their slab.  Returns the two slabs' HBM addresses."""
-        dev = self._lazy_dev
-        if dev['uploaded'][slot] != tIndex:
-            for k in (0, 1):
-                slab = dev['slab'][slot][k]
-                if dev['comp_bytes'][k] is not None:
-                    dev['decoder'].decode(dev['staged'][slot][k], slab.ptr)
-                else:
-                    buf = self._lazy_slots[slot][k]
-                    check(lib.nf_memcpy_h2d(slab.ptr, buf.ctypes.data, buf.nbytes))
-            dev['uploaded'][slot] = tIndex
-        return dev['slab'][slot][0].ptr, dev['slab'][slot][1].ptr
-
-    def _lazy_alloc(self, slot):
-        """Buffers of a slot, allocated once on the caller's thread (HIP calls stay off the prefetch thread) and re-used for
-        every step: no page faults per step, pinned H2D."""
-        dev = self._lazy_dev
-        if self._lazy_slots[slot] is None:
-            shp = (self.nz, self.ny, self.nx)
-            host_decoded = [dev is None or dev['comp_bytes'][k] is None for k in (0, 1)]
-            self._lazy_slots[slot] = tuple(self._host_array(shp, self._lazy_dtype) if h else None for h in host_decoded)
-            if dev is not None:
-                from .ingest import ChunkDecoder
-                nbytes = self.nz * self.ny * self.nx * self._lazy_dtype.itemsize
-                dev['comp'][slot] = [None if n is None else ChunkDecoder.new_pinned(n + 64) for n in dev['comp_bytes']]
-                dev['slab'][slot] = [_lib.DeviceBuffer(nbytes), _lib.DeviceBuffer(nbytes)]
-                dev['staged'][slot] = [None, None]
-
-    def _lazy_wait(self):
-        if self._lazy_pending is not None:
-            fut = self._lazy_pending[0]
-            self._lazy_pending = None
-            fut.result()        # re-raises a read error of the background thread here, in the caller
-
-    def _lazy_get(self, tIndex):
-        """Pinned (u, v) buffers holding step tIndex: prefetched already, being prefetched, or read now."""
-        self._lazy_wait()
-        for slot in (0, 1):
-            if self._lazy_slot_step[slot] == tIndex:
-                self._lazy_cur = slot
-                return self._lazy_slots[slot]
-        slot = 1 - getattr(self, '_lazy_cur', 1)      # never the slot the engine may still be copying from
-        self._lazy_cur = slot
-        return self._stage_step(tIndex, slot)
-
-    def _prefetch(self, tIndex):
-        if not (0 <= tIndex < self.nt) or tIndex in self._lazy_slot_step:
-            return
-        if self._lazy_pool is None:
-            import concurrent.futures
-            self._lazy_pool = concurrent.futures.ThreadPoolExecutor(1, thread_name_prefix='nf-prefetch')
-        slot = 1 - self._lazy_cur
-        self._lazy_alloc(slot)       # HIP calls stay on the caller's thread; the worker only fills the buffers
-        self._lazy_pending = (self._lazy_pool.submit(self._stage_step, tIndex, slot), tIndex, slot)
-
     def _compute(self, tIndex, readback=None, prefetch_next=None):
         if not (0 <= tIndex < self.nt):
             raise RuntimeError(f'ERROR: time index {tIndex} out of range [0, {self.nt})')
-        if self._lazy is not None and self._lazy_step[0] != tIndex:
-            # one time step from the file; the engine sees a virtual (nt, nz, ny, nx) base that it only
-            # dereferences at step tIndex
-            au, av = self._lazy_get(tIndex)
-            self._lazy_step = (tIndex, au, av)
-            off = tIndex * self.nz * self.ny * self.nx * self._lazy_dtype.itemsize
-            if self._lazy_dev is not None:      # decoded (or copied) into HBM slabs: the engine reads them in place
-                pu, pv = self._lazy_upload(tIndex, self._lazy_cur)
-                check(lib.nf_field_set_uv(ctypes.byref(self._h), pu - off, pv - off, self.nt, self._uv_code, 1, self._fill))
-            else:
-                check(lib.nf_field_set_uv(ctypes.byref(self._h), au.ctypes.data - off, av.ctypes.data - off, self.nt,
-                                          self._uv_code, 0, self._fill))
-            if self._lazy_prefetch and self.nt > 1:
-                # the next step (fluxviz's 't' key, fluxplot's loop) inflates on host threads while the GPU works on
-                # this one: the blocking C call below releases the GIL
-                self._prefetch((tIndex + 1) % self.nt if prefetch_next is None else prefetch_next)
+        if self._lazy is not None and self._lazy_step != tIndex:
+            # one time step from the file(s): staged in pinned host memory or decoded into an HBM slab; the engine sees a
+            # virtual (nt, nz, ny, nx) base that it only dereferences at step tIndex
+            pu, pv, on_dev = self._stager.get(tIndex)
+            self._lazy_step = tIndex
+            off = tIndex * self._stager.step_bytes
+            check(lib.nf_field_set_uv(ctypes.byref(self._h), pu - off, pv - off, self.nt, self._uv_code, on_dev, self._fill))
+            # the steps that come next (fluxviz's 't' key, fluxplot's loop) are prepared on a host thread while the GPU works
+            # on this one: the blocking C call below releases the GIL
+            nxt = self._stager.next_after(tIndex)
+            self._stager.prefetch(nxt % self.nt if prefetch_next is None else (nxt if nxt < self.nt else -1))
         check(lib.nf_field_compute_flux(ctypes.byref(self._h), int(tIndex), _lib.dptr(self._row)))
         self._row_valid = True
         if self._readback if readback is None else readback:
@@ -525,7 +422,7 @@ class Field(object):
         if self._lazy is not None:
             # file-backed: one step on the GPU, the next one inflating into the other pinned slot (no wrap-around prefetch
             # after the last step)
-            rows = numpy.array([self._compute(t, readback=False, prefetch_next=t + 1).copy() for t in range(self.nt)])
+            rows = numpy.array([self._compute(t, readback=False, prefetch_next=True).copy() for t in range(self.nt)])
             if out is not None:
                 out.copy_(torch.from_numpy(rows))
             return rows[:, self._nseg:self._nseg + len(self.plis)], rows[:, :self._nseg]

@@ -61,29 +61,45 @@ class ChunkDecoder(object):
     def gather(self, raw, plan, pinned):
         """Copy the compressed chunks of `plan` out of the mapped file `raw` into `pinned`, back to back (8-byte aligned).
         Pure host work (memcpy releases the GIL): meant for the prefetch thread."""
-        chunks = plan['chunks']
-        n = len(chunks)
-        in_off = numpy.zeros(n, numpy.int64)
-        in_len = numpy.array([c[1] for c in chunks], numpy.int64)
-        origin = numpy.ascontiguousarray(numpy.array([c[2] for c in chunks], numpy.int64).reshape(n, 3))
-        pos = 0
-        for i in range(n):
-            in_off[i] = pos
-            pos += (int(in_len[i]) + 7) & ~7
-        if pos > pinned.nbytes:
-            raise RuntimeError('ERROR: staging buffer too small for the compressed chunks of this time step')
-        src = numpy.frombuffer(raw, numpy.uint8)
+        return self.gather_many([(raw, plan, 0)], pinned, plan['slab_dims'][0])[0]
 
-        def copy(i):
-            a, ln = chunks[i][0], int(in_len[i])
-            pinned.array[in_off[i]:in_off[i] + ln] = src[a:a + ln]
-        if n > 1 and self._threads > 1:
-            with concurrent.futures.ThreadPoolExecutor(min(self._threads, n)) as pool:
-                list(pool.map(copy, range(n)))
+    def gather_many(self, items, pinned, total_nz):
+        """items: [(mapped file, device_plan of one slab, z offset of that slab in the group's slab)] -- e.g. uo and vo of
+        several time steps, stacked along z into one (total_nz, ny, nx) slab.  The compressed chunks of all of them are
+        copied into `pinned` back to back; slabs of the same chunk geometry are merged into ONE StagedChunks (= one launch,
+        one wavefront per chunk); returns the list of StagedChunks (one per distinct geometry)."""
+        groups = {}
+        copies = []
+        pos = 0
+        for raw, plan, zoff in items:
+            key = (tuple(plan['chunk_dims']), tuple(plan['slab_dims'][1:]), plan['elem_size'], plan['shuffled'])
+            g = groups.setdefault(key, dict(in_off=[], in_len=[], origin=[], plan=plan))
+            src = numpy.frombuffer(raw, numpy.uint8)
+            for a, ln, org in plan['chunks']:
+                g['in_off'].append(pos)
+                g['in_len'].append(ln)
+                g['origin'].append((org[0] + zoff, org[1], org[2]))
+                copies.append((src, a, ln, pos))
+                pos += (ln + 7) & ~7
+        if pos > pinned.nbytes:
+            raise RuntimeError('ERROR: staging buffer too small for the compressed chunks of this group of time steps')
+
+        def copy(c):
+            src, a, ln, at = c
+            pinned.array[at:at + ln] = src[a:a + ln]
+        if len(copies) > 1 and self._threads > 1:
+            with concurrent.futures.ThreadPoolExecutor(min(self._threads, len(copies))) as pool:
+                list(pool.map(copy, copies))
         else:
-            for i in range(n):
-                copy(i)
-        return StagedChunks(pinned, pos, in_off, in_len, origin, plan)
+            for c in copies:
+                copy(c)
+        out = []
+        for key, g in groups.items():
+            plan = dict(g['plan'])
+            plan['slab_dims'] = (int(total_nz),) + tuple(plan['slab_dims'][1:])
+            out.append(StagedChunks(pinned, pos, numpy.array(g['in_off'], numpy.int64), numpy.array(g['in_len'], numpy.int64),
+                                    numpy.ascontiguousarray(numpy.array(g['origin'], numpy.int64).reshape(-1, 3)), plan))
+        return out
 
     @staticmethod
     def staging_bytes(lazy, nt):

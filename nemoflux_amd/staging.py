@@ -1,0 +1,171 @@
+"""Staging of file-backed uo / vo for the engine, one time step (host path) or one GROUP of time steps (device path) at a time.
+
+Replaces the lazy NetCDF read of nemoflux/field.py:149 (`nc[name][timeIndex, :, :, :]`, inflated by netCDF4 on the host at
+every update).  Two slots are kept, so that while the GPU works on the steps of one slot a background host thread prepares
+the next ones in the other (fluxviz's 't' key and fluxplot's loop walk the steps in order):
+
+* host path  -- a variable the device cannot decode (contiguous data, exotic chunking / filters, classic NetCDF): the step is
+  read / inflated by nemoflux_amd.hdf5min on all host cores into a pinned buffer and handed to the engine as host memory
+  (or copied into the slab when the other variable is on the device path).
+* device path -- deflated (+ shuffled) HDF5 chunks, what netCDF-4 / XIOS write: the host thread only GATHERS the compressed
+  chunks of a group of G steps into pinned memory; the caller's thread copies them to HBM and nf_inflate.hip inflates them
+  there, one wavefront per chunk, all G x 2 x (chunks per step) of them in one launch.  The decoder is serial inside a
+  chunk, so its throughput comes from the number of chunks in flight (3 per CU = 768 on the chip): G is chosen to get
+  there.
+"""
+import concurrent.futures
+import ctypes
+import os
+
+import numpy
+
+from . import _lib
+from ._lib import lib, check
+
+_RESIDENT_STREAMS = 768        # 3 decoder wavefronts per CU (47 KiB of LDS each) x 256 CUs
+
+
+class StepStager(object):
+    def __init__(self, sources, nt, nz, ny, nx, dtype, host_array, prefetch=True, gpu_decode=True, max_group_bytes=16 << 30):
+        self.src = tuple(sources)
+        self.nt, self.nz, self.ny, self.nx = nt, nz, ny, nx
+        self.dtype = numpy.dtype(dtype)
+        self.step_bytes = nz * ny * nx * self.dtype.itemsize
+        self._host_array = host_array
+        self._prefetch_on = bool(prefetch)
+        self.decoder = None
+        self.comp_bytes = [None, None]            # staging size per step of a variable on the device path
+        self.group = 1
+        if gpu_decode and os.environ.get('NF_GPU_INFLATE', '1') != '0':
+            from .ingest import ChunkDecoder
+            need = [ChunkDecoder.staging_bytes(s, nt) if hasattr(s, 'device_plan') else None for s in self.src]
+            if any(n is not None for n in need):
+                self.decoder = ChunkDecoder()
+                self.comp_bytes = need
+                per_step = sum(len(s.device_plan(0)['chunks']) for s, n in zip(self.src, need) if n is not None)
+                g = max(1, _RESIDENT_STREAMS // max(per_step, 1))
+                g = min(g, nt, max(1, int(max_group_bytes // (2 * self.step_bytes))))
+                self.group = int(os.environ.get('NF_INFLATE_GROUP', g))
+        self.on_device = self.decoder is not None
+        self._slots = [None, None]                # per slot: dict of buffers
+        self._range = [(-1, -1), (-1, -1)]        # steps [g0, g1) staged in the slot (host half done)
+        self._uploaded = [(-1, -1), (-1, -1)]     # ... and decoded / copied into its HBM slab
+        self._cur = 1
+        self._pending = None
+        self._pending_slot = -1
+        self._pool = None
+
+    # ------------------------------------------------------------------------------------------ buffers (caller's thread)
+    def _alloc(self, slot):
+        if self._slots[slot] is not None:
+            return
+        shp = (self.nz, self.ny, self.nx)
+        G = self.group
+        b = dict(staged=[], host=[None, None], comp=None, slab=None)
+        for k in (0, 1):
+            if self.comp_bytes[k] is None:        # decoded on the host: one pinned step buffer per step of the group
+                b['host'][k] = [self._host_array(shp, self.dtype) for _ in range(G)]
+        if self.on_device:
+            from .ingest import ChunkDecoder
+            total = sum(n for n in self.comp_bytes if n is not None) * G
+            b['comp'] = ChunkDecoder.new_pinned(total + 64)
+            b['slab'] = _lib.DeviceBuffer(2 * G * self.step_bytes)
+        self._slots[slot] = b
+
+    # ------------------------------------------------------------------------------------------ host half (any thread)
+    def _read_host(self, src, t, buf):
+        if hasattr(src, 'read_step'):
+            if numpy.dtype(src.dtype) == self.dtype:
+                return src.read_step(t, out=buf)
+            numpy.copyto(buf, src.read_step(t))
+            return buf
+        numpy.copyto(buf, src[t] if len(src.shape) == 4 else src)
+        return buf
+
+    def _stage(self, g0, g1, slot):
+        """zlib, the native un-shuffle, memcpy and numpy's copies all release the GIL"""
+        b = self._slots[slot]
+        self._range[slot] = (-1, -1)
+        items = []
+        for t in range(g0, g1):
+            for k in (0, 1):
+                if self.comp_bytes[k] is not None:
+                    items.append((self.src[k].raw_bytes(), self.src[k].device_plan(t), ((t - g0) * 2 + k) * self.nz))
+                else:
+                    self._read_host(self.src[k], t, b['host'][k][t - g0])
+        b['staged'] = self.decoder.gather_many(items, b['comp'], 2 * (g1 - g0) * self.nz) if items else []
+        self._uploaded[slot] = (-1, -1)
+        self._range[slot] = (g0, g1)
+
+    # ------------------------------------------------------------------------------------------ device half (caller's thread)
+    def _upload(self, slot):
+        g0, g1 = self._range[slot]
+        if self._uploaded[slot] == (g0, g1):
+            return
+        b = self._slots[slot]
+        for staged in b['staged']:
+            self.decoder.decode(staged, b['slab'].ptr)
+        for k in (0, 1):
+            if self.comp_bytes[k] is None:
+                for t in range(g0, g1):
+                    buf = b['host'][k][t - g0]
+                    check(lib.nf_memcpy_h2d(b['slab'].ptr + ((t - g0) * 2 + k) * self.step_bytes, buf.ctypes.data, buf.nbytes))
+        self._uploaded[slot] = (g0, g1)
+
+    # ------------------------------------------------------------------------------------------ interface
+    def _wait(self):
+        if self._pending is not None:
+            fut = self._pending
+            self._pending = None
+            self._pending_slot = -1
+            fut.result()        # re-raises a read error of the background thread here, in the caller
+
+    def _group_of(self, t):
+        g0 = (t // self.group) * self.group
+        return g0, min(g0 + self.group, self.nt)
+
+    def get(self, t):
+        """(address of uo[t], address of vo[t], on_device) -- prefetched already, being prefetched, or staged now."""
+        slot = None
+        for s in (0, 1):          # a slot the worker is filling shows the empty range until it is done
+            if self._range[s][0] <= t < self._range[s][1] and s != self._pending_slot:
+                slot = s
+        if slot is None:
+            self._wait()
+            for s in (0, 1):
+                if self._range[s][0] <= t < self._range[s][1]:
+                    slot = s
+        if slot is None:
+            slot = 1 - self._cur          # never the slot the engine may still be reading
+            self._alloc(slot)
+            self._stage(*self._group_of(t), slot)
+        self._cur = slot
+        b = self._slots[slot]
+        g0 = self._range[slot][0]
+        if self.on_device:
+            self._upload(slot)
+            base = b['slab'].ptr + (t - g0) * 2 * self.step_bytes
+            return base, base + self.step_bytes, 1
+        return b['host'][0][t - g0].ctypes.data, b['host'][1][t - g0].ctypes.data, 0
+
+    def prefetch(self, t):
+        """Start the host half of the group that holds step t on the background thread (no-op if it is staged already)."""
+        if not self._prefetch_on or not (0 <= t < self.nt):
+            return
+        if any(r[0] <= t < r[1] for r in self._range) or self._pending is not None:
+            return
+        if self._pool is None:
+            self._pool = concurrent.futures.ThreadPoolExecutor(1, thread_name_prefix='nf-prefetch')
+        slot = 1 - self._cur
+        self._alloc(slot)        # HIP calls stay on the caller's thread; the worker only fills host buffers
+        self._pending_slot = slot
+        self._pending = self._pool.submit(self._stage, *self._group_of(t), slot)
+
+    def next_after(self, t):
+        """first step after the group of t (what is worth prefetching while t's group is being worked on)"""
+        return self._group_of(t)[1]
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)      # the worker writes into buffers this object owns
+            self._pool = None

@@ -977,9 +977,9 @@ def test_file_backed_field_against_the_oracle(prefetch, gpu_decode, oracle):
                    prefetch=prefetch, gpu_decode=gpu_decode)
     # uo (8 shuffled + deflated chunks per step, tiling y and x) is inflated ON THE DEVICE when gpu_decode is on; vo is
     # contiguous in its file and is staged from the mapped file either way
-    assert (ff._lazy_dev is not None) == gpu_decode
+    assert ff._stager.on_device == gpu_decode
     if gpu_decode:
-        assert ff._lazy_dev['comp_bytes'][0] is not None and ff._lazy_dev['comp_bytes'][1] is None
+        assert ff._stager.comp_bytes[0] is not None and ff._stager.comp_bytes[1] is None and ff._stager.group == 3
     # the decoded values, straight from the parser (pinned to h5py's own read-back in tests/test_hdf5min.py)
     with hdf5min.File(os.path.join(h5, 'nemo_T.h5')) as f:
         blon, blat = f.datasets['bounds_lon'].read(), f.datasets['bounds_lat'].read()
