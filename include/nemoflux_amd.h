@@ -233,6 +233,8 @@ int nf_field_timing_split(nf_field **self, double *flux_ms, double *expand_ms);
 typedef struct nf_inflater nf_inflater;
 int nf_inflater_new(nf_inflater **self);
 int nf_inflater_del(nf_inflater **self);
+/* how many chunks the device decodes at once (resident decoder wavefronts): callers batch that many per nf_inflater_run */
+int nf_inflater_capacity(int *streams);
 int nf_inflater_run(nf_inflater **self, const void *comp_host, size_t comp_bytes, const long long *in_off,
                     const long long *in_len, int nchunks, long long chunk_bytes, int elem_size, int shuffled,
                     const long long *chunk_dims, const long long *slab_dims, const long long *origin, void *out_dev,

@@ -6,7 +6,7 @@
 //           (deflate, then un-shuffle) that netCDF4/xarray run on the host for every time step.
 //
 // The decoder itself is nf_inflate_core.h (RFC 1950/1951, Adler-32 checked).  One workgroup = one wavefront = one stream;
-// its 47 KiB state (32 KiB window, input ring, lookup tables) lives in LDS, so three streams run per CU and several hundred
+// its 39 KiB state (32 KiB window, input ring, lookup tables) lives in LDS, so four streams run per CU and a thousand
 // at once on the chip -- the format is serial inside a stream, the parallelism is across the chunks (75 levels x 2 fields
 // per time step in XIOS output).  HDF5's shuffle filter stored the bytes of every element de-interleaved (all first bytes,
 // then all second bytes, ...): k_place gathers them back, one element per lane, coalesced on both sides, and puts the
@@ -217,6 +217,24 @@ int nf_inflater_new(nf_inflater **self)
         set_error("out of host memory");
         return NF_ERR_HOST;
     }
+    return NF_OK;
+}
+
+/* wavefronts (= chunks) the device decodes at once: resident k_inflate workgroups per CU (LDS-limited) x CUs */
+int nf_inflater_capacity(int *streams)
+{
+    if (!streams) {
+        set_error("nf_inflater_capacity: null argument");
+        return NF_ERR_ARG;
+    }
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_inflate, 64, 0) != hipSuccess) {
+        set_error("no usable AMD GPU (hipGetDevice); nemoflux_amd has no CPU fallback");
+        return NF_ERR_NO_DEVICE;
+    }
+    *streams = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
     return NF_OK;
 }
 

@@ -49,30 +49,32 @@ enum {
 };
 
 constexpr int kNfiWindow = 32768;          // RFC 1951: distances up to 32 KiB
-constexpr int kNfiRingWords = 2048;        // input ring: two halves of 1024 words (4 KiB each)
-constexpr int kNfiHalf = 1024;
+constexpr int kNfiRingWords = 512;         // input ring: two halves of 256 words (1 KiB each); a round reads < 100 words
+constexpr int kNfiHalf = 256;
 constexpr int kNfiQueue = 64;              // symbols decoded by lane 0 per round
-constexpr int kNfiLitBits = 10, kNfiDistBits = 9, kNfiClBits = 7;
+constexpr int kNfiLitBits = 10, kNfiDistBits = 8, kNfiClBits = 7;
+constexpr uint32_t kNfiStoredRound = 512;  // bytes of a stored block moved per round (must stay inside one ring half)
 
-struct NfiHuff {          // canonical code of one alphabet, for codes longer than the lookup table
-    uint16_t count[16];   // number of codes of each length
-    uint16_t symbol[288]; // symbols ordered by code
+template <int N> struct NfiHuffT {   // canonical code of one alphabet, for codes longer than the lookup table
+    uint16_t count[16];              // number of codes of each length
+    uint16_t symbol[N];              // symbols ordered by code
 };
+typedef NfiHuffT<288> NfiHuff;       // literal / length alphabet
+typedef NfiHuffT<32> NfiHuffSmall;   // distance alphabet (30) and the code-length alphabet (19)
 
-struct NfiCtx {           // lives in LDS (44 KiB): one per wavefront
+struct NfiCtx {           // lives in LDS (< 40 KiB, so that four fit a CU's 160 KiB): one per wavefront
     uint8_t window[kNfiWindow];
     uint32_t ring[kNfiRingWords];
     uint16_t lit_tab[1 << kNfiLitBits];    // (symbol << 4) | length, 0 = longer code
     uint16_t dist_tab[1 << kNfiDistBits];
     uint16_t cl_tab[1 << kNfiClBits];
-    NfiHuff lit, dist;
-    uint16_t lens[320];                    // code lengths: 288 literal/length + 32 distance
+    NfiHuff lit;
+    NfiHuffSmall dist;
+    uint8_t lens[320];                     // code lengths: 288 literal/length + 32 distance
     uint16_t code[320];                    // canonical code of every symbol (bit-reversed, as it appears in the stream)
-    // symbol queue of one round
-    uint32_t q_pos[kNfiQueue];
-    uint16_t q_len[kNfiQueue];             // 0 = literal
-    uint16_t q_dist[kNfiQueue];
-    uint8_t q_lit[kNfiQueue];
+    // symbol queue of one round: (length << 16) | distance for a match, the byte itself (length 0) for a literal
+    uint32_t q_sym[kNfiQueue];
+    uint32_t q_pos0;                       // output position of the round's first symbol
     // state shared between the phases (written by lane 0, read by all after a barrier)
     uint64_t bitbuf;
     int32_t bitcnt;
@@ -141,7 +143,7 @@ NFI_FN uint32_t nfi_take(NfiBits &b, int n)   // n <= 24, caller made sure cnt >
 }
 
 // decode one symbol: lookup table first, canonical walk for the codes that do not fit it (RFC 1951 3.2.2)
-NFI_FN int nfi_symbol(NfiBits &b, const uint16_t *tab, int tabbits, const NfiHuff &h)
+template <class H> NFI_FN int nfi_symbol(NfiBits &b, const uint16_t *tab, int tabbits, const H &h)
 {
     const uint16_t e = tab[b.buf & ((1u << tabbits) - 1u)];
     if (e & 15) {
@@ -171,7 +173,7 @@ NFI_FN int nfi_symbol(NfiBits &b, const uint16_t *tab, int tabbits, const NfiHuf
 // ---------------------------------------------------------------------------------------------- table construction
 // lens[0..n) -> canonical description (lane 0) + bit-reversed code of every symbol; returns "left" of the Kraft sum
 // (0 = complete, > 0 = incomplete, < 0 = over-subscribed)
-NFI_FN int nfi_canonical(NfiHuff &h, const uint16_t *lens, uint16_t *code, int n)
+template <class H, class L> NFI_FN int nfi_canonical(H &h, const L *lens, uint16_t *code, int n)
 {
     for (int l = 0; l <= 15; ++l) h.count[l] = 0;
     for (int s = 0; s < n; ++s) h.count[lens[s]]++;
@@ -205,7 +207,7 @@ NFI_FN int nfi_canonical(NfiHuff &h, const uint16_t *lens, uint16_t *code, int n
 }
 
 // all lanes: lookup table of `bits` bits from (lens, code)
-NFI_FN void nfi_fill_table(uint16_t *tab, int bits, const uint16_t *lens, const uint16_t *code, int n)
+NFI_FN void nfi_fill_table(uint16_t *tab, int bits, const uint8_t *lens, const uint16_t *code, int n)
 {
     NFI_FOR_LANES(k, 1 << bits) tab[k] = 0;
     NFI_SYNC();
@@ -257,7 +259,7 @@ NFI_FN void nfi_block_header(NfiCtx &c)
                 nfi_refill(c, b);
                 cl[NFI_TABLE(kNfiClOrder)[k]] = (uint16_t)nfi_take(b, 3);
             }
-            NfiHuff &h = c.dist;           // scratch: the distance description is rebuilt right after
+            NfiHuffSmall &h = c.dist;      // scratch: the distance description is rebuilt right after
             uint16_t clcode[19];
             if (nfi_canonical(h, cl, clcode, 19) != 0 && !(h.count[0] == 18)) c.err = NFI_ERR_CODES;   // must be complete
             for (int k = 0; k < (1 << kNfiClBits); ++k) c.cl_tab[k] = 0;
@@ -271,7 +273,7 @@ NFI_FN void nfi_block_header(NfiCtx &c)
                 if (sym < 0) {
                     c.err = NFI_ERR_SYMBOL;
                 } else if (sym < 16) {
-                    c.lens[idx < nlit ? idx : 288 + (idx - nlit)] = (uint16_t)sym;
+                    c.lens[idx < nlit ? idx : 288 + (idx - nlit)] = (uint8_t)sym;
                     ++idx;
                 } else {
                     int rep, val = 0;
@@ -286,7 +288,7 @@ NFI_FN void nfi_block_header(NfiCtx &c)
                         rep = 11 + (int)nfi_take(b, 7);
                     }
                     if (idx + rep > nlit + ndist) { c.err = NFI_ERR_CODES; break; }
-                    for (int r = 0; r < rep; ++r, ++idx) c.lens[idx < nlit ? idx : 288 + (idx - nlit)] = (uint16_t)val;
+                    for (int r = 0; r < rep; ++r, ++idx) c.lens[idx < nlit ? idx : 288 + (idx - nlit)] = (uint8_t)val;
                 }
             }
             for (int s = nlit; s < 288; ++s) c.lens[s] = 0;
@@ -319,22 +321,29 @@ NFI_FN void nfi_build_tables(NfiCtx &c)
 }
 
 // ---------------------------------------------------------------------------------------------- phase B: lane 0
-// decode up to kNfiQueue symbols of the current Huffman block into the queue
+// decode up to kNfiQueue symbols of the current Huffman block into the queue.  The next input word is fetched from the ring
+// one refill ahead (its LDS latency hides behind the symbols decoded meanwhile) and every symbol costs ONE queue store.
 NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
 {
     NfiBits b{c.bitbuf, c.bitcnt, c.word};
+    uint32_t nextw = c.ring[b.word & (kNfiRingWords - 1)];
+#define NFI_REFILL()                                             \
+    if (b.cnt <= 32) {                                           \
+        b.buf |= (uint64_t)nextw << b.cnt;                       \
+        b.cnt += 32;                                             \
+        ++b.word;                                                \
+        nextw = c.ring[b.word & (kNfiRingWords - 1)];            \
+    }
     uint32_t pos = c.pos;
+    c.q_pos0 = pos;
     int nq = 0;
     while (nq < kNfiQueue) {
-        nfi_refill(c, b);
+        NFI_REFILL();
         const int sym = nfi_symbol(b, c.lit_tab, kNfiLitBits, c.lit);
         if (sym < 0) { c.err = NFI_ERR_SYMBOL; break; }
         if (sym < 256) {
             if (pos >= out_len) { c.err = NFI_ERR_OUTPUT; break; }
-            c.q_pos[nq] = pos;
-            c.q_len[nq] = 0;
-            c.q_lit[nq] = (uint8_t)sym;
-            ++nq;
+            c.q_sym[nq++] = (uint32_t)sym;
             ++pos;
         } else if (sym == 256) {
             c.state = c.last ? 3 : 0;
@@ -343,19 +352,17 @@ NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
             const int li = sym - 257;
             if (li >= 29) { c.err = NFI_ERR_SYMBOL; break; }
             const uint32_t len = NFI_TABLE(kNfiLenBase)[li] + nfi_take(b, NFI_TABLE(kNfiLenExtra)[li]);
-            nfi_refill(c, b);
+            NFI_REFILL();
             const int ds = nfi_symbol(b, c.dist_tab, kNfiDistBits, c.dist);
             if (ds < 0 || ds >= 30) { c.err = NFI_ERR_SYMBOL; break; }
             const uint32_t dist = NFI_TABLE(kNfiDistBase)[ds] + nfi_take(b, NFI_TABLE(kNfiDistExtra)[ds]);
             if (dist > pos) { c.err = NFI_ERR_DISTANCE; break; }
             if (pos + len > out_len) { c.err = NFI_ERR_OUTPUT; break; }
-            c.q_pos[nq] = pos;
-            c.q_len[nq] = (uint16_t)len;
-            c.q_dist[nq] = (uint16_t)dist;
-            ++nq;
+            c.q_sym[nq++] = (len << 16) | dist;          // len >= 3, dist <= 32768
             pos += len;
         }
     }
+#undef NFI_REFILL
     c.nq = nq;
     c.pos = pos;
     c.bitbuf = b.buf;
@@ -377,28 +384,37 @@ NFI_FN void nfi_copy_match(NfiCtx &c, uint32_t pos, uint32_t len, uint32_t dist)
 #ifdef NFI_HOST
 NFI_FN void nfi_apply_queue(NfiCtx &c)
 {
+    uint32_t pos = c.q_pos0;
     for (int k = 0; k < c.nq; ++k) {
-        if (c.q_len[k] == 0) c.window[c.q_pos[k] & (kNfiWindow - 1)] = c.q_lit[k];
-        else nfi_copy_match(c, c.q_pos[k], c.q_len[k], c.q_dist[k]);
+        const uint32_t q = c.q_sym[k], len = q >> 16;
+        if (len == 0) c.window[pos++ & (kNfiWindow - 1)] = (uint8_t)q;
+        else {
+            nfi_copy_match(c, pos, len, q & 0xffffu);
+            pos += len;
+        }
     }
 }
 #else
-// device: lane k holds queue entry k; a ballot gives the positions of the matches, so the runs of literals between them are
-// found with scalar bit operations instead of LDS reads
+// device: lane k holds queue entry k; output positions come from a wavefront prefix sum of the lengths; a ballot gives
+// the positions of the matches, so the runs of literals between them are found with scalar bit operations, not LDS reads
 NFI_FN void nfi_apply_queue(NfiCtx &c)
 {
     const int nq = c.nq, lane = NFI_LANE;
-    const bool mine = lane < nq;
-    const uint32_t mylen = mine ? c.q_len[lane] : 0u, mypos = mine ? c.q_pos[lane] : 0u;
-    const uint32_t mydist = mylen ? c.q_dist[lane] : 0u;
-    const uint8_t mylit = (mine && !mylen) ? c.q_lit[lane] : 0;
+    const uint32_t q = lane < nq ? c.q_sym[lane] : 0u;
+    const uint32_t mylen = q >> 16, mydist = q & 0xffffu;
+    uint32_t adv = lane < nq ? (mylen ? mylen : 1u) : 0u, incl = adv;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    const uint32_t mypos = c.q_pos0 + incl - adv;
     const unsigned long long matches = __ballot(mylen != 0);
     int k = 0;
     while (k < nq) {                                         // uniform
         const unsigned long long rest = matches >> k;
         const int nm = rest ? k + (int)__builtin_ctzll(rest) : nq;      // next match at or after k
         if (nm > k) {
-            if (lane >= k && lane < nm) c.window[mypos & (kNfiWindow - 1)] = mylit;
+            if (lane >= k && lane < nm) c.window[mypos & (kNfiWindow - 1)] = (uint8_t)q;
             NFI_SYNC();
         }
         if (nm < nq) {
@@ -415,7 +431,7 @@ NFI_FN void nfi_apply_queue(NfiCtx &c)
 NFI_FN void nfi_stored_round(NfiCtx &c, uint32_t out_len)
 {
     // the bit buffer holds whole bytes here (the header aligned it); give them back to the ring position
-    uint32_t n = c.stored_left < 2048u ? c.stored_left : 2048u;
+    uint32_t n = c.stored_left < kNfiStoredRound ? c.stored_left : kNfiStoredRound;
     if (c.pos + n > out_len) {
         if (NFI_LANE == 0) c.err = NFI_ERR_OUTPUT;
         NFI_SYNC();

@@ -40,7 +40,7 @@ class StagedChunks(object):
 
 
 class ChunkDecoder(object):
-    def __init__(self, threads=8):
+    def __init__(self, threads=16):
         _lib.require_gpu()
         self._h = ctypes.c_void_p()
         check(lib.nf_inflater_new(ctypes.byref(self._h)))
@@ -52,6 +52,13 @@ class ChunkDecoder(object):
                 lib.nf_inflater_del(ctypes.byref(self._h))
         except Exception:
             pass
+
+    @staticmethod
+    def capacity():
+        """chunks the device decodes at once (resident decoder wavefronts)"""
+        n = ctypes.c_int()
+        check(lib.nf_inflater_capacity(ctypes.byref(n)))
+        return n.value
 
     @staticmethod
     def new_pinned(nbytes):

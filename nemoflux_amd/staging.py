@@ -10,7 +10,7 @@ the next ones in the other (fluxviz's 't' key and fluxplot's loop walk the steps
 * device path -- deflated (+ shuffled) HDF5 chunks, what netCDF-4 / XIOS write: the host thread only GATHERS the compressed
   chunks of a group of G steps into pinned memory; the caller's thread copies them to HBM and nf_inflate.hip inflates them
   there, one wavefront per chunk, all G x 2 x (chunks per step) of them in one launch.  The decoder is serial inside a
-  chunk, so its throughput comes from the number of chunks in flight (3 per CU = 768 on the chip): G is chosen to get
+  chunk, so its throughput comes from the number of chunks in flight (4 per CU = 1024 on the chip): G is chosen to get
   there.
 """
 import concurrent.futures
@@ -21,8 +21,6 @@ import numpy
 
 from . import _lib
 from ._lib import lib, check
-
-_RESIDENT_STREAMS = 768        # 3 decoder wavefronts per CU (47 KiB of LDS each) x 256 CUs
 
 
 class StepStager(object):
@@ -43,7 +41,7 @@ class StepStager(object):
                 self.decoder = ChunkDecoder()
                 self.comp_bytes = need
                 per_step = sum(len(s.device_plan(0)['chunks']) for s, n in zip(self.src, need) if n is not None)
-                g = max(1, _RESIDENT_STREAMS // max(per_step, 1))
+                g = max(1, ChunkDecoder.capacity() // max(per_step, 1))    # resident decoder wavefronts: 4 per CU
                 g = min(g, nt, max(1, int(max_group_bytes // (2 * self.step_bytes))))
                 self.group = int(os.environ.get('NF_INFLATE_GROUP', g))
         self.on_device = self.decoder is not None
