@@ -23,6 +23,9 @@ from . import _lib
 from ._lib import lib, check
 
 
+_TRACE = os.environ.get('NF_STAGE_TRACE', '0') != '0'
+
+
 class StepStager(object):
     def __init__(self, sources, nt, nz, ny, nx, dtype, host_array, prefetch=True, gpu_decode=True, max_group_bytes=16 << 30):
         self.src = tuple(sources)
@@ -82,6 +85,8 @@ class StepStager(object):
 
     def _stage(self, g0, g1, slot):
         """zlib, the native un-shuffle, memcpy and numpy's copies all release the GIL"""
+        import time
+        t_start = time.perf_counter()
         b = self._slots[slot]
         self._range[slot] = (-1, -1)
         items = []
@@ -94,6 +99,8 @@ class StepStager(object):
         b['staged'] = self.decoder.gather_many(items, b['comp'], 2 * (g1 - g0) * self.nz) if items else []
         self._uploaded[slot] = (-1, -1)
         self._range[slot] = (g0, g1)
+        if _TRACE:
+            print(f'# staging: host half of steps [{g0},{g1}) {1e3 * (time.perf_counter() - t_start):.1f} ms', flush=True)
 
     # ------------------------------------------------------------------------------------------ device half (caller's thread)
     def _upload(self, slot):
@@ -101,8 +108,14 @@ class StepStager(object):
         if self._uploaded[slot] == (g0, g1):
             return
         b = self._slots[slot]
+        import time
+        t_start = time.perf_counter()
         for staged in b['staged']:
             self.decoder.decode(staged, b['slab'].ptr)
+        if _TRACE:
+            print(f'# staging: device half of steps [{g0},{g1}) {1e3 * (time.perf_counter() - t_start):.1f} ms '
+                  f'({sum(len(x.in_len) for x in b["staged"])} chunks, {sum(int(x.used) for x in b["staged"][:1]) / 1e6:.0f} MB compressed)',
+                  flush=True)
         for k in (0, 1):
             if self.comp_bytes[k] is None:
                 for t in range(g0, g1):
@@ -158,6 +171,12 @@ class StepStager(object):
         self._alloc(slot)        # HIP calls stay on the caller's thread; the worker only fills host buffers
         self._pending_slot = slot
         self._pending = self._pool.submit(self._stage, *self._group_of(t), slot)
+
+    def invalidate(self):
+        """forget what is staged (the buffers stay): the next get() reads the file again -- measurements, re-opened files"""
+        self._wait()
+        self._range = [(-1, -1), (-1, -1)]
+        self._uploaded = [(-1, -1), (-1, -1)]
 
     def next_after(self, t):
         """first step after the group of t (what is worth prefetching while t's group is being worked on)"""
