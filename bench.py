@@ -357,7 +357,7 @@ def cpu_baseline(dg, u, v, nz, ny, nx, polys, args):
     omp = os.environ.get('OMP_NUM_THREADS', str(os.cpu_count()))
     # A6+A7 on all host cores: one polyline of the batch per thread (the C restatement releases the GIL under ctypes)
     from concurrent.futures import ThreadPoolExecutor
-    sample = polys[1:1 + min(len(polys) - 1, max(4, min(32, ncores)))]
+    sample = polys[1:1 + min(len(polys) - 1, max(4, min(16, ncores)))]
     nseg_sample = sum(len(p) - 1 for p in sample)
     t_a6 = None
     if sample:
