@@ -53,7 +53,6 @@ const char *nf_last_error(void);
 int nf_version(void);
 int nf_device_count(int *count);
 int nf_set_device(int device);
-int nf_get_device(int *device);
 int nf_device_name(char *buf, int buflen); /* e.g. "gfx950:..." */
 int nf_malloc(void **dev, size_t bytes);
 int nf_free(void *dev);
@@ -236,10 +235,6 @@ int nf_inflater_new(nf_inflater **self);
 int nf_inflater_del(nf_inflater **self);
 /* how many chunks the device decodes at once (resident decoder wavefronts): callers batch that many per nf_inflater_run */
 int nf_inflater_capacity(int *streams);
-/* Optional: copy the compressed bytes to the device ahead of time, on the inflater's own stream (synchronous for the
- * caller, which may be a staging thread -- after nf_set_device -- while the compute stream is busy); the next
- * nf_inflater_run with comp_host = NULL and the same comp_bytes then starts from that copy. */
-int nf_inflater_upload(nf_inflater **self, const void *comp_host, size_t comp_bytes);
 int nf_inflater_run(nf_inflater **self, const void *comp_host, size_t comp_bytes, const long long *in_off,
                     const long long *in_len, int nchunks, long long chunk_bytes, int elem_size, int shuffled,
                     const long long *chunk_dims, const long long *slab_dims, const long long *origin, void *out_dev,

@@ -121,14 +121,6 @@ try {
     return NF_OK;
 }
 NF_API_CATCH
-int nf_get_device(int *device)
-try {
-    NF_REQUIRE(device, NF_ERR_ARG, "nf_get_device: null argument");
-    NF_NEED_DEVICE();
-    NF_HIP(hipGetDevice(device));
-    return NF_OK;
-}
-NF_API_CATCH
 int nf_device_name(char *buf, int buflen)
 try {
     NF_REQUIRE(buf && buflen > 0, NF_ERR_ARG, "nf_device_name: null or empty buffer");

@@ -89,13 +89,8 @@ struct Inflater {
     InflateJob *d_jobs = nullptr;
     int *d_status = nullptr;
     size_t comp_cap = 0, tmp_cap = 0, jobs_cap = 0;
-    size_t uploaded_bytes = 0;          // compressed bytes nf_inflater_upload left in d_comp (0 = none)
-    hipStream_t copy_stream = nullptr;  // the upload's own stream: it runs beside whatever the compute stream does
     void release()
     {
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
-        copy_stream = nullptr;
-        uploaded_bytes = 0;
         for (void *p : {(void *)d_comp, (void *)d_tmp, (void *)d_jobs, (void *)d_status})
             if (p) (void)hipFree(p);
         d_comp = d_tmp = nullptr;
@@ -120,44 +115,12 @@ static const char *inflate_error_name(int rc)
     }
 }
 
-static size_t comp_padded(size_t comp_bytes) { return ((comp_bytes + 3) & ~(size_t)3) + 32; }   // whole words + slack
-
-static int inflater_ensure_comp(Inflater *h, size_t comp_pad)
-{
-    if (h->comp_cap < comp_pad) {
-        if (h->d_comp) (void)hipFree(h->d_comp);
-        h->d_comp = nullptr;
-        h->comp_cap = 0;
-        NF_HIP(hipMalloc((void **)&h->d_comp, comp_pad));
-        h->comp_cap = comp_pad;
-    }
-    return NF_OK;
-}
-
-// H2D of the compressed bytes on the inflater's own stream (callable from a staging thread while the compute stream works)
-int inflater_upload(Inflater *h, const void *comp_host, size_t comp_bytes)
-{
-    NF_REQUIRE(h && comp_host && comp_bytes > 0, NF_ERR_ARG, "inflate upload: null argument");
-    const size_t comp_pad = comp_padded(comp_bytes);
-    h->uploaded_bytes = 0;
-    const int rc = inflater_ensure_comp(h, comp_pad);
-    if (rc != NF_OK) return rc;
-    if (!h->copy_stream) NF_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-    NF_HIP(hipMemsetAsync(h->d_comp + (comp_pad - 64), 0, 64, h->copy_stream));
-    NF_HIP(hipMemcpyAsync(h->d_comp, comp_host, comp_bytes, hipMemcpyHostToDevice, h->copy_stream));
-    NF_HIP(hipStreamSynchronize(h->copy_stream));
-    h->uploaded_bytes = comp_bytes;
-    return NF_OK;
-}
-
 int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const long long *in_off, const long long *in_len,
                  int n, long long chunk_bytes, int elem_size, int shuffled, const long long *chunk_dims,
                  const long long *slab_dims, const long long *origin, void *out_dev, hipStream_t s, int *status_host)
 {
-    NF_REQUIRE(h && chunk_dims && slab_dims && (n == 0 || (in_off && in_len && origin && out_dev)), NF_ERR_ARG,
+    NF_REQUIRE(h && chunk_dims && slab_dims && (n == 0 || (comp_host && in_off && in_len && origin && out_dev)), NF_ERR_ARG,
                "inflate: null argument");
-    NF_REQUIRE(n == 0 || comp_host || h->uploaded_bytes == comp_bytes, NF_ERR_STATE,
-               "inflate: no compressed data (pass comp_host, or nf_inflater_upload the same bytes first)");
     NF_REQUIRE(elem_size == 1 || elem_size == 4 || elem_size == 8, NF_ERR_ARG, "inflate: element size must be 1, 4 or 8");
     NF_REQUIRE(!(shuffled && elem_size == 1), NF_ERR_ARG, "inflate: single bytes cannot be shuffled");
     for (int k = 0; k < 3; ++k)
@@ -176,11 +139,14 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
         jobs[i] = InflateJob{(unsigned long long)in_off[i], (unsigned)in_len[i], (unsigned)origin[3 * i], (unsigned)origin[3 * i + 1],
                              (unsigned)origin[3 * i + 2]};
     }
-    const size_t comp_pad = comp_padded(comp_bytes);      // slack the ring may read (never interprets)
+    const size_t comp_pad = ((comp_bytes + 3) & ~(size_t)3) + 32;      // whole words + slack the ring may read (never interprets)
     const size_t tmp_bytes = (size_t)chunk_bytes * (size_t)n;
-    if (comp_host) {
-        const int rc = inflater_ensure_comp(h, comp_pad);
-        if (rc != NF_OK) return rc;
+    if (h->comp_cap < comp_pad) {
+        if (h->d_comp) (void)hipFree(h->d_comp);
+        h->d_comp = nullptr;
+        h->comp_cap = 0;
+        NF_HIP(hipMalloc((void **)&h->d_comp, comp_pad));
+        h->comp_cap = comp_pad;
     }
     if (h->tmp_cap < tmp_bytes) {
         if (h->d_tmp) (void)hipFree(h->d_tmp);
@@ -199,11 +165,8 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
         NF_HIP(hipMalloc((void **)&h->d_status, sizeof(int) * (size_t)n));
         h->jobs_cap = (size_t)n;
     }
-    if (comp_host) {
-        NF_HIP(hipMemsetAsync(h->d_comp + (comp_pad - 64), 0, 64, s));      // the padding behind the data
-        NF_HIP(hipMemcpyAsync(h->d_comp, comp_host, comp_bytes, hipMemcpyHostToDevice, s));
-    }
-    h->uploaded_bytes = 0;      // consumed (or replaced) either way
+    NF_HIP(hipMemsetAsync(h->d_comp + (comp_pad - 64), 0, 64, s));      // the padding behind the data
+    NF_HIP(hipMemcpyAsync(h->d_comp, comp_host, comp_bytes, hipMemcpyHostToDevice, s));
     NF_HIP(hipMemcpyAsync(h->d_jobs, jobs.data(), sizeof(InflateJob) * (size_t)n, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_inflate, dim3((unsigned)n), dim3(64), 0, s, h->d_comp, (unsigned long long)(comp_pad - 32),
                        h->d_jobs, n, h->d_tmp, (unsigned)chunk_bytes, h->d_status);
@@ -284,15 +247,6 @@ int nf_inflater_del(nf_inflater **self)
         *self = nullptr;
     }
     return NF_OK;
-}
-
-int nf_inflater_upload(nf_inflater **self, const void *comp_host, size_t comp_bytes)
-{
-    if (!self || !*self) {
-        set_error("nf_inflater_upload: null handle");
-        return NF_ERR_ARG;
-    }
-    return inflater_upload(reinterpret_cast<Inflater *>(*self), comp_host, comp_bytes);
 }
 
 int nf_inflater_run(nf_inflater **self, const void *comp_host, size_t comp_bytes, const long long *in_off,

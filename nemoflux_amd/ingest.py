@@ -120,24 +120,16 @@ class ChunkDecoder(object):
             worst = max(worst, sum((c[1] + 7) & ~7 for c in plan['chunks']))
         return worst
 
-    def upload(self, staged):
-        """H2D of the gathered bytes ahead of decode(), on the decoder's own stream: meant for the staging thread (which must
-        have made the caller's device current: nf_set_device), so that the copy runs beside the compute stream's work."""
-        check(lib.nf_inflater_upload(ctypes.byref(self._h), ctypes.c_void_p(staged.pinned.ptr), int(staged.used)))
-        staged.uploaded = True
-
     def decode(self, staged, out_ptr, stream=None):
-        """H2D of the gathered bytes (unless upload() did it), inflate + un-shuffle + placement on the device into the slab at
-        out_ptr.  Synchronous; raises NemofluxError naming the first malformed chunk."""
+        """H2D of the gathered bytes, inflate + un-shuffle + placement on the device into the slab at out_ptr.  Synchronous;
+        raises NemofluxError naming the first malformed chunk."""
         n = len(staged.in_len)
         plan = staged.plan
         status = numpy.zeros(max(n, 1), numpy.int32)
         ll = _lib.c_ll_p
         cd = numpy.array(plan['chunk_dims'], numpy.int64)
         sd = numpy.array(plan['slab_dims'], numpy.int64)
-        host = None if getattr(staged, 'uploaded', False) else ctypes.c_void_p(staged.pinned.ptr)
-        staged.uploaded = False
-        check(lib.nf_inflater_run(ctypes.byref(self._h), host, int(staged.used),
+        check(lib.nf_inflater_run(ctypes.byref(self._h), ctypes.c_void_p(staged.pinned.ptr), int(staged.used),
                                   staged.in_off.ctypes.data_as(ll), staged.in_len.ctypes.data_as(ll), n,
                                   int(plan['chunk_bytes']), int(plan['elem_size']), int(plan['shuffled']),
                                   cd.ctypes.data_as(ll), sd.ctypes.data_as(ll), staged.origin.ctypes.data_as(ll),

@@ -34,10 +34,7 @@ class StepStager(object):
         self.step_bytes = nz * ny * nx * self.dtype.itemsize
         self._host_array = host_array
         self._prefetch_on = bool(prefetch)
-        self._upload_early = os.environ.get('NF_UPLOAD_EARLY', '1') != '0'
-        self.decoder = None                       # device path: one decoder (compressed copy + inflate slots) per slot
-        self.decoders = [None, None]
-        self.device = 0
+        self.decoder = None
         self.comp_bytes = [None, None]            # staging size per step of a variable on the device path
         self.group = 1
         if gpu_decode and os.environ.get('NF_GPU_INFLATE', '1') != '0':
@@ -45,10 +42,6 @@ class StepStager(object):
             need = [ChunkDecoder.staging_bytes(s, nt) if hasattr(s, 'device_plan') else None for s in self.src]
             if any(n is not None for n in need):
                 self.decoder = ChunkDecoder()
-                self.decoders = [self.decoder, ChunkDecoder()]
-                dev = ctypes.c_int()
-                check(lib.nf_get_device(ctypes.byref(dev)))
-                self.device = dev.value
                 self.comp_bytes = need
                 per_step = sum(len(s.device_plan(0)['chunks']) for s, n in zip(self.src, need) if n is not None)
                 g = max(1, ChunkDecoder.capacity() // max(per_step, 1))    # resident decoder wavefronts: 4 per CU
@@ -103,12 +96,7 @@ class StepStager(object):
                     items.append((self.src[k].raw_bytes(), self.src[k].device_plan(t), ((t - g0) * 2 + k) * self.nz))
                 else:
                     self._read_host(self.src[k], t, b['host'][k][t - g0])
-        b['staged'] = self.decoders[slot].gather_many(items, b['comp'], 2 * (g1 - g0) * self.nz) if items else []
-        if len(b['staged']) == 1 and self._upload_early:
-            # one geometry (the usual case): the compressed bytes go to HBM right here, on this thread and on the decoder's own
-            # stream, beside whatever the compute stream is doing; the caller's thread then only launches the kernels
-            check(lib.nf_set_device(self.device))
-            self.decoders[slot].upload(b['staged'][0])
+        b['staged'] = self.decoder.gather_many(items, b['comp'], 2 * (g1 - g0) * self.nz) if items else []
         self._uploaded[slot] = (-1, -1)
         self._range[slot] = (g0, g1)
         if _TRACE:
@@ -123,7 +111,7 @@ class StepStager(object):
         import time
         t_start = time.perf_counter()
         for staged in b['staged']:
-            self.decoders[slot].decode(staged, b['slab'].ptr)
+            self.decoder.decode(staged, b['slab'].ptr)
         if _TRACE:
             print(f'# staging: device half of steps [{g0},{g1}) {1e3 * (time.perf_counter() - t_start):.1f} ms '
                   f'({sum(len(x.in_len) for x in b["staged"])} chunks, {sum(int(x.used) for x in b["staged"][:1]) / 1e6:.0f} MB compressed)',
