@@ -47,6 +47,20 @@ def test_no_gpu_means_loud_failure():
     with pytest.raises(_lib.NemofluxError, match='no CPU fallback'):
         Field.fromArrays(numpy.zeros((2, 2, 4)), numpy.zeros((2, 2, 4)), numpy.zeros((1, 2)), numpy.zeros((1, 1, 2, 2)),
                          numpy.zeros((1, 1, 2, 2)), [])
+    # the file-ingest decoder runs on the device only: there is no host inflate behind this ABI
+    from nemoflux_amd.ingest import ChunkDecoder
+    with pytest.raises(_lib.NemofluxError, match='no CPU fallback'):
+        ChunkDecoder()
+    h, n = ctypes.c_void_p(), ctypes.c_int()
+    assert _lib.lib.nf_inflater_new(ctypes.byref(h)) == 0
+    ll = (ctypes.c_longlong * 3)(1, 1, 4)
+    z = (ctypes.c_longlong * 3)(0, 0, 0)
+    one = (ctypes.c_longlong * 1)(8)
+    buf = (ctypes.c_ubyte * 16)()
+    assert _lib.lib.nf_inflater_run(ctypes.byref(h), buf, 16, z, one, 1, 16, 4, 1, ll, ll, z, ctypes.c_void_p(16), None, None) == 4
+    assert b'no CPU fallback' in _lib.lib.nf_last_error()
+    assert _lib.lib.nf_inflater_capacity(ctypes.byref(n)) == 4
+    assert _lib.lib.nf_inflater_del(ctypes.byref(h)) == 0 and not h.value
 
 
 def test_argument_errors_without_gpu():
@@ -94,6 +108,8 @@ def test_null_arguments_are_errors_not_crashes():
     assert lib.nf_field_del(ctypes.byref(h)) == 0
     assert lib.nf_field_del(ctypes.byref(h)) == 0          # deleting twice is harmless (handle was nulled)
     assert lib.nf_tuning_set(None, 0) == 1 and lib.nf_tuning_set(b'no_such_knob', 0) == 1
+    assert lib.nf_inflater_new(None) == 1 and lib.nf_inflater_capacity(None) == 1
+    assert lib.nf_inflater_run(None, None, 0, None, None, 0, 0, 4, 0, None, None, None, None, None, None) == 1
 
 
 def test_product_never_imports_the_oracle():
