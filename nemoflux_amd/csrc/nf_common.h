@@ -42,6 +42,38 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 __host__ __device__ inline unsigned xcd_grid(unsigned ntiles) { return ((ntiles + kXcds - 1) / kXcds) * kXcds; }
 __device__ inline unsigned xcd_tile(unsigned b, unsigned grid) { return (b % kXcds) * (grid / kXcds) + b / kXcds; }
 
+// ---- cells the weights / the point location are not defined on --------------------------------
+// v = (x0,y0,...,x3,y3) of a quad in the (lon,lat) plane
+__device__ inline bool quad_is_nonconvex(const double *v)
+{
+    // a corner AT a geographic pole that is not the end of an edge lying on the pole line (|lat| = 90 along a whole edge,
+    // as in the top row of an un-rotated lon-lat grid, is fine): the pole's longitude is arbitrary, so the planar quad is
+    // not the image of the cell, convex or not
+    int npole = 0, first = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (fabs(v[2 * k + 1]) >= 90.0 - 1.e-9) {
+            ++npole;
+            if (first < 0) first = k;
+        }
+    if (npole == 1 || npole == 3) return true;
+    if (npole == 2 && !(fabs(v[2 * ((first + 1) & 3) + 1]) >= 90.0 - 1.e-9 || (first == 0 && fabs(v[2 * 3 + 1]) >= 90.0 - 1.e-9)))
+        return true;   // opposite corners
+    double cmin = 0.0, cmax = 0.0, scale = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int k1 = (k + 1) & 3, k2 = (k + 2) & 3;
+        const double ex = v[2 * k1] - v[2 * k], ey = v[2 * k1 + 1] - v[2 * k + 1];
+        const double fx = v[2 * k2] - v[2 * k1], fy = v[2 * k2 + 1] - v[2 * k1 + 1];
+        const double cr = ex * fy - ey * fx;
+        cmin = fmin(cmin, cr);
+        cmax = fmax(cmax, cr);
+        scale = fmax(scale, ex * ex + ey * ey);
+    }
+    return cmin < -1.e-12 * scale && cmax > 1.e-12 * scale;
+}
+
+
 // ---- launchers (defined in the .hip files) ----------------------------------------------------------
 // K0: geometry.  bounds (ncell,4) of T -> corner table xy (ncell,4,2), arc (ncell,4), arcE/arcN (ncell),
 // lon/lat box (4 doubles: lonmin, lonmax, latmin, latmax as order-preserving keys; see nf_geom.hip).

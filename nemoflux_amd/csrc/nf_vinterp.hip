@@ -87,6 +87,7 @@ __global__ __launch_bounds__(kBlock) void k_find_points(const double *__restrict
         }
     }
     const double slack = valid ? 1.e-6 * (fabs(xmin) + fabs(xmax) + fabs(ymin) + fabs(ymax) + 1.0) : 0.0;
+    const bool unusable = valid && quad_is_nonconvex(v);
     const double wslack = vmax64(slack);
     const double wxmin = vmin64(xmin) - wslack, wxmax = vmax64(xmax) + wslack;
     const double wymin = vmin64(ymin) - wslack, wymax = vmax64(ymax) + wslack;
@@ -104,10 +105,16 @@ __global__ __launch_bounds__(kBlock) void k_find_points(const double *__restrict
             const double px = tx + (nshift == 3 ? k - 1 : 0) * periodX;
             if (px < wxmin || px > wxmax) continue;  // wave-uniform
             if (!valid || px < xmin - slack || px > xmax + slack || ty < ymin - slack || ty > ymax + slack) continue;
+            if (unusable) continue;   // no inverse bilinear map in a non-convex / pole-vertex cell: the point is "not found" there
             double xi, eta;
             inv_bilinear_v(v, px, ty, xi, eta);
-            if (xi >= -tol && xi <= 1.0 + tol && eta >= -tol && eta <= 1.0 + tol)
-                atomicMin(&best[p], (unsigned long long)c * 4 + (unsigned long long)k);
+            if (xi >= -tol && xi <= 1.0 + tol && eta >= -tol && eta <= 1.0 + tol) {
+                // Newton must have converged onto the point
+                const double mx = ((v[0] + xi * (v[2] - v[0])) + eta * (v[6] - v[0])) + (xi * eta) * ((v[0] - v[2]) + (v[4] - v[6])) - px;
+                const double my = ((v[1] + xi * (v[3] - v[1])) + eta * (v[7] - v[1])) + (xi * eta) * ((v[1] - v[3]) + (v[5] - v[7])) - ty;
+                if (fabs(mx) + fabs(my) <= 1.e-9 * ((xmax - xmin) + (ymax - ymin)))
+                    atomicMin(&best[p], (unsigned long long)c * 4 + (unsigned long long)k);
+            }
         }
     }
 }

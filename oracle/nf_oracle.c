@@ -473,9 +473,15 @@ void nfo_vector_interp(const double *points, long ncell, const double *targets, 
             for (int k = 0; k < nshift && !found; ++k) {
                 const double px = targets[3 * p] + (nshift == 3 ? k - 1 : 0) * periodX, py = targets[3 * p + 1];
                 if (px < xmin - slack || px > xmax + slack || py < ymin - slack || py > ymax + slack) continue;
+                if (quad_is_nonconvex(v)) continue;   /* no inverse map there (see A6): the point is "not found" in such a cell */
                 double xi, eta;
                 inv_bilinear(v, px, py, &xi, &eta);
                 if (!(xi >= -tol && xi <= 1.0 + tol && eta >= -tol && eta <= 1.0 + tol)) continue;
+                {   /* Newton must have converged onto the point */
+                    const double mx = ((v[0] + xi * (v[2] - v[0])) + eta * (v[6] - v[0])) + (xi * eta) * ((v[0] - v[2]) + (v[4] - v[6])) - px;
+                    const double my = ((v[1] + xi * (v[3] - v[1])) + eta * (v[7] - v[1])) + (xi * eta) * ((v[1] - v[3]) + (v[5] - v[7])) - py;
+                    if (!(fabs(mx) + fabs(my) <= 1.e-9 * ((xmax - xmin) + (ymax - ymin)))) continue;
+                }
                 const double rxx = (1.0 - eta) * (v[2] - v[0]) + eta * (v[4] - v[6]);
                 const double rxy = (1.0 - eta) * (v[3] - v[1]) + eta * (v[5] - v[7]);
                 const double rex = (1.0 - xi) * (v[6] - v[0]) + xi * (v[4] - v[2]);

@@ -338,6 +338,10 @@ def test_oracle_refuses_nonconvex_and_pole_cells(oracle):
     with pytest.raises(oracle.UnsupportedCell) as ei:
         oracle.polyline_weights(pts, numpy.array([(100., 70., 0.), (175., 86., 0.)]))
     assert ei.value.cell in pole_cells
+    # point location (VectorInterp) never lands in such a cell either: a point there is "not found" or belongs to a real cell
+    tg = numpy.array([(175., 86., 0.), (100., 89.5, 0.), (-60., 88., 0.), (10., -89., 0.), (30., 20., 0.)])
+    _, ids = oracle.vector_interp(pts, tg, numpy.ones((pts.shape[0], 4)))
+    assert not (set(ids.tolist()) & pole_cells) and ids[-1] >= 0
     # away from them the planar tiling is consistent: coverage 1 and the lon / lat "edge data" integrate to the end-point
     # differences (the coverage property), on closed and open lines
     lonlat = [pts[:, :, 0], pts[:, :, 1]]
