@@ -158,6 +158,18 @@ def test_config_c3_orca025_like_station_transect(real, oracle):
     # secondary: bilinear interpolation error vs the analytic psi difference is O(h^2)
     from nemoflux_amd.fluxexact import exactFlux
     assert abs(got - exactFlux(PSI_CS, ll, nz, 1)[0]) <= 5e-5
+    # SURVEY 8d C3 "secondary": the same stations snapped to their nearest grid nodes -> the closed form is exact, for the
+    # whole transect and for every one of its 49 segments
+    from conftest import exact_segment_fluxes
+    dx, dy = 360. / nx, 180. / ny
+    snapped = numpy.stack([-180. + numpy.round((ll[:, 0] + 180.) / dx) * dx, -90. + numpy.round((ll[:, 1] + 90.) / dy) * dy], axis=1)
+    sxyz = numpy.zeros((snapped.shape[0], 3))
+    sxyz[:, :2] = snapped
+    fs = quiet_field(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, [sxyz], readback=False)
+    tot = fs.computeFlux(0)[0]
+    tol = 1e-12 if real == 'float64' else 2e-7
+    assert abs(tot - exactFlux(PSI_CS, snapped, nz, 1)[0]) <= tol
+    assert numpy.abs(fs.getSegmentFluxes()[0] - exact_segment_fluxes(PSI_CS, [snapped.tolist()], nz, 1)[0][0]).max() <= tol
 
 
 def test_orca12_properties_two_steps():
