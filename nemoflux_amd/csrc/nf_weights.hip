@@ -660,6 +660,8 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     if (nrec == 0) {
         NF_HIP(hipMemsetAsync(out->seg_start, 0, sizeof(int) * (size_t)(nseg + 1), s));
         NF_HIP(hipStreamSynchronize(s));
+        for (int q = 0; q < nseg; ++q)
+            if (segs_host[4 * q + 2] == 0.0 && segs_host[4 * q + 3] == 0.0) out->coverage[(size_t)q] = 1.0;
         return NF_OK;
     }
 
@@ -716,6 +718,8 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     NF_HIP(hipGetLastError());
     NF_HIP(hipStreamSynchronize(s));
     if (err_word != ~0ull) return refuse(err_word);   // Newton did not converge somewhere (fill pass)
+    for (int q = 0; q < nseg; ++q)                     // a zero-length segment has nothing to cover
+        if (segs_host[4 * q + 2] == 0.0 && segs_host[4 * q + 3] == 0.0) out->coverage[(size_t)q] = 1.0;
     return NF_OK;
 }
 

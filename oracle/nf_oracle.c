@@ -395,6 +395,8 @@ long nfo_polyline_weights(const double *points, long ncell, const double *xyz, i
     if (coverage) {
         for (int q = 0; q + 1 < npts; ++q) coverage[q] = 0.0;
         for (long i = 0; i < nrec; ++i) coverage[recs[i].seg] += recs[i].coef * (recs[i].tb - recs[i].ta);
+        for (int q = 0; q + 1 < npts; ++q)   /* a zero-length segment has nothing to cover */
+            if (xyz[3 * (q + 1)] == xyz[3 * q] && xyz[3 * (q + 1) + 1] == xyz[3 * q + 1]) coverage[q] = 1.0;
     }
     long need = nrec * 4;
     if (need > cap) { free(recs); return -need; }
