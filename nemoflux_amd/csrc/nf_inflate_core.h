@@ -8,11 +8,12 @@
 //
 // Work split inside the wavefront (the format is serial per stream, the parallelism is ACROSS streams):
 //   phase A  all lanes   keep the LDS input ring filled (coalesced 4-byte words from HBM)
-//   phase B  lane 0      decode up to 64 symbols through LDS lookup tables into a small queue (literal / length+distance,
-//                        with the output position of each)
-//   phase C  all lanes   literals are written to the 32 KiB LDS window in parallel, matches are copied in order, 64 bytes
-//                        per step (overlapping copies by the period rule), then the new bytes are flushed to HBM as whole
-//                        4-byte words
+//   phase B  lane 0      decode up to 64 symbols through LDS lookup tables into a small queue (one packed word per symbol:
+//                        the literal, or length and distance)
+//   phase C  all lanes   in queue order (output positions by a prefix sum of the lengths): runs of literals are written to
+//                        the 32 KiB LDS window by as many lanes at once, matches are copied 64 bytes per step (overlapping
+//                        copies by the period rule); every 8 KiB the new bytes are flushed to HBM as whole 4-byte words
+//                        and summed into the stream's Adler-32
 //   tables   lane 0 assigns the canonical codes of a dynamic / fixed block, all lanes fill the 10-bit lookup tables
 //
 // The same source compiles for the host (NFI_HOST: one "lane", no barriers) so that tests/ can run it against zlib's own
@@ -99,8 +100,6 @@ NFI_CONST uint16_t kNfiDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 
 NFI_CONST uint8_t kNfiDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11,
                                           12, 12, 13, 13};
 NFI_CONST uint8_t kNfiClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
-#define NFI_TABLE(name) name
 
 // ---------------------------------------------------------------------------------------------- input ring (phase A)
 // words: the stream's bytes seen as 4-byte words starting at the word that holds its first byte; nwords: how many of
@@ -257,7 +256,7 @@ NFI_FN void nfi_block_header(NfiCtx &c)
             for (int k = 0; k < 19; ++k) cl[k] = 0;
             for (int k = 0; k < ncl; ++k) {
                 nfi_refill(c, b);
-                cl[NFI_TABLE(kNfiClOrder)[k]] = (uint16_t)nfi_take(b, 3);
+                cl[kNfiClOrder[k]] = (uint16_t)nfi_take(b, 3);
             }
             NfiHuffSmall &h = c.dist;      // scratch: the distance description is rebuilt right after
             uint16_t clcode[19];
@@ -351,11 +350,11 @@ NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
         } else {
             const int li = sym - 257;
             if (li >= 29) { c.err = NFI_ERR_SYMBOL; break; }
-            const uint32_t len = NFI_TABLE(kNfiLenBase)[li] + nfi_take(b, NFI_TABLE(kNfiLenExtra)[li]);
+            const uint32_t len = kNfiLenBase[li] + nfi_take(b, kNfiLenExtra[li]);
             NFI_REFILL();
             const int ds = nfi_symbol(b, c.dist_tab, kNfiDistBits, c.dist);
             if (ds < 0 || ds >= 30) { c.err = NFI_ERR_SYMBOL; break; }
-            const uint32_t dist = NFI_TABLE(kNfiDistBase)[ds] + nfi_take(b, NFI_TABLE(kNfiDistExtra)[ds]);
+            const uint32_t dist = kNfiDistBase[ds] + nfi_take(b, kNfiDistExtra[ds]);
             if (dist > pos) { c.err = NFI_ERR_DISTANCE; break; }
             if (pos + len > out_len) { c.err = NFI_ERR_OUTPUT; break; }
             c.q_sym[nq++] = (len << 16) | dist;          // len >= 3, dist <= 32768
