@@ -364,3 +364,63 @@ def test_oracle_refuses_nonconvex_and_pole_cells(oracle):
     reg = oracle.assemble_points(numpy.ascontiguousarray(o0.bounds_lon[:, :12]), numpy.ascontiguousarray(o0.bounds_lat[:, :12]))
     w = oracle.polyline_weights(reg, numpy.array([(-120., 0., 0.), (0., 0., 0.)]), periodX=0.)
     assert abs(w.coverage[0] - 0.5) <= 1e-12
+
+
+def line_quadrature_of_face_vectors(vector_interp, xyz, nsub=4000):
+    """Flux across the polyline xyz by midpoint quadrature of the face-interpolated vector field:
+    sum over pieces of (Vx dy - Vy dx), V = the W2 (Piola) interpolation of the cell-by-cell edge data at the piece's
+    mid-point (what mint.VectorInterp.getFaceVectors returns, field.py:94-95).  `vector_interp(points (n,3)) -> (n,3)`."""
+    total = 0.0
+    for a, b in zip(xyz[:-1], xyz[1:]):
+        t = (numpy.arange(nsub) + 0.5) / nsub
+        mid = a[None, :] + t[:, None] * (b - a)[None, :]
+        v = vector_interp(mid)
+        d = (b - a) / nsub
+        total += float((v[:, 0] * d[1] - v[:, 1] * d[0]).sum())
+    return total
+
+
+@pytest.mark.parametrize('rotated', [False, True])
+def test_weights_agree_with_quadrature_of_the_interpolated_field(rotated, oracle):
+    """An independent route to the same number, tying the two mint restatements to each other through calculus instead of
+    through shared code: the polyline weights (A6/A7: clip, inverse bilinear map at the two ends of every sub-segment,
+    the four edge formulas, 1/n sharing) and the face-vector interpolation (f2: point location and the Piola formula at
+    thousands of interior points) must give the same flux, sum_k w_k f_k = integral of V x dl.
+    Un-rotated grid (rectangular cells, xi affine in lon/lat): for ARBITRARY conforming edge data, also with divergence, so
+    nothing cancels by accident.  Rotated grid (distorted cells): for edge data that derive from a node potential -- there the
+    flux inside a cell does not depend on the path; for divergent data it does, and the weights integrate along the chord in
+    xi space, not along the physical straight line (measured: the quadrature then converges to a value 1 % away), which is
+    a property of the algorithm, not an error.  Midpoint quadrature: O(1/nsub^2) inside a cell, O(1/nsub) from the pieces
+    that straddle a cell boundary."""
+    nx, ny = 36, 18
+    o = oracle.DataGen(nx, ny, 1, 1)
+    if rotated:
+        o.rotatePole((20., 30.))
+    pts = oracle.assemble_points(o.bounds_lon, o.bounds_lat)
+    rng = numpy.random.default_rng(17)
+    if rotated:
+        psi = rng.standard_normal((ny + 1, nx + 1))
+        psi[:, -1] = psi[:, 0]
+        p0, p1, p2, p3 = psi[:-1, :-1], psi[:-1, 1:], psi[1:, 1:], psi[1:, :-1]
+        data = numpy.stack([p1 - p0, p2 - p1, p2 - p3, p3 - p0], axis=-1).reshape(-1, 4)
+    else:
+        # one value per unique edge (shared by the two cells, periodic in x), NOT a stream-function difference
+        eU = rng.standard_normal((ny, nx))            # east edges
+        eV = rng.standard_normal((ny, nx))            # north edges
+        data = numpy.zeros((ny, nx, 4))
+        data[:, :, 1] = eU
+        data[:, :, 2] = eV
+        data[1:, :, 0] = eV[:-1]
+        data[:, 1:, 3] = eU[:, :-1]
+        data[:, 0, 3] = eU[:, -1]
+        data = data.reshape(-1, 4)
+    lines = [numpy.array([(-150.3, -41.2, 0.), (-20.7, 33.9, 0.), (95.1, -12.4, 0.)]),
+             numpy.array([(12.5, -44.0, 0.), (17.5, 38.0, 0.)]),
+             numpy.array([(-100., -40., 0.), (100., -40., 0.), (0., 45., 0.), (-100., -40., 0.)])]
+    for xyz in lines:
+        w = oracle.polyline_weights(pts, xyz)
+        assert numpy.allclose(w.coverage, 1.0, rtol=0, atol=1e-10)
+        direct = oracle.get_integral(w, data)
+        quad = line_quadrature_of_face_vectors(lambda p: oracle.vector_interp(pts, p, data)[0], xyz)
+        scale = numpy.abs(w.weight * data.reshape(-1)[w.cell_edge]).sum()
+        assert abs(direct - quad) <= 2e-3 * scale, (rotated, direct, quad)
