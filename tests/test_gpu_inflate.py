@@ -123,3 +123,31 @@ def test_device_inflate_refuses_malformed_streams(decoder):
         with pytest.raises(NemofluxError):
             decoder.decode_streams([noise], 10000)
     assert numpy.array_equal(decoder.decode_streams([good], len(data))[0], numpy.frombuffer(data, numpy.uint8))
+
+
+def test_device_inflate_more_streams_than_resident_wavefronts(decoder):
+    """1500 different streams in ONE launch -- more than the 1024 decoder wavefronts the chip holds at once -- of mixed
+    content (text-like, runs, noise, shuffled floats), levels and strategies: every one must come back exact."""
+    assert decoder.capacity() >= 256
+    rng = numpy.random.default_rng(9)
+    n, size = 1500, 40000
+    datas, streams = [], []
+    for i in range(n):
+        kind = i % 4
+        if kind == 0:
+            d = rng.integers(0, 1 << int(rng.integers(1, 9)), size, dtype=numpy.uint8)
+        elif kind == 1:
+            d = numpy.repeat(rng.integers(0, 256, size // 50, dtype=numpy.uint8), 50)
+        elif kind == 2:
+            f = (numpy.cumsum(rng.standard_normal(size // 4)) * 1e-2).astype('<f4')
+            d = numpy.ascontiguousarray(f.view(numpy.uint8).reshape(-1, 4).T).reshape(-1)
+        else:
+            d = numpy.tile(rng.integers(0, 256, int(rng.integers(1, 3000)), dtype=numpy.uint8), size)[:size]
+        d = numpy.ascontiguousarray(d[:size])
+        co = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, 15, 8,
+                              [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_FIXED][int(rng.integers(0, 4))])
+        datas.append(d)
+        streams.append(co.compress(d.tobytes()) + co.flush())
+    out = decoder.decode_streams(streams, size)
+    for i in range(n):
+        assert numpy.array_equal(out[i], datas[i]), i
