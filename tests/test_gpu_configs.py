@@ -1070,3 +1070,35 @@ def test_weights_agree_with_quadrature_of_the_interpolated_field_gpu(rotated, or
         scale = numpy.abs(w * data.reshape(-1)[ce]).sum()
         quad = line_quadrature_of_face_vectors(vectors, xyz)
         assert abs(direct - quad) <= 2e-3 * scale, (rotated, direct, quad)
+
+
+def test_three_dimensional_uo_without_a_time_axis(oracle):
+    """field.py:122-136 getSizes: uo of shape (z, y, x) -- a file holding one time step without the time axis -- is one
+    step (nt = 1); host arrays, HBM tensors and float32 alike; a 2-D (y, x) field is one level (the reference's tensordot
+    would contract y with the thickness there, SURVEY 8a quirk 10: here it is accepted as nz = 1 when deptht_bounds has one
+    level, and rejected otherwise)."""
+    import torch
+    g = load_golden('def36_zt')
+    t = 1
+    u3, v3 = numpy.ascontiguousarray(g['u'][t]), numpy.ascontiguousarray(g['v'][t])
+    tr = [transect_xyz(T_OPEN)]
+    ref = quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], g['u'], g['v'], tr)
+    want = ref.computeFlux(t, readback=True)
+    for u, v in ((u3, v3), (torch.from_numpy(u3).cuda(), torch.from_numpy(v3).cuda())):
+        f = quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], u, v, tr)
+        assert (f.nt, f.nz, f.ny, f.nx) == (1, g['u'].shape[1], 18, 36)
+        assert f.computeFlux(0, readback=True) == want
+        assert numpy.array_equal(f.integratedVelocity, ref.integratedVelocity)
+        with pytest.raises(RuntimeError):
+            f.computeFlux(1)
+    # (y, x): one level
+    f2 = quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'][:1], u3[0], v3[0], tr)
+    assert (f2.nt, f2.nz) == (1, 1)
+    th = g['deptht_bounds'][0, 1] - g['deptht_bounds'][0, 0]
+    st = oracle.EdgeFluxState(18, 36)
+    oracle.edge_flux(st, oracle.vertical_integral(u3[:1], numpy.array([th])), oracle.vertical_integral(v3[:1], numpy.array([th])),
+                     f2.arcLengths)
+    f2.update()
+    assert numpy.array_equal(f2.integratedVelocity, st.integratedVelocity)
+    with pytest.raises(RuntimeError):
+        quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], u3[0], v3[0], tr)     # 2 levels of thickness, 1 of data
