@@ -33,9 +33,26 @@
 #define NFI_CONST __constant__ static const
 #define NFI_LANE ((int)threadIdx.x)
 #define NFI_NLANE 64
-#define NFI_SYNC() __syncthreads()
+// One stream = one wavefront = one workgroup, so "all lanes have done their LDS writes" needs no s_barrier and no wait for
+// the LDS queue to drain: a wavefront's LDS instructions execute in issue order, a later read sees an earlier write of
+// another lane.  What is needed is that the compiler keeps that order: a wavefront-scope fence + scheduling barrier (no
+// instruction is emitted).  k_inflate is launched with exactly 64 lanes per workgroup.
+#define NFI_SYNC()                                              \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+    } while (0)
 #endif
 #define NFI_FOR_LANES(i, n) for (int i = NFI_LANE; i < (int)(n); i += NFI_NLANE)
+// The symbol decoder is serial and every lane would compute the same thing, so it runs as UNIFORM code: all lanes execute it,
+// every value it reads from LDS is passed through readfirstlane, and the compiler keeps the whole bit-buffer arithmetic on
+// the scalar unit (one instruction per cycle, native 64-bit shifts) instead of issuing 64-wide vector instructions for one
+// useful lane -- 300 -> ~110 cycles per literal.
+#ifdef NFI_HOST
+#define NFI_UNI(x) ((uint32_t)(x))
+#else
+#define NFI_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#endif
 
 enum {
     NFI_OK = 0,
@@ -92,13 +109,6 @@ struct NfiCtx {           // lives in LDS (< 40 KiB, so that four fit a CU's 160
     uint32_t adler_a, adler_b;             // running Adler-32 of the flushed output
 };
 
-NFI_CONST uint16_t kNfiLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59,
-                                         67, 83, 99, 115, 131, 163, 195, 227, 258};
-NFI_CONST uint8_t kNfiLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-NFI_CONST uint16_t kNfiDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769,
-                                          1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-NFI_CONST uint8_t kNfiDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11,
-                                          12, 12, 13, 13};
 NFI_CONST uint8_t kNfiClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // ---------------------------------------------------------------------------------------------- input ring (phase A)
@@ -144,22 +154,22 @@ NFI_FN uint32_t nfi_take(NfiBits &b, int n)   // n <= 24, caller made sure cnt >
 // decode one symbol: lookup table first, canonical walk for the codes that do not fit it (RFC 1951 3.2.2)
 template <class H> NFI_FN int nfi_symbol(NfiBits &b, const uint16_t *tab, int tabbits, const H &h)
 {
-    const uint16_t e = tab[b.buf & ((1u << tabbits) - 1u)];
+    const uint32_t e = NFI_UNI(tab[b.buf & ((1u << tabbits) - 1u)]);
     if (e & 15) {
         b.buf >>= (e & 15);
-        b.cnt -= (e & 15);
-        return e >> 4;
+        b.cnt -= (int)(e & 15);
+        return (int)(e >> 4);
     }
     int code = 0, first = 0, index = 0;
     uint64_t bits = b.buf;
     for (int len = 1; len <= 15; ++len) {
         code |= (int)(bits & 1);
         bits >>= 1;
-        const int count = h.count[len];
+        const int count = (int)NFI_UNI(h.count[len]);
         if (code - count < first) {
             b.buf >>= len;
             b.cnt -= len;
-            return h.symbol[index + (code - first)];
+            return (int)NFI_UNI(h.symbol[index + (code - first)]);
         }
         index += count;
         first += count;
@@ -320,49 +330,95 @@ NFI_FN void nfi_build_tables(NfiCtx &c)
 }
 
 // ---------------------------------------------------------------------------------------------- phase B: lane 0
-// decode up to kNfiQueue symbols of the current Huffman block into the queue.  The next input word is fetched from the ring
-// one refill ahead (its LDS latency hides behind the symbols decoded meanwhile) and every symbol costs ONE queue store.
+// decode up to kNfiQueue symbols of the current Huffman block into the queue.  A wavefront issues one instruction every
+// four cycles at best, so what this loop costs is its instruction count: the run of short-coded literals -- most symbols of
+// real data -- is a loop of its own with one table lookup, one packed queue store and a handful of scalar instructions per
+// byte; everything else (long codes, matches, end of block, the output running full) leaves it for the general path below.
 NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
 {
-    NfiBits b{c.bitbuf, c.bitcnt, c.word};
-    uint32_t nextw = c.ring[b.word & (kNfiRingWords - 1)];
-#define NFI_REFILL()                                             \
-    if (b.cnt <= 32) {                                           \
-        b.buf |= (uint64_t)nextw << b.cnt;                       \
-        b.cnt += 32;                                             \
-        ++b.word;                                                \
-        nextw = c.ring[b.word & (kNfiRingWords - 1)];            \
+    NfiBits b;      // executed by ALL lanes on uniform values (see NFI_UNI): scalar code
+    b.buf = ((uint64_t)NFI_UNI((uint32_t)(c.bitbuf >> 32)) << 32) | NFI_UNI((uint32_t)c.bitbuf);
+    b.cnt = (int)NFI_UNI(c.bitcnt);
+    b.word = NFI_UNI(c.word);
+    const int last = (int)NFI_UNI(c.last);
+    uint32_t nextw = NFI_UNI(c.ring[b.word & (kNfiRingWords - 1)]);
+#define NFI_REFILL()                                                     \
+    if (b.cnt <= 32) {                                                   \
+        b.buf |= (uint64_t)nextw << b.cnt;                               \
+        b.cnt += 32;                                                     \
+        ++b.word;                                                        \
+        nextw = NFI_UNI(c.ring[b.word & (kNfiRingWords - 1)]);           \
     }
-    uint32_t pos = c.pos;
+    uint32_t pos = NFI_UNI(c.pos);
     c.q_pos0 = pos;
-    int nq = 0;
-    while (nq < kNfiQueue) {
-        NFI_REFILL();
-        const int sym = nfi_symbol(b, c.lit_tab, kNfiLitBits, c.lit);
-        if (sym < 0) { c.err = NFI_ERR_SYMBOL; break; }
-        if (sym < 256) {
-            if (pos >= out_len) { c.err = NFI_ERR_OUTPUT; break; }
+    uint32_t nq = 0;
+    int err = 0, state = 1;
+    constexpr uint32_t kMask = (1u << kNfiLitBits) - 1u;
+    for (;;) {
+        // ---- run of short-coded literals.  A table entry is (symbol << 4) | length, 0 for a code longer than the table:
+        // entries 1 .. 4095 are exactly the literals 0 .. 255.
+        uint32_t rem = kNfiQueue - nq;
+        if (out_len - pos < rem) rem = out_len - pos;
+        uint32_t e = 0;
+        bool have = false;                        // e holds the entry of the symbol at the head of the bit buffer
+        while (rem) {
+            NFI_REFILL();
+            e = NFI_UNI(c.lit_tab[(uint32_t)b.buf & kMask]);
+            have = true;
+            if (e - 1u >= 4095u) break;
+            b.buf >>= (e & 15);
+            b.cnt -= (int)(e & 15);
+            c.q_sym[nq++] = e >> 4;
+            ++pos;
+            --rem;
+            have = false;
+        }
+        if (nq == kNfiQueue) break;
+        // ---- any other symbol
+        if (!have) {                              // the output is full: only the end-of-block code may follow
+            NFI_REFILL();
+            e = NFI_UNI(c.lit_tab[(uint32_t)b.buf & kMask]);
+        }
+        int sym;
+        if (e & 15) {
+            b.buf >>= (e & 15);
+            b.cnt -= (int)(e & 15);
+            sym = (int)(e >> 4);
+        } else {
+            sym = nfi_symbol(b, c.lit_tab, kNfiLitBits, c.lit);      // takes the canonical walk (the entry is 0)
+            if (sym < 0) { err = NFI_ERR_SYMBOL; break; }
+        }
+        if (sym < 256) {                          // a literal with a long code, or one that does not fit any more
+            if (pos >= out_len) { err = NFI_ERR_OUTPUT; break; }
             c.q_sym[nq++] = (uint32_t)sym;
             ++pos;
         } else if (sym == 256) {
-            c.state = c.last ? 3 : 0;
+            state = last ? 3 : 0;
             break;
         } else {
             const int li = sym - 257;
-            if (li >= 29) { c.err = NFI_ERR_SYMBOL; break; }
-            const uint32_t len = kNfiLenBase[li] + nfi_take(b, kNfiLenExtra[li]);
+            if (li >= 29) { err = NFI_ERR_SYMBOL; break; }
+            // base and extra bits of the length / distance codes (RFC 1951 3.2.5) by arithmetic: a table in memory would
+            // cost a scalar-memory round trip per symbol
+            const int lx = li < 8 ? 0 : (li - 4) >> 2;
+            const uint32_t lbase = li < 8 ? 3u + (uint32_t)li : (li == 28 ? 258u : 3u + ((4u + (uint32_t)(li & 3)) << lx));
+            const uint32_t len = lbase + nfi_take(b, li == 28 ? 0 : lx);
             NFI_REFILL();
             const int ds = nfi_symbol(b, c.dist_tab, kNfiDistBits, c.dist);
-            if (ds < 0 || ds >= 30) { c.err = NFI_ERR_SYMBOL; break; }
-            const uint32_t dist = kNfiDistBase[ds] + nfi_take(b, kNfiDistExtra[ds]);
-            if (dist > pos) { c.err = NFI_ERR_DISTANCE; break; }
-            if (pos + len > out_len) { c.err = NFI_ERR_OUTPUT; break; }
+            if (ds < 0 || ds >= 30) { err = NFI_ERR_SYMBOL; break; }
+            const int dx = ds < 4 ? 0 : (ds - 2) >> 1;
+            const uint32_t dbase = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + (uint32_t)(ds & 1)) << dx);
+            const uint32_t dist = dbase + nfi_take(b, dx);
+            if (dist > pos) { err = NFI_ERR_DISTANCE; break; }
+            if (pos + len > out_len) { err = NFI_ERR_OUTPUT; break; }
             c.q_sym[nq++] = (len << 16) | dist;          // len >= 3, dist <= 32768
             pos += len;
         }
     }
 #undef NFI_REFILL
-    c.nq = nq;
+    if (err) c.err = err;
+    c.state = state;
+    c.nq = (int)nq;
     c.pos = pos;
     c.bitbuf = b.buf;
     c.bitcnt = b.cnt;
@@ -375,8 +431,15 @@ NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
 // shares its slot with a byte that an earlier long-distance match of the same round still has to read.)
 NFI_FN void nfi_copy_match(NfiCtx &c, uint32_t pos, uint32_t len, uint32_t dist)
 {
+    const float rcp = 1.0f / (float)dist;            // j < 258: the float quotient is exact to within one, fixed up below
     NFI_FOR_LANES(j, len) {
-        const uint32_t off = (uint32_t)j < dist ? (uint32_t)j : (uint32_t)j % dist;   // overlapping copy: period = dist
+        uint32_t off = (uint32_t)j;                  // overlapping copy (dist < len): the bytes repeat with period dist
+        if (off >= dist) {
+            const uint32_t q = (uint32_t)((float)off * rcp);
+            off -= q * dist;
+            if ((int32_t)off < 0) off += dist;
+            else if (off >= dist) off -= dist;
+        }
         c.window[(pos + j) & (kNfiWindow - 1)] = c.window[(pos - dist + off) & (kNfiWindow - 1)];
     }
 }
@@ -572,7 +635,7 @@ NFI_FN int nfi_inflate_stream(NfiCtx &c, const uint8_t *src, uint32_t in_len, ui
             NFI_SYNC();
             if (!c.err && c.state == 1) nfi_build_tables(c);
         } else if (c.state == 1) {
-            if (NFI_LANE == 0) nfi_decode_round(c, out_len);
+            nfi_decode_round(c, out_len);          // all lanes, uniform
             NFI_SYNC();
             nfi_apply_queue(c);
             nfi_flush(c, dst, false);
