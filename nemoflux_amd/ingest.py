@@ -40,8 +40,11 @@ class StagedChunks(object):
 
 
 class ChunkDecoder(object):
-    def __init__(self, threads=16):
+    def __init__(self, threads=None):
         _lib.require_gpu()
+        if threads is None:
+            import os
+            threads = int(os.environ.get('NF_GATHER_THREADS', 8))
         self._h = ctypes.c_void_p()
         check(lib.nf_inflater_new(ctypes.byref(self._h)))
         self._threads = threads
