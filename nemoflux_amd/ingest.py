@@ -44,7 +44,7 @@ class ChunkDecoder(object):
         _lib.require_gpu()
         if threads is None:
             import os
-            threads = int(os.environ.get('NF_GATHER_THREADS', 8))
+            threads = int(os.environ.get('NF_GATHER_THREADS', 16))
         self._h = ctypes.c_void_p()
         check(lib.nf_inflater_new(ctypes.byref(self._h)))
         self._threads = threads
@@ -73,7 +73,7 @@ class ChunkDecoder(object):
         Pure host work (memcpy releases the GIL): meant for the prefetch thread."""
         return self.gather_many([(raw, plan, 0)], pinned, plan['slab_dims'][0])[0]
 
-    def gather_many(self, items, pinned, total_nz):
+    def gather_many(self, items, pinned, total_nz, threads=None):
         """items: [(mapped file, device_plan of one slab, z offset of that slab in the group's slab)] -- e.g. uo and vo of
         several time steps, stacked along z into one (total_nz, ny, nx) slab.  The compressed chunks of all of them are
         copied into `pinned` back to back; slabs of the same chunk geometry are merged into ONE StagedChunks (= one launch,
@@ -97,8 +97,9 @@ class ChunkDecoder(object):
         def copy(c):
             src, a, ln, at = c
             pinned.array[at:at + ln] = src[a:a + ln]
-        if len(copies) > 1 and self._threads > 1:
-            with concurrent.futures.ThreadPoolExecutor(min(self._threads, len(copies))) as pool:
+        threads = self._threads if threads is None else threads
+        if len(copies) > 1 and threads > 1:
+            with concurrent.futures.ThreadPoolExecutor(min(threads, len(copies))) as pool:
                 list(pool.map(copy, copies))
         else:
             for c in copies:
