@@ -102,11 +102,27 @@ int main(void)
     const int rc = mnt_polylineintegral_computeWeights(&pli, 1, &xyz[0][0], 0);
     printf("computeWeights with 1 point -> %d (%s)\n", rc, nf_last_error());
 
+    /* ---- file ingest: one zlib stream (a stored block holding the float 1.0f, Adler-32 0x014300C0) inflated on the device */
+    static const unsigned char stream[15] = {0x78, 0x01, 0x01, 0x04, 0x00, 0xFB, 0xFF, 0x00, 0x00, 0x80, 0x3F, 0x01, 0x43, 0x00, 0xC0};
+    const long long in_off[1] = {0}, in_len[1] = {15}, dims[3] = {1, 1, 1}, origin[3] = {0, 0, 0};
+    nf_inflater *inf = NULL;
+    void *slab = NULL;
+    float decoded = 0.f;
+    int status = -1;
+    CHECK(nf_inflater_new(&inf));
+    CHECK(nf_malloc(&slab, 16));
+    CHECK(nf_inflater_run(&inf, stream, sizeof stream, in_off, in_len, 1, 4, 4, 0, dims, dims, origin, slab, NULL, &status));
+    CHECK(nf_memcpy_d2h(&decoded, slab, 4));
+    CHECK(nf_free(slab));
+    CHECK(nf_inflater_del(&inf));
+    printf("ingest: decoded %.1f (status %d)\n", decoded, status);
+
     CHECK(mnt_polylineintegral_del(&pli));
     CHECK(mnt_grid_del(&grid));
     CHECK(nf_field_del(&fld));
     free(row);
-    const int ok = fabs(flux2 - 360.0) < 1e-9 && fabs(flux1 - 360.0) < 1e-9 && rc == NF_ERR_ARG && ncells == NY * NX;
+    const int ok = fabs(flux2 - 360.0) < 1e-9 && fabs(flux1 - 360.0) < 1e-9 && rc == NF_ERR_ARG && ncells == NY * NX &&
+                   decoded == 1.0f && status == 0;
     printf(ok ? "C client OK\n" : "C client FAILED\n");
     return ok ? 0 : 2;
 }

@@ -141,6 +141,7 @@ def test_plain_c_client_of_the_abi(tmp_path):
     r = subprocess.run([build_c_client(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'C client OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'level 2: 5 segments, flux = 360.0000' in r.stdout and 'level 1: 648 cells, flux = 360.0000' in r.stdout
+    assert 'ingest: decoded 1.0 (status 0)' in r.stdout
 
 
 def _bench_json(extra, nproc=1):
