@@ -139,7 +139,7 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
         jobs[i] = InflateJob{(unsigned long long)in_off[i], (unsigned)in_len[i], (unsigned)origin[3 * i], (unsigned)origin[3 * i + 1],
                              (unsigned)origin[3 * i + 2]};
     }
-    const size_t comp_pad = ((comp_bytes + 3) & ~(size_t)3) + 32;      // whole words + slack the ring may read (never interprets)
+    const size_t comp_pad = ((comp_bytes + 3) & ~(size_t)3) + 64;      // whole words + slack the ring may read (never interprets)
     const size_t tmp_bytes = (size_t)chunk_bytes * (size_t)n;
     if (h->comp_cap < comp_pad) {
         if (h->d_comp) (void)hipFree(h->d_comp);
@@ -165,10 +165,11 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
         NF_HIP(hipMalloc((void **)&h->d_status, sizeof(int) * (size_t)n));
         h->jobs_cap = (size_t)n;
     }
-    NF_HIP(hipMemsetAsync(h->d_comp + (comp_pad - 64), 0, 64, s));      // the padding behind the data
+    const size_t tail = comp_bytes & ~(size_t)3;                        // zero the last partial word and the padding behind the data
+    NF_HIP(hipMemsetAsync(h->d_comp + tail, 0, comp_pad - tail, s));
     NF_HIP(hipMemcpyAsync(h->d_comp, comp_host, comp_bytes, hipMemcpyHostToDevice, s));
     NF_HIP(hipMemcpyAsync(h->d_jobs, jobs.data(), sizeof(InflateJob) * (size_t)n, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_inflate, dim3((unsigned)n), dim3(64), 0, s, h->d_comp, (unsigned long long)(comp_pad - 32),
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)n), dim3(64), 0, s, h->d_comp, (unsigned long long)comp_pad,
                        h->d_jobs, n, h->d_tmp, (unsigned)chunk_bytes, h->d_status);
     const SlabGeom g{(unsigned)chunk_dims[0], (unsigned)chunk_dims[1], (unsigned)chunk_dims[2], (unsigned)slab_dims[0],
                      (unsigned)slab_dims[1], (unsigned)slab_dims[2]};

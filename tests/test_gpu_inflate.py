@@ -93,6 +93,14 @@ def test_device_tiled_and_overhanging_chunks(decoder):
     assert lv.device_plan(0) is None
 
 
+def test_device_inflate_single_tiny_stream(decoder):
+    """one stream of a few bytes: the compressed buffer is smaller than its own padding"""
+    for data in (b'a', b'abcd', b'\x00\x00\x80\x3f'):
+        for level in (0, 6):
+            out = decoder.decode_streams([zlib.compress(data, level)], len(data))
+            assert bytes(out[0]) == data
+
+
 def test_device_inflate_refuses_malformed_streams(decoder):
     from nemoflux_amd._lib import NemofluxError
     rng = numpy.random.default_rng(4)
