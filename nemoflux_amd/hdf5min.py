@@ -159,6 +159,20 @@ class Dataset(object):
                 self._chunks = list(self._h5._chunk_btree(btree, rank))
         return self._chunks
 
+    def _chunks_of_lead(self, lead):
+        """chunks whose leading offset covers `lead`, through an index built once (a year of daily output has tens of
+        thousands of chunks: scanning them for every time step would be quadratic)"""
+        chunks = self._ensure_chunks()
+        idx = getattr(self, '_lead_index', None)
+        if idx is None or idx[0] is not chunks:
+            c0 = int(self._layout[2][0])
+            table = {}
+            for c in chunks:
+                for k in range(c[0][0], min(c[0][0] + c0, self.shape[0])):
+                    table.setdefault(k, []).append(c)
+            idx = self._lead_index = (chunks, table)
+        return idx[1].get(lead, [])
+
     def device_plan(self, lead):
         """How the slab [lead] of the leading axis can be decoded ON THE DEVICE (nemoflux_amd.ingest.ChunkDecoder), or None
         when it has to go through the host path: {'chunks': [(byte offset in the mapped file, compressed size, (z0, y0, x0)
@@ -185,7 +199,7 @@ class Dataset(object):
         pad = 4 - rank                            # slab seen as (nz, ny, nx) with leading ones
         slab = (1,) * pad + tuple(int(x) for x in self.shape[1:])
         cdim = (1,) * pad + cshape[1:]
-        todo = [c for c in self._ensure_chunks() if c[0][0] == lead]
+        todo = self._chunks_of_lead(lead)
         expected = int(numpy.prod([-(-n // c) for n, c in zip(slab, cdim)]))
         if len(todo) != expected or any(c[2] != 0 or c[3] == UNDEF for c in todo):
             return None                           # chunks never written / stored unfiltered: the host path fills them in
@@ -201,8 +215,7 @@ class Dataset(object):
         shape = self.shape if lead is None else (1,) + self.shape[1:]
         nbytes = int(numpy.prod(cshape)) * self.dtype.itemsize
         self._ensure_chunks()
-        todo = [c for c in self._chunks if c[3] != UNDEF and
-                (lead is None or c[0][0] <= lead < c[0][0] + cshape[0])]
+        todo = [c for c in (self._chunks if lead is None else self._chunks_of_lead(lead)) if c[3] != UNDEF]
         expected = int(numpy.prod([-(-s // c) for s, c in zip(shape, cshape)]))
         if len(todo) < expected:   # chunks that were never written read as the HDF5 fill value (0 when the file defines none)
             if out is None:
