@@ -1102,3 +1102,32 @@ def test_three_dimensional_uo_without_a_time_axis(oracle):
     assert numpy.array_equal(f2.integratedVelocity, st.integratedVelocity)
     with pytest.raises(RuntimeError):
         quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], u3[0], v3[0], tr)     # 2 levels of thickness, 1 of data
+
+
+@pytest.mark.parametrize('geometry', ['rectangles', 'parallelograms'])
+def test_gpu_weight_entries_against_an_independent_sampling_algorithm(geometry, oracle):
+    """GPU weights, entry by entry, against tests/test_oracle_golden.py::sampled_weights -- an algorithm that shares nothing
+    with K2 or with the oracle's restatement (sampling instead of clipping, closed-form inverse bilinear map, numerical
+    integrals)."""
+    from nemoflux_amd import mint
+    from test_oracle_golden import sampled_weights
+    o = oracle.DataGen(24, 12, 1, 1)
+    blon, blat = o.bounds_lon.copy(), o.bounds_lat.copy()
+    if geometry == 'parallelograms':
+        blon = blon + 0.35 * blat
+    pts = oracle.assemble_points(blon, blat)
+    xyz = numpy.array([(-131.3, -41.2, 0.), (-20.7, 33.9, 0.), (95.1, -12.4, 0.), (60.3, 47.7, 0.)])
+    grid = mint.Grid()
+    grid.setPoints(pts)
+    pli = mint.PolylineIntegral()
+    pli.setGrid(grid)
+    pli.buildLocator(numCellsPerBucket=128, periodX=0., enableFolding=False)
+    pli.computeWeights(xyz, counterclock=False)
+    ce, w, sg = pli.getWeights()
+    got = {}
+    for s_, c_, w_ in zip(sg.tolist(), ce.tolist(), w.tolist()):
+        got[(s_, c_)] = got.get((s_, c_), 0.0) + w_
+    want = sampled_weights(pts, xyz)
+    scale = max(abs(x) for x in got.values())
+    assert set(k for k, val in want.items() if abs(val) > 1e-3) <= set(got)
+    assert max(abs(got[k] - want.get(k, 0.0)) for k in got) <= 2e-3 * scale

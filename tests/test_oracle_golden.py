@@ -424,3 +424,78 @@ def test_weights_agree_with_quadrature_of_the_interpolated_field(rotated, oracle
         quad = line_quadrature_of_face_vectors(lambda p: oracle.vector_interp(pts, p, data)[0], xyz)
         scale = numpy.abs(w.weight * data.reshape(-1)[w.cell_edge]).sum()
         assert abs(direct - quad) <= 2e-3 * scale, (rotated, direct, quad)
+
+
+def sampled_weights(pts, xyz, nsub=20000):
+    """Weights per (segment, cell, edge) by a route that shares no code and no algorithm with the restatement: the target
+    segment is SAMPLED (no clipping), every sample is located by the closed-form inverse of the bilinear map (a quadratic, no
+    Newton iteration), and the four weight integrals  w_S = int (1-eta) dxi,  w_N = int eta dxi,  w_E = int xi deta,
+    w_W = int (1-xi) deta  along the piece of the line inside the cell are accumulated with the midpoint rule over
+    consecutive samples that fall in the same cell.  O(1/nsub) from the pieces that straddle a cell boundary."""
+    v = pts[:, :, :2]
+    v0, e1, e3 = v[:, 0], v[:, 1] - v[:, 0], v[:, 3] - v[:, 0]
+    h = v[:, 0] - v[:, 1] + v[:, 2] - v[:, 3]
+    cross = lambda a, b: a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]     # noqa: E731
+    lo, hi = v.min(axis=1), v.max(axis=1)
+    out = {}
+    for s, (a, b) in enumerate(zip(xyz[:-1, :2], xyz[1:, :2])):
+        t = (numpy.arange(nsub + 1)) / nsub
+        p = a[None, :] + t[:, None] * (b - a)[None, :]
+        cand = numpy.nonzero((hi[:, 0] >= p[:, 0].min()) & (lo[:, 0] <= p[:, 0].max()) &
+                             (hi[:, 1] >= p[:, 1].min()) & (lo[:, 1] <= p[:, 1].max()))[0]
+        cell_of = numpy.full(nsub + 1, -1)
+        xi = numpy.zeros((nsub + 1, 2))
+        for c in cand:
+            q = p - v0[c]
+            A, B, C = cross(e3[c], h[c]), cross(e3[c], e1[c]) - cross(q, h[c][None, :]), -cross(q, e1[c][None, :])
+            with numpy.errstate(all='ignore'):
+                if abs(A) < 1e-14 * max(abs(cross(e3[c], e1[c])), 1e-300):
+                    eta = -C / B
+                else:
+                    disc = numpy.sqrt(numpy.maximum(B * B - 4 * A * C, 0.0))
+                    r1, r2 = (-B + disc) / (2 * A), (-B - disc) / (2 * A)
+                    eta = numpy.where((r1 >= -1e-9) & (r1 <= 1 + 1e-9), r1, r2)
+                d = e1[c][None, :] + eta[:, None] * h[c][None, :]
+                xi0 = ((q - eta[:, None] * e3[c][None, :]) * d).sum(axis=1) / (d * d).sum(axis=1)
+            inside = (xi0 >= -1e-9) & (xi0 <= 1 + 1e-9) & (eta >= -1e-9) & (eta <= 1 + 1e-9) & (cell_of < 0)
+            cell_of[inside] = c
+            xi[inside, 0], xi[inside, 1] = xi0[inside], eta[inside]
+        same = (cell_of[1:] == cell_of[:-1]) & (cell_of[1:] >= 0)
+        dxi = xi[1:] - xi[:-1]
+        xm = 0.5 * (xi[1:] + xi[:-1])
+        w = numpy.stack([dxi[:, 0] * (1 - xm[:, 1]), dxi[:, 1] * xm[:, 0], dxi[:, 0] * xm[:, 1], dxi[:, 1] * (1 - xm[:, 0])], axis=1)
+        for c in numpy.unique(cell_of[1:][same]):
+            sel = same & (cell_of[1:] == c)
+            for e in range(4):
+                out[(s, int(c) * 4 + e)] = float(w[sel, e].sum())
+    return out
+
+
+@pytest.mark.parametrize('geometry', ['rectangles', 'parallelograms'])
+def test_weight_entries_against_an_independent_sampling_algorithm(geometry, oracle):
+    """the GPU weights and the oracle's are the same algorithm by the same author.  Here every weight
+    ENTRY of the restatement is checked against sampled_weights (sampling instead of clipping, closed-form instead of Newton
+    inverse map, numerical instead of closed-form integrals) on lines that cross cells in general position -- where every
+    point of the line belongs to exactly one cell, so the 1/n sharing along edges does not enter.  On rectangles and on
+    sheared cells (parallelograms: xi is affine in lon/lat, so a straight line is straight in xi space too).  On cells that
+    are not parallelograms the entries differ by construction -- the algorithm takes the chord in xi space between the two
+    ends of a sub-segment, the sampling follows the curved image of the line (1.7 % of the largest weight on the 24 x 12
+    rotated grid) -- and only fluxes of divergence-free data agree there (the quadrature test above)."""
+    nx, ny = 24, 12
+    o = oracle.DataGen(nx, ny, 1, 1)
+    blon, blat = o.bounds_lon.copy(), o.bounds_lat.copy()
+    if geometry == 'parallelograms':
+        blon = blon + 0.35 * blat                  # shear: every cell becomes the same parallelogram
+    pts = oracle.assemble_points(blon, blat)
+    xyz = numpy.array([(-131.3, -41.2, 0.), (-20.7, 33.9, 0.), (95.1, -12.4, 0.), (60.3, 47.7, 0.)])
+    w = oracle.polyline_weights(pts, xyz, periodX=0.)
+    assert numpy.allclose(w.coverage, 1.0, rtol=0, atol=1e-10)
+    got = w.as_dict()
+    want = sampled_weights(pts, xyz)
+    assert set(k for k, val in want.items() if abs(val) > 1e-3) <= set(got)
+    scale = max(abs(x) for x in got.values())
+    worst = max(abs(got[k] - want.get(k, 0.0)) for k in got)
+    assert worst <= 2e-3 * scale, (geometry, worst, scale)
+    # and the totals for arbitrary data
+    data = numpy.random.default_rng(5).standard_normal(pts.shape[0] * 4)
+    assert abs(sum(got[k] * data[k[1]] for k in got) - sum(want[k] * data[k[1]] for k in want)) <= 2e-3 * scale * numpy.sqrt(len(got))
