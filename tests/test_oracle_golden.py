@@ -499,3 +499,32 @@ def test_weight_entries_against_an_independent_sampling_algorithm(geometry, orac
     # and the totals for arbitrary data
     data = numpy.random.default_rng(5).standard_normal(pts.shape[0] * 4)
     assert abs(sum(got[k] * data[k[1]] for k in got) - sum(want[k] * data[k[1]] for k in want)) <= 2e-3 * scale * numpy.sqrt(len(got))
+
+
+def test_shared_edge_rule_against_the_sampling_algorithm(oracle):
+    """A target line that runs ALONG grid lines (every point lies on an edge shared by two cells, or on a node shared by
+    four): the restatement splits the weight 1/n between the cells that see the same sub-segment, the sampling algorithm gives
+    every sample to ONE cell.  For conforming edge data (one value per unique edge) both must give the same flux -- which
+    pins the multiplicity rule without using it."""
+    nx, ny = 24, 12
+    o = oracle.DataGen(nx, ny, 1, 1)
+    pts = oracle.assemble_points(o.bounds_lon, o.bounds_lat)
+    rng = numpy.random.default_rng(23)
+    eU, eV = rng.standard_normal((ny, nx)), rng.standard_normal((ny, nx))
+    data = numpy.zeros((ny, nx, 4))
+    data[:, :, 1], data[:, :, 2] = eU, eV
+    data[1:, :, 0], data[:, 1:, 3], data[:, 0, 3] = eV[:-1], eU[:, :-1], eU[:, -1]
+    data[0, :, 0] = rng.standard_normal(nx)          # the southern boundary edges are not shared: any value
+    data = data.reshape(-1)
+    # along y = 30 from node to node, up the grid line x = 45, then a diagonal through nodes
+    xyz = numpy.array([(-135., 30., 0.), (45., 30., 0.), (45., -45., 0.), (-15., 15., 0.)])
+    w = oracle.polyline_weights(pts, xyz, periodX=0.)
+    assert numpy.allclose(w.coverage, 1.0, rtol=0, atol=1e-10)
+    got = w.as_dict()
+    halves = [k for k in got if abs(got[k]) > 0]
+    assert len(set(k[1] // 4 for k in halves)) >= 2 * 12          # both sides of the grid lines carry weight
+    want = sampled_weights(pts, xyz)
+    a = sum(got[k] * data[k[1]] for k in got)
+    b = sum(want[k] * data[k[1]] for k in want)
+    scale = sum(abs(got[k] * data[k[1]]) for k in got)
+    assert abs(a - b) <= 2e-3 * scale, (a, b)          # the sampling loses a piece of 1/nsub at every cell crossing
