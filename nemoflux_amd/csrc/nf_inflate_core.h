@@ -6,15 +6,13 @@
 // as they are and every chunk is inflated by its own wavefront, hundreds at a time, straight into the staging slab the
 // flux kernel reads.  Written from the two RFCs; no zlib code is used.
 //
-// Work split inside the wavefront (the format is serial per stream, the parallelism is ACROSS streams):
-//   phase A  all lanes   keep the LDS input ring filled (coalesced 4-byte words from HBM)
-//   phase B  lane 0      decode up to 64 symbols through LDS lookup tables into a small queue (one packed word per symbol:
-//                        the literal, or length and distance)
-//   phase C  all lanes   in queue order (output positions by a prefix sum of the lengths): runs of literals are written to
-//                        the 32 KiB LDS window by as many lanes at once, matches are copied 64 bytes per step (overlapping
-//                        copies by the period rule); every 8 KiB the new bytes are flushed to HBM as whole 4-byte words
-//                        and summed into the stream's Adler-32
-//   tables   lane 0 assigns the canonical codes of a dynamic / fixed block, all lanes fill the 10-bit lookup tables
+// Work inside the wavefront (the format is serial per stream, the parallelism is ACROSS streams):
+//   input    all lanes keep the LDS input ring filled (coalesced 4-byte words from HBM)
+//   decode   all lanes run the symbol decoder on UNIFORM values (scalar code): one LDS table lookup per symbol; a literal is
+//            one byte store into the 32 KiB LDS window, a match is copied by the 64 lanes on the spot (overlapping copies by
+//            the period rule) -- stream order, no queue
+//   output   every 8 KiB the new bytes are flushed to HBM as whole 4-byte words and summed into the stream's Adler-32
+//   tables   lane 0 assigns the canonical codes of a dynamic / fixed block, all lanes fill the lookup tables
 //
 // The same source compiles for the host (NFI_HOST: one "lane", no barriers) so that tests/ can run it against zlib's own
 // output on the CPU; on the device it is driven by nf_inflate.hip.  Every loop is bounded by the input and output
@@ -69,7 +67,7 @@ enum {
 constexpr int kNfiWindow = 32768;          // RFC 1951: distances up to 32 KiB
 constexpr int kNfiRingWords = 512;         // input ring: two halves of 256 words (1 KiB each); a round reads < 100 words
 constexpr int kNfiHalf = 256;
-constexpr int kNfiQueue = 64;              // symbols decoded by lane 0 per round
+constexpr int kNfiQueue = 64;              // symbols decoded per round (between two looks at the input ring and the flush)
 constexpr int kNfiLitBits = 10, kNfiDistBits = 8, kNfiClBits = 7;
 constexpr uint32_t kNfiStoredRound = 512;  // bytes of a stored block moved per round (must stay inside one ring half)
 
@@ -90,9 +88,6 @@ struct NfiCtx {           // lives in LDS (< 40 KiB, so that four fit a CU's 160
     NfiHuffSmall dist;
     uint8_t lens[320];                     // code lengths: 288 literal/length + 32 distance
     uint16_t code[320];                    // canonical code of every symbol (bit-reversed, as it appears in the stream)
-    // symbol queue of one round: (length << 16) | distance for a match, the byte itself (length 0) for a literal
-    uint32_t q_sym[kNfiQueue];
-    uint32_t q_pos0;                       // output position of the round's first symbol
     // state shared between the phases (written by lane 0, read by all after a barrier)
     uint64_t bitbuf;
     int32_t bitcnt;
@@ -100,7 +95,6 @@ struct NfiCtx {           // lives in LDS (< 40 KiB, so that four fit a CU's 160
     uint32_t loaded;        // ring words loaded so far
     uint32_t pos;           // output bytes produced
     uint32_t flushed;       // output bytes written to HBM
-    int32_t nq;
     int32_t state;          // 0 = need a block header, 1 = inside a Huffman block, 2 = inside a stored block, 3 = finished
     int32_t last;           // BFINAL of the current block
     uint32_t stored_left;
@@ -330,10 +324,28 @@ NFI_FN void nfi_build_tables(NfiCtx &c)
 }
 
 // ---------------------------------------------------------------------------------------------- phase B: lane 0
-// decode up to kNfiQueue symbols of the current Huffman block into the queue.  A wavefront issues one instruction every
-// four cycles at best, so what this loop costs is its instruction count: the run of short-coded literals -- most symbols of
-// real data -- is a loop of its own with one table lookup, one packed queue store and a handful of scalar instructions per
-// byte; everything else (long codes, matches, end of block, the output running full) leaves it for the general path below.
+// A match is copied 64 bytes per step by all lanes; an overlapping copy (dist < len) repeats the last dist bytes.
+NFI_FN void nfi_copy_match(NfiCtx &c, uint32_t pos, uint32_t len, uint32_t dist)
+{
+    const float rcp = 1.0f / (float)dist;            // j < 258: the float quotient is exact to within one, fixed up below
+    NFI_FOR_LANES(j, len) {
+        uint32_t off = (uint32_t)j;                  // overlapping copy (dist < len): the bytes repeat with period dist
+        if (off >= dist) {
+            const uint32_t q = (uint32_t)((float)off * rcp);
+            off -= q * dist;
+            if ((int32_t)off < 0) off += dist;
+            else if (off >= dist) off -= dist;
+        }
+        c.window[(pos + j) & (kNfiWindow - 1)] = c.window[(pos - dist + off) & (kNfiWindow - 1)];
+    }
+}
+
+// decode up to kNfiQueue symbols of the current Huffman block straight into the LDS window.  Executed by ALL lanes on uniform
+// values: a literal is one byte store (every lane writes the same byte to the same address), a match is copied by the 64
+// lanes on the spot -- the symbols take effect in stream order, and a wavefront's LDS instructions execute in issue order, so
+// no queue, no barrier and no reordering hazard is left.  A wavefront issues one instruction every four cycles at best, so
+// what this loop costs is its instruction count: the run of short-coded literals -- most symbols of real data -- is a loop of
+// its own with one table lookup, one byte store and a handful of scalar instructions per byte.
 NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
 {
     NfiBits b;      // executed by ALL lanes on uniform values (see NFI_UNI): scalar code
@@ -350,8 +362,7 @@ NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
         nextw = NFI_UNI(c.ring[b.word & (kNfiRingWords - 1)]);           \
     }
     uint32_t pos = NFI_UNI(c.pos);
-    c.q_pos0 = pos;
-    uint32_t nq = 0;
+    uint32_t nq = 0;                              // symbols of this round
     int err = 0, state = 1;
     constexpr uint32_t kMask = (1u << kNfiLitBits) - 1u;
     for (;;) {
@@ -368,7 +379,8 @@ NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
             if (e - 1u >= 4095u) break;
             b.buf >>= (e & 15);
             b.cnt -= (int)(e & 15);
-            c.q_sym[nq++] = e >> 4;
+            c.window[pos & (kNfiWindow - 1)] = (uint8_t)(e >> 4);
+            ++nq;
             ++pos;
             --rem;
             have = false;
@@ -390,7 +402,8 @@ NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
         }
         if (sym < 256) {                          // a literal with a long code, or one that does not fit any more
             if (pos >= out_len) { err = NFI_ERR_OUTPUT; break; }
-            c.q_sym[nq++] = (uint32_t)sym;
+            c.window[pos & (kNfiWindow - 1)] = (uint8_t)sym;
+            ++nq;
             ++pos;
         } else if (sym == 256) {
             state = last ? 3 : 0;
@@ -411,14 +424,14 @@ NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
             const uint32_t dist = dbase + nfi_take(b, dx);
             if (dist > pos) { err = NFI_ERR_DISTANCE; break; }
             if (pos + len > out_len) { err = NFI_ERR_OUTPUT; break; }
-            c.q_sym[nq++] = (len << 16) | dist;          // len >= 3, dist <= 32768
+            nfi_copy_match(c, pos, len, dist);          // len in 3 .. 258, dist in 1 .. 32768
+            ++nq;
             pos += len;
         }
     }
 #undef NFI_REFILL
     if (err) c.err = err;
     c.state = state;
-    c.nq = (int)nq;
     c.pos = pos;
     c.bitbuf = b.buf;
     c.bitcnt = b.cnt;
@@ -426,69 +439,6 @@ NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
 }
 
 // ---------------------------------------------------------------------------------------------- phase C: all lanes
-// In queue order: a run of literals is written by as many lanes at once, a match is copied 64 bytes per step.  (Writing all
-// literals of the round first would be wrong: the window is a ring of exactly the maximum distance, so a literal further on
-// shares its slot with a byte that an earlier long-distance match of the same round still has to read.)
-NFI_FN void nfi_copy_match(NfiCtx &c, uint32_t pos, uint32_t len, uint32_t dist)
-{
-    const float rcp = 1.0f / (float)dist;            // j < 258: the float quotient is exact to within one, fixed up below
-    NFI_FOR_LANES(j, len) {
-        uint32_t off = (uint32_t)j;                  // overlapping copy (dist < len): the bytes repeat with period dist
-        if (off >= dist) {
-            const uint32_t q = (uint32_t)((float)off * rcp);
-            off -= q * dist;
-            if ((int32_t)off < 0) off += dist;
-            else if (off >= dist) off -= dist;
-        }
-        c.window[(pos + j) & (kNfiWindow - 1)] = c.window[(pos - dist + off) & (kNfiWindow - 1)];
-    }
-}
-#ifdef NFI_HOST
-NFI_FN void nfi_apply_queue(NfiCtx &c)
-{
-    uint32_t pos = c.q_pos0;
-    for (int k = 0; k < c.nq; ++k) {
-        const uint32_t q = c.q_sym[k], len = q >> 16;
-        if (len == 0) c.window[pos++ & (kNfiWindow - 1)] = (uint8_t)q;
-        else {
-            nfi_copy_match(c, pos, len, q & 0xffffu);
-            pos += len;
-        }
-    }
-}
-#else
-// device: lane k holds queue entry k; output positions come from a wavefront prefix sum of the lengths; a ballot gives
-// the positions of the matches, so the runs of literals between them are found with scalar bit operations, not LDS reads
-NFI_FN void nfi_apply_queue(NfiCtx &c)
-{
-    const int nq = c.nq, lane = NFI_LANE;
-    const uint32_t q = lane < nq ? c.q_sym[lane] : 0u;
-    const uint32_t mylen = q >> 16, mydist = q & 0xffffu;
-    uint32_t adv = lane < nq ? (mylen ? mylen : 1u) : 0u, incl = adv;
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-    }
-    const uint32_t mypos = c.q_pos0 + incl - adv;
-    const unsigned long long matches = __ballot(mylen != 0);
-    int k = 0;
-    while (k < nq) {                                         // uniform
-        const unsigned long long rest = matches >> k;
-        const int nm = rest ? k + (int)__builtin_ctzll(rest) : nq;      // next match at or after k
-        if (nm > k) {
-            if (lane >= k && lane < nm) c.window[mypos & (kNfiWindow - 1)] = (uint8_t)q;
-            NFI_SYNC();
-        }
-        if (nm < nq) {
-            const uint32_t pos = __shfl(mypos, nm, 64), len = __shfl(mylen, nm, 64), dist = __shfl(mydist, nm, 64);
-            nfi_copy_match(c, pos, len, dist);
-            NFI_SYNC();
-        }
-        k = nm + 1;
-    }
-}
-#endif
-
 // bytes of a stored block: straight from the input ring into the window (all lanes), at most one ring half per call
 NFI_FN void nfi_stored_round(NfiCtx &c, uint32_t out_len)
 {
@@ -605,7 +555,6 @@ NFI_FN int nfi_inflate_stream(NfiCtx &c, const uint8_t *src, uint32_t in_len, ui
         c.loaded = 0;
         c.pos = 0;
         c.flushed = 0;
-        c.nq = 0;
         c.state = 0;
         c.last = 0;
         c.err = in_len < 6 ? NFI_ERR_INPUT : NFI_OK;
@@ -637,7 +586,6 @@ NFI_FN int nfi_inflate_stream(NfiCtx &c, const uint8_t *src, uint32_t in_len, ui
         } else if (c.state == 1) {
             nfi_decode_round(c, out_len);          // all lanes, uniform
             NFI_SYNC();
-            nfi_apply_queue(c);
             nfi_flush(c, dst, false);
         } else {
             nfi_stored_round(c, out_len);
