@@ -16,7 +16,7 @@ Scaling: strong by default -- BASELINE config 4 is the FIXED 3600 x 1800 x 75 x 
 --scaling weak gives every rank a C4-sized block of 12 time steps of a 12*N-step series instead.
 At N=1 the line also carries a float32 sub-record (the dtype of real NEMO files) and the CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: starts its own N ranks, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 """
 import argparse
@@ -139,6 +139,7 @@ def run_workload(args, dtype, scaling, rank, world, local, want_totals=False):
     barrier()
     elapsed = time.perf_counter() - t0
     nlaunch, kernel_ms, flux_ms, expand_ms = fld.readKernelTiming(split=True)
+    k3_ms = fld.readTransectTiming()
     fld.enableKernelTiming(False)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
@@ -160,8 +161,30 @@ def run_workload(args, dtype, scaling, rank, world, local, want_totals=False):
             nfdist.reduce_rows(rows)
         torch.cuda.synchronize()
         m['reduce'] = {'message_bytes': int(rows.numel() * rows.element_size()), 'op': 'all_reduce(SUM, float64)',
-                       'backend': dist.get_backend(), 'allreduce_ms': round((time.perf_counter() - t0) / reps * 1e3, 4),
-                       'calls_per_step': 1}
+                       'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                       'allreduce_ms': round((time.perf_counter() - t0) / reps * 1e3, 4), 'calls_per_step': 1}
+        # what the communicator itself says (the engine's own RCCL communicator when the backend is RCCL), and one record
+        # per rank: which device it ran on, which slabs it owned, what its kernels took
+        comm = nfdist.native_comm()
+        seen = comm.info() if comm is not None else None
+        m['reduce']['path'] = ('nf_rows_allreduce (ncclAllReduce on the library\'s own communicator)' if comm is not None
+                               else 'torch.distributed.all_reduce')
+        if seen is not None:
+            m['reduce']['world_size_rccl'] = seen['world_size']
+            m['reduce']['library'] = seen['library']
+        prop = torch.cuda.get_device_properties(local)
+        mine = {'rank': rank, 'device_index': local, 'device_name': prop.name,
+                'device_uuid': str(getattr(prop, 'uuid', '')), 'pci_bus_id': int(getattr(prop, 'pci_bus_id', -1)),
+                'rccl_rank': None if seen is None else seen['rank'],
+                'rccl_device_index': None if seen is None else seen['device_index'],
+                'slabs': [int(srange[0]), int(srange[1])], 'steps_touched': [int(t_begin), int(t_end)],
+                'launches_per_pass': nlaunch // max(1, args.steps),
+                'k_flux_ms': round(flux_ms / max(1, args.steps), 4),
+                'k_expand_ms': round(expand_ms / max(1, args.steps), 4),
+                'k3_ms': round(k3_ms / max(1, args.steps), 4)}
+        recs = [None] * world
+        dist.all_gather_object(recs, mine)
+        m['ranks'] = recs
         step()                       # the rows the accuracy block reads: one clean pass after the repeated reduces
 
     # ---- accuracy: every transect total of every time step vs the closed form (fluxexact.py:36-46)
@@ -200,7 +223,9 @@ def run_workload(args, dtype, scaling, rank, world, local, want_totals=False):
                      'kernel': 'nf::k_flux + nf::k_expand_planes (one event pair around both)' if expand_ms > 0 else 'nf::k_flux',
                      'avg_launch_ms': round(avg_ms, 4), 'launches': nlaunch,
                      'avg_ms_by_kernel': {'nf::k_flux': round(flux_ms / max(1, nlaunch), 4),
-                                          'nf::k_expand_planes': round(expand_ms / max(1, nlaunch), 4)},
+                                          'nf::k_expand_planes': round(expand_ms / max(1, nlaunch), 4),
+                                          'transect reduction (nf::k_gather_segscan + 2 finalize kernels)':
+                                              round(k3_ms / max(1, nlaunch), 4)},
                      'algorithmic_bytes_per_unit': round(bytes_per_unit, 3),
                      'units_per_launch': units_per_launch,
                      'wall_frac': round(bytes_per_unit * units_total * (own / float(nt_global * nz)) /
@@ -230,13 +255,20 @@ def main():
                          '(ncell,4) copies and |.| arrays are derived at read-back, which a batch driver never asks for')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has made no GPU call and never will
+        # (device_count() does not initialise the runtime); the N ranks are fresh child processes.
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     from nemoflux_amd import dist as nfdist
 
     rank, world, local = nfdist.init_from_env()
-    if world != args.gpus and rank == 0:
-        print(f'# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree', file=sys.stderr)
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: nemoflux_amd has no CPU fallback')
     torch.cuda.set_device(local)
@@ -264,6 +296,7 @@ def main():
     }
     if 'reduce' in m:
         out['reduce'] = m['reduce']
+        out['ranks'] = m['ranks']
     if 'totals' in m:
         out['totals'] = m['totals']
 
@@ -288,7 +321,37 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        nfdist.destroy_native_comms()
         dist.destroy_process_group()
+
+
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks the way the driver's own N>1 command does
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>), one process per GPU, as a
+    child of this process -- which has not touched the GPU -- relay rank 0's JSON line and return the child's exit code.
+    Fewer than N visible devices is an error, not a silent N=1 run (NF_FORCE_DEVICE, the rehearsal hook of
+    nemoflux_amd.dist that puts every rank on one GPU, lifts that check)."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()        # counts devices without initialising the HIP runtime in this process
+    if ndev < ngpus and 'NF_FORCE_DEVICE' not in os.environ:
+        print(f'bench.py: --gpus {ngpus} but {ndev} GPU(s) visible on this node; refusing to run a smaller job under that '
+              'name', file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={ngpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: what RCCL needs between processes on this host
+    env.setdefault('OMP_NUM_THREADS', '4')
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:               # rank 0's JSON line (and anything else the ranks print) goes straight through
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
 
 
 def cpu_baseline(dg, u, v, nz, ny, nx, polys, args):

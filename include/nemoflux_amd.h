@@ -100,6 +100,11 @@ int mnt_polylineintegral_buildLocator(PolylineIntegral_t **self, int numCellsPer
  * pole (the cells around the pole of a rotated grid) -- never a silent number. */
 int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, const double xyz[],
                                         int counterclock);
+/* extension (not in mint): what computeWeights does with such a cell.  skip = 0 (default): the error above.  skip = 1:
+ * the cell contributes nothing -- the rest of the line is integrated and mnt_polylineintegral_getCoverage reports
+ * the fraction of every target segment that was (real ORCA grids with a few distorted polar cells far from the
+ * transect's physics; mint itself returns a number there, pinned by nothing in the reference). */
+int mnt_polylineintegral_setUnsupportedCells(PolylineIntegral_t **self, int skip);
 /* .getIntegral(data (ncell,4) float64 HOST, placement) -> *result   field.py:102, fluxplot.py:56
  * Host data is staged to HBM (PCIe-inclusive path); see ...getIntegralDev for resident data. */
 int mnt_polylineintegral_getIntegral(PolylineIntegral_t **self, const double data[], int placement,
@@ -166,6 +171,8 @@ int nf_field_set_slab_range(nf_field **self, long s_begin, long s_end);
 /* Transects (field.py:43-49): add polylines, then build all weights in one batched pass.
  * xyz: (npts,3) host.  *transect_id receives the index. */
 int nf_field_add_transect(nf_field **self, const double *xyz, int npts, int counterclock, int *transect_id);
+/* same policy switch as mnt_polylineintegral_setUnsupportedCells, for the batched build below; call before build_weights */
+int nf_field_set_unsupported_cells(nf_field **self, int skip);
 int nf_field_build_weights(nf_field **self, int numCellsPerBucket, double periodX);
 int nf_field_num_transects(nf_field **self, int *n);
 int nf_field_num_segments(nf_field **self, int *nseg_total);             /* over all transects */
@@ -214,6 +221,29 @@ int nf_field_timing(nf_field **self, int enable);
 int nf_field_timing_read(nf_field **self, long *launches, double *total_ms);
 /* how the total of the last nf_field_timing_read splits between the flux kernel and the expansion kernel behind it */
 int nf_field_timing_split(nf_field **self, double *flux_ms, double *expand_ms);
+/* time of the transect reductions (K3: gather + segmented scan + the two finalize kernels) launched behind the timed flux
+ * launches of the last nf_field_timing_read -- measured with the same events, not part of its total */
+int nf_field_timing_k3(nf_field **self, double *k3_ms);
+
+/* ------------------------------------------------------------------ multi-GPU: the one collective */
+/* The reference walks the time steps serially (fluxplot.py:51-59) and contracts z with one tensordot (field.py:161); here
+ * every rank integrates its own (t,z) slabs (nf_field_set_slab_range above) into partial rows (nt, row_length) and ONE
+ * all-reduce(sum, float64) over RCCL / xGMI gives every rank the totals.  One process per GPU.  librccl is resolved at
+ * first use from the copy the process already holds (PyTorch's, or the system's librccl.so.1): no link-time dependency.
+ *   nf_rccl_unique_id : rank 0 creates the 128-byte id and hands it to the other ranks by any means (file, socket, MPI,
+ *                       torch.distributed store)
+ *   nf_rccl_comm_init : every rank, after nf_set_device(its GPU); collective over the nranks callers
+ *   nf_rows_allreduce : rows_dev (HBM, n doubles) summed in place over all ranks, asynchronous on hip_stream.  rccl_comm may
+ *                       also be a ncclComm_t the caller created itself with the same librccl
+ *   nf_rccl_comm_info : what the communicator says about itself (number of ranks, this rank, HIP device index)
+ *   nf_rccl_library   : path of the librccl the entry points were resolved from */
+#define NF_RCCL_UNIQUE_ID_BYTES 128
+int nf_rccl_unique_id(void *id128);
+int nf_rccl_comm_init(void **comm, int nranks, const void *id128, int rank);
+int nf_rccl_comm_destroy(void *comm);
+int nf_rccl_comm_info(void *comm, int *nranks, int *rank, int *device);
+int nf_rccl_library(char *buf, int buflen);
+int nf_rows_allreduce(void *rccl_comm, double *rows_dev, size_t n, void *hip_stream);
 
 /* ------------------------------------------------------------------ file ingest straight to HBM (field.py:149) */
 /* Real NEMO files are NetCDF-4 = HDF5 with uo / vo stored as byte-shuffled, deflated chunks; the reference has netCDF4 /

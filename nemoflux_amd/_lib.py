@@ -66,6 +66,7 @@ _sig('mnt_polylineintegral_del', [_pp])
 _sig('mnt_polylineintegral_setGrid', [_pp, _h])
 _sig('mnt_polylineintegral_buildLocator', [_pp, ctypes.c_int, ctypes.c_double, ctypes.c_int])
 _sig('mnt_polylineintegral_computeWeights', [_pp, ctypes.c_int, c_double_p, ctypes.c_int])
+_sig('mnt_polylineintegral_setUnsupportedCells', [_pp, ctypes.c_int])
 _sig('mnt_polylineintegral_getIntegral', [_pp, c_double_p, ctypes.c_int, c_double_p])
 _sig('mnt_polylineintegral_getIntegralDev', [_pp, ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p])
 _sig('mnt_polylineintegral_getCoverage', [_pp, c_double_p])
@@ -94,6 +95,7 @@ _sig('nf_field_set_sverdrup', [_pp, ctypes.c_int])
 _sig('nf_field_set_compact', [_pp, ctypes.c_int])
 _sig('nf_field_set_slab_range', [_pp, ctypes.c_long, ctypes.c_long])
 _sig('nf_field_add_transect', [_pp, c_double_p, ctypes.c_int, ctypes.c_int, c_int_p])
+_sig('nf_field_set_unsupported_cells', [_pp, ctypes.c_int])
 _sig('nf_field_build_weights', [_pp, ctypes.c_int, ctypes.c_double])
 _sig('nf_field_num_transects', [_pp, c_int_p])
 _sig('nf_field_num_segments', [_pp, c_int_p])
@@ -116,6 +118,13 @@ _sig('nf_field_grid', [_pp, _pp])
 _sig('nf_field_timing', [_pp, ctypes.c_int])
 _sig('nf_field_timing_read', [_pp, ctypes.POINTER(ctypes.c_long), c_double_p])
 _sig('nf_field_timing_split', [_pp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)])
+_sig('nf_field_timing_k3', [_pp, ctypes.POINTER(ctypes.c_double)])
+_sig('nf_rccl_unique_id', [ctypes.c_void_p])
+_sig('nf_rccl_comm_init', [c_void_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_int])
+_sig('nf_rccl_comm_destroy', [ctypes.c_void_p])
+_sig('nf_rccl_comm_info', [ctypes.c_void_p, c_int_p, c_int_p, c_int_p])
+_sig('nf_rccl_library', [ctypes.c_char_p, ctypes.c_int])
+_sig('nf_rows_allreduce', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p])
 c_ll_p = ctypes.POINTER(ctypes.c_longlong)
 _sig('nf_inflater_new', [_pp])
 _sig('nf_inflater_del', [_pp])

@@ -228,6 +228,7 @@ struct PolylineIntegral_t {
     double *d_stage = nullptr;  // host data staged to HBM for getIntegral
     long stage_cells = 0;
     int nseg = 0;
+    int skip_unsupported = 0;   // mnt_polylineintegral_setUnsupportedCells
 };
 
 extern "C" {
@@ -358,6 +359,15 @@ try {
 }
 NF_API_CATCH
 
+int mnt_polylineintegral_setUnsupportedCells(PolylineIntegral_t **self, int skip)
+try {
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_polylineintegral_setUnsupportedCells: null argument");
+    NF_REQUIRE(skip == 0 || skip == 1, NF_ERR_ARG, "mnt_polylineintegral_setUnsupportedCells: policy must be 0 (refuse) or 1 (skip)");
+    (*self)->skip_unsupported = skip;
+    return NF_OK;
+}
+NF_API_CATCH
+
 static int polyline_segments(const double *xyz, int npoints, int counterclock, std::vector<double> &segs,
                              std::vector<int> &cc)
 {
@@ -382,7 +392,8 @@ try {
     std::vector<double> segs;
     std::vector<int> cc;
     p->nseg = polyline_segments(xyz, npoints, counterclock, segs, cc);
-    NF_TRY(build_weights(p->grid->d_xy, p->grid->ncell, segs.data(), cc.data(), p->nseg, p->periodX, &p->ws, nullptr));
+    NF_TRY(build_weights(p->grid->d_xy, p->grid->ncell, segs.data(), cc.data(), p->nseg, p->periodX, &p->ws, nullptr,
+                         p->skip_unsupported));
     dev_free(p->d_tr_off);
     dev_free(p->d_scratch);
     dev_free(p->d_row);
@@ -646,19 +657,20 @@ struct nf_field {
     std::vector<int> tr_off;
     WeightSet ws;
     bool weights_built = false;
+    int skip_unsupported = 0;   // nf_field_set_unsupported_cells
     int *d_tr_off = nullptr;
     double *d_scratch = nullptr, *d_row = nullptr;
     Grid_t grid_view;
     // timing
     bool timing = false;
-    struct TimedLaunch {         // events around one flux launch (+ expansion); mid sits between the two kernels
-        hipEvent_t e0 = nullptr, mid = nullptr, e1 = nullptr;
-        bool has_mid = false;
+    struct TimedLaunch {         // events around one flux launch (+ expansion); mid sits between the two kernels;
+        hipEvent_t e0 = nullptr, mid = nullptr, e1 = nullptr, e2 = nullptr;   // e2 closes the transect reduction (K3)
+        bool has_mid = false, has_k3 = false;
     };
     std::vector<TimedLaunch> ev;     // pool: created once (nf_field_timing reserves), re-used after every timing_read
     size_t ev_used = 0;              // launches recorded since the last timing_read
     long ev_dropped = 0;             // launches not recorded because the pool was at its cap
-    double last_flux_ms = 0.0, last_expand_ms = 0.0;   // split of the last timing_read
+    double last_flux_ms = 0.0, last_expand_ms = 0.0, last_k3_ms = 0.0;   // split of the last timing_read
     // hipGraph of one compute_all pass (launch-bound small grids: 4 launches per time step)
     hipGraphExec_t graph_exec = nullptr;
     double *graph_rows = nullptr;
@@ -698,7 +710,7 @@ static int elem_size(int dtype) { return dtype == NF_F32 ? 4 : 8; }
 static void field_drop_events(nf_field *f)
 {
     for (auto &t : f->ev)
-        for (hipEvent_t e : {t.e0, t.mid, t.e1})
+        for (hipEvent_t e : {t.e0, t.mid, t.e1, t.e2})
             if (e) (void)hipEventDestroy(e);
     f->ev.clear();
     f->ev_used = 0;
@@ -711,11 +723,17 @@ constexpr size_t kMaxTimedLaunches = 1 << 16;
 static int field_reserve_events(nf_field *f, size_t n)
 {
     if (n > kMaxTimedLaunches) n = kMaxTimedLaunches;
-    while (f->ev.size() < n) {
-        f->ev.emplace_back();
-        NF_HIP(hipEventCreate(&f->ev.back().e0));
-        NF_HIP(hipEventCreate(&f->ev.back().mid));
-        NF_HIP(hipEventCreate(&f->ev.back().e1));
+    while (f->ev.size() < n) {   // an entry joins the pool only when all of its events exist
+        nf_field::TimedLaunch t;
+        hipError_t err = hipSuccess;
+        for (hipEvent_t *e : {&t.e0, &t.mid, &t.e1, &t.e2})
+            if (err == hipSuccess) err = hipEventCreate(e);
+        if (err != hipSuccess) {
+            for (hipEvent_t e : {t.e0, t.mid, t.e1, t.e2})
+                if (e) (void)hipEventDestroy(e);
+            NF_HIP(err);
+        }
+        f->ev.push_back(t);
     }
     return NF_OK;
 }
@@ -737,8 +755,19 @@ static int field_timed_flux(nf_field *f, FluxArgs &a)
     a.mid_event = nullptr;
     a.mid_recorded = nullptr;
     f->ev[k].has_mid = mid;
+    f->ev[k].has_k3 = false;
     NF_TRY(rc);
     NF_HIP(hipEventRecord(f->ev[k].e1, f->stream));
+    return NF_OK;
+}
+
+// the transect reduction launched right behind a timed flux launch: e1 .. e2 of the same entry
+static int field_timed_k3_end(nf_field *f)
+{
+    if (!f->timing || f->ev_used == 0 || f->ev_dropped) return NF_OK;
+    auto &t = f->ev[f->ev_used - 1];
+    NF_HIP(hipEventRecord(t.e2, f->stream));
+    t.has_k3 = true;
     return NF_OK;
 }
 
@@ -818,6 +847,7 @@ static int field_step_async(nf_field *f, long t, double *row_dev)
         NF_REQUIRE(f->weights_built, NF_ERR_STATE, "compute: build_weights first");
         NF_TRY(launch_integral(f->ws, f->d_iV, f->ncell, 2, f->nx, f->d_tr_off, (int)f->polylines.size(),
                                f->d_scratch, row_dev, f->stream));
+        NF_TRY(field_timed_k3_end(f));
     }
     return NF_OK;
 }
@@ -917,9 +947,11 @@ static int field_all_steps_batched(nf_field *f, double *rows_dev)
     } else {
         NF_TRY(launch_flux(a, f->stream));
     }
-    if (rowlen > 0)
+    if (rowlen > 0) {
         NF_TRY(launch_integral(f->ws, f->d_iVb, f->ncell, 2, f->nx, f->d_tr_off, (int)f->polylines.size(), f->d_scratchb,
                                rows_dev, f->stream, (int)f->nt, (long)(4 * n), rowlen));
+        NF_TRY(field_timed_k3_end(f));
+    }
     // the resident single-step arrays keep their meaning: they hold the LAST step (what read_step returns)
     NF_HIP(hipMemcpyAsync(f->d_iV, f->d_iVb + (size_t)(f->nt - 1) * 4 * n, sizeof(double) * 4 * n,
                           hipMemcpyDeviceToDevice, f->stream));
@@ -1100,6 +1132,15 @@ try {
 }
 NF_API_CATCH
 
+int nf_field_set_unsupported_cells(nf_field **self, int skip)
+try {
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_unsupported_cells: null field");
+    NF_REQUIRE(skip == 0 || skip == 1, NF_ERR_ARG, "nf_field_set_unsupported_cells: policy must be 0 (refuse) or 1 (skip)");
+    (*self)->skip_unsupported = skip;
+    return NF_OK;
+}
+NF_API_CATCH
+
 int nf_field_build_weights(nf_field **self, int numCellsPerBucket, double periodX)
 try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_build_weights: null field");
@@ -1114,7 +1155,8 @@ try {
         polyline_segments(f->polylines[p].data(), (int)(f->polylines[p].size() / 3), f->poly_cc[p], segs, cc);
         f->tr_off.push_back((int)cc.size());
     }
-    NF_TRY(build_weights(f->d_xy, f->ncell, segs.data(), cc.data(), (int)cc.size(), periodX, &f->ws, f->stream));
+    NF_TRY(build_weights(f->d_xy, f->ncell, segs.data(), cc.data(), (int)cc.size(), periodX, &f->ws, f->stream,
+                         f->skip_unsupported));
     // the engine reduces its own planes: fold the (cell, edge) weights onto the unique edges of (eU, eV) (field.py:219-223)
     // (only on request -- nf_tuning_set("edge_weights", 1) -- because the records measure faster: see nf_integral.hip)
     if (integral_uses_edges()) NF_TRY(fold_weights(&f->ws, f->ncell, f->nx, f->stream));
@@ -1378,10 +1420,15 @@ try {
     NF_REQUIRE(self && *self && launches && total_ms, NF_ERR_ARG, "nf_field_timing_read: null argument");
     nf_field *f = *self;
     NF_HIP(hipStreamSynchronize(f->stream));
-    double tot = 0.0, flux = 0.0, expand = 0.0;
+    double tot = 0.0, flux = 0.0, expand = 0.0, k3 = 0.0;
     for (size_t k = 0; k < f->ev_used; ++k) {
         const auto &t = f->ev[k];
         float ms = 0.f, part = 0.f;
+        if (t.has_k3) {
+            NF_HIP(hipEventElapsedTime(&part, t.e1, t.e2));
+            k3 += part;
+            part = 0.f;
+        }
         NF_HIP(hipEventElapsedTime(&ms, t.e0, t.e1));
         tot += ms;
         if (t.has_mid) {
@@ -1396,6 +1443,7 @@ try {
     *total_ms = tot;
     f->last_flux_ms = flux;
     f->last_expand_ms = expand;
+    f->last_k3_ms = k3;
     f->ev_used = 0;
     return NF_OK;
 }
@@ -1405,6 +1453,13 @@ try {
     NF_REQUIRE(self && *self && flux_ms && expand_ms, NF_ERR_ARG, "nf_field_timing_split: null argument");
     *flux_ms = (*self)->last_flux_ms;
     *expand_ms = (*self)->last_expand_ms;
+    return NF_OK;
+}
+NF_API_CATCH
+int nf_field_timing_k3(nf_field **self, double *k3_ms)
+try {
+    NF_REQUIRE(self && *self && k3_ms, NF_ERR_ARG, "nf_field_timing_k3: null argument");
+    *k3_ms = (*self)->last_k3_ms;
     return NF_OK;
 }
 NF_API_CATCH

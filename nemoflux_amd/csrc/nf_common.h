@@ -149,8 +149,10 @@ int fold_weights(WeightSet *ws, long ncell, long nx, hipStream_t s);
 // expands records into mint-style entries (host arrays): cell_edge = cell*4+edge, weight, seg
 int weights_to_host(const WeightSet &ws, int64_t *cell_edge, double *weight, int *seg);
 // segs_host: (nseg,4) = x0,y0,dx,dy ; seg_cc_host: counterclock flag per segment
+// skip_unsupported: 0 = a target segment that overlaps a non-convex / pole-vertex cell is an error (default); 1 = such
+// cells contribute nothing and the segment's coverage is < 1
 int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
-                  double periodX, WeightSet *out, hipStream_t s);
+                  double periodX, WeightSet *out, hipStream_t s, int skip_unsupported = 0);
 
 // K3: gather + wavefront segmented reduction -> per-segment sums, then per-transect sums.
 // row: (nseg + ntransect) doubles in HBM; tr_offsets_dev: (ntransect+1) segment offsets.

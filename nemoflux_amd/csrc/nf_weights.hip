@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
                                                  const int *__restrict__ seg_cc, int nseg, int nshift,
                                                  double periodX, const int *__restrict__ wave_off,
                                                  int *__restrict__ wave_cnt, Records rec,
-                                                 unsigned long long *__restrict__ err)
+                                                 unsigned long long *__restrict__ err, int skip_unsupported)
 {
     __shared__ double s_xy[kBlock * 8];
     const int tid = threadIdx.x;
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
                                   cymax < symin - slack);
             double ta = 0.0, tb = 0.0;
             if (hit && nonconvex) {   // not a cell the weights are defined on: refuse if the line really crosses it
-                if (!FILL && segment_overlaps_quad(v, qx, qy, dx, dy)) flag_cell(err, c, 1, s);
+                // (skip policy: the cell contributes nothing and the segment's coverage says so)
+                if (!FILL && !skip_unsupported && segment_overlaps_quad(v, qx, qy, dx, dy)) flag_cell(err, c, 1, s);
                 hit = false;
             }
             if (hit) hit = clip_cell(v, qx, qy, dx, dy, ta, tb);
@@ -604,7 +605,7 @@ int fold_weights(WeightSet *ws, long ncell, long nx, hipStream_t s)
 }
 
 int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
-                  double periodX, WeightSet *out, hipStream_t s)
+                  double periodX, WeightSet *out, hipStream_t s, int skip_unsupported)
 {
     out->release();
     out->nseg = nseg;
@@ -626,7 +627,7 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
         snprintf(buf, sizeof buf,
                  kind == 1 ? "computeWeights: target segment %d crosses cell %ld, which is not convex in the (lon,lat) plane "
                              "(a reflex corner or a bow-tie, e.g. a cell touching the pole of a rotated grid): the weights "
-                             "are not defined there"
+                             "are not defined there (setUnsupportedCells('skip') drops such cells instead: coverage < 1)"
                            : "computeWeights: target segment %d: the inverse bilinear map did not converge in cell %ld",
                  seg, cell);
         set_error(buf);
@@ -646,7 +647,7 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     Records none{};
     hipLaunchKernelGGL(k_clip<false>, dim3(nblocks), dim3(kBlock), 0, s, xy, ncell, d_segs.as<double>(),
                        d_cc.as<int>(), nseg, nshift, periodX, (const int *)nullptr, d_cnt.as<int>(), none,
-                       d_err.as<unsigned long long>());
+                       d_err.as<unsigned long long>(), skip_unsupported);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_cnt.as<int>(), nwaves, d_off.as<int>());
     int nrec_i = 0;
     NF_HIP(hipMemcpyAsync(&nrec_i, d_off.as<int>() + nwaves, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -675,7 +676,7 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
                 r_w.as<double>()};
     hipLaunchKernelGGL(k_clip<true>, dim3(nblocks), dim3(kBlock), 0, s, xy, ncell, d_segs.as<double>(),
                        d_cc.as<int>(), nseg, nshift, periodX, d_off.as<int>(), (int *)nullptr, rec,
-                       d_err.as<unsigned long long>());
+                       d_err.as<unsigned long long>(), skip_unsupported);
     NF_HIP(hipGetLastError());
 
     // stable sort of record indices by global segment id

@@ -4,10 +4,17 @@ The reference has no distributed code; this is the MI355X-native a
 (t,z) slab contributes additively and independently to every transect total, so the flattened slab index
 s = t*nz + z is cut into contiguous ranges, one per rank (one process per GPU); each rank integrates only its
 slabs (nf_field_set_slab_range) and the (nt, nseg+ntransect) float64 rows are summed with a single
-torch.distributed all_reduce -- RCCL over xGMI on GPUs ('nccl' backend), gloo on CPU for tests.  The message is
-<= ~0.4 MB (latency-bound), so no bucketing is needed.
+all-reduce over RCCL / xGMI.  The message is <= ~0.4 MB (latency-bound), so no bucketing is needed.
+
+On GPUs ('nccl' backend = RCCL) the reduce is the C ABI's own: nf_rows_allreduce (ncclAllReduce(sum, ncclDouble) in
+csrc/nf_reduce.hip) on a communicator the library creates with nf_rccl_comm_init -- torch.distributed only carries the
+128-byte unique id from rank 0 to the others, the way a plain-C client would carry it over MPI or a socket.  gloo (CPU
+tests, and the rehearsal of N ranks on a one-GPU box) goes through torch.distributed's all_reduce.  NF_NATIVE_REDUCE=0
+keeps torch.distributed's RCCL call on GPUs too.
 """
+import ctypes
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -66,10 +73,88 @@ def all_reduce(tensor, op=None, group=None):
     return tensor
 
 
+class NativeComm(object):
+    """The engine's own RCCL communicator over the ranks of a torch.distributed group (nf_rccl_* of the C ABI)."""
+
+    def __init__(self, group=None):
+        from ._lib import lib, check
+        self._lib, self._check = lib, check
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            check(lib.nf_rccl_unique_id(buf))
+            ident[0] = buf.raw
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(ident, src=src, group=group)
+        self.ptr = ctypes.c_void_p()
+        check(lib.nf_rccl_comm_init(ctypes.byref(self.ptr), world, ctypes.c_char_p(ident[0]), rank))
+
+    def all_reduce_sum(self, rows):
+        assert rows.is_cuda and rows.dtype == torch.float64 and rows.is_contiguous()
+        self._check(self._lib.nf_rows_allreduce(self.ptr, ctypes.c_void_p(rows.data_ptr()), rows.numel(),
+                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def info(self):
+        """What the communicator says about itself: {'world_size', 'rank', 'device_index', 'library'}."""
+        n, r, d = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self._check(self._lib.nf_rccl_comm_info(self.ptr, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d)))
+        path = ctypes.create_string_buffer(512)
+        self._check(self._lib.nf_rccl_library(path, 512))
+        return {'world_size': n.value, 'rank': r.value, 'device_index': d.value, 'library': path.value.decode()}
+
+    def destroy(self):
+        if getattr(self, 'ptr', None):
+            torch.cuda.synchronize()
+            self._lib.nf_rccl_comm_destroy(self.ptr)
+            self.ptr = None
+
+
+_native = {}   # group -> NativeComm, or False when it could not be created on every rank
+
+
+def native_comm(group=None):
+    """The NativeComm of `group` (created at first use, collectively), or None: not the 'nccl' backend, switched off with
+    NF_NATIVE_REDUCE=0, or the communicator could not be created on every rank (reported once on stderr)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != 'nccl':
+        return None
+    if os.environ.get('NF_NATIVE_REDUCE', '1') == '0':
+        return None
+    if group not in _native:
+        comm, err = None, ''
+        try:
+            comm = NativeComm(group)
+        except Exception as e:   # the ranks must agree on the path they take, so no rank raises here
+            err = f'{type(e).__name__}: {e}'
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device='cuda')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            _native[group] = comm
+        else:
+            if comm is not None:
+                comm.destroy()
+            if err or dist.get_rank(group) == 0:
+                print(f'# nemoflux_amd.dist: native RCCL communicator unavailable ({err or "failed on another rank"}); '
+                      'reducing through torch.distributed', file=sys.stderr)
+            _native[group] = False
+    return _native[group] or None
+
+
+def destroy_native_comms():
+    for comm in _native.values():
+        if comm:
+            comm.destroy()
+    _native.clear()
+
+
 def reduce_rows(rows, group=None):
     """Sum the per-rank partial rows in place (all ranks get the totals).  One collective."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        all_reduce(rows, dist.ReduceOp.SUM, group)
+        comm = native_comm(group) if rows.is_cuda and rows.dtype == torch.float64 and rows.is_contiguous() else None
+        if comm is not None:
+            comm.all_reduce_sum(rows)
+        else:
+            all_reduce(rows, dist.ReduceOp.SUM, group)
     return rows
 
 

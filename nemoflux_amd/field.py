@@ -130,7 +130,7 @@ class Field(object):
         """Same positional signature as the reference (field.py:17).  tFile/uFile/vFile: NetCDF-4 files (read by
         nemoflux_amd.io / hdf5min; compressed uo/vo one time step at a time) or the .npz bundles of
         nemoflux_amd.datagen / subsetnemo; see fromArrays for in-memory / HBM data and _setup for the keywords
-        (fill_value, periodX, slab_range, readback, compact, stream, ...)."""
+        (fill_value, periodX, slab_range, readback, compact, stream, unsupportedCells, ...)."""
         t = open_tfile(tFile)
         if 'deptht_bounds' not in t:
             raise RuntimeError(f'ERROR: {tFile} has no variable deptht_bounds')
@@ -152,7 +152,8 @@ class Field(object):
     # ------------------------------------------------------------------------------------------
     def _setup(self, bounds_lon, bounds_lat, deptht_bounds, uo, vo, lonLatZPoints, sverdrup,
                fill_value=numpy.nan, periodX=360., numCellsPerBucket=128, slab_range=None, readback=True,
-               timeValues=None, stream=None, timeObj=None, compact=False, prefetch=True, gpu_decode=True):
+               timeValues=None, stream=None, timeObj=None, compact=False, prefetch=True, gpu_decode=True,
+               unsupportedCells='refuse'):
         _lib.require_gpu()
         self.sverdrup = sverdrup
         self.periodX = periodX
@@ -241,6 +242,10 @@ class Field(object):
             tid = ctypes.c_int()
             check(lib.nf_field_add_transect(ctypes.byref(self._h), _lib.dptr(xyz), xyz.shape[0], 0, ctypes.byref(tid)))
             self.plis.append(_Transect(self, i, xyz))
+        if unsupportedCells not in ('refuse', 'skip'):
+            raise RuntimeError("ERROR: unsupportedCells must be 'refuse' or 'skip'")
+        if unsupportedCells == 'skip':   # non-convex / pole-vertex cells drop out; the coverage warning below reports it
+            check(lib.nf_field_set_unsupported_cells(ctypes.byref(self._h), 1))
         check(lib.nf_field_build_weights(ctypes.byref(self._h), int(numCellsPerBucket), float(periodX)))
         n = ctypes.c_int()
         check(lib.nf_field_num_segments(ctypes.byref(self._h), ctypes.byref(n)))
@@ -490,3 +495,9 @@ class Field(object):
         a, b = ctypes.c_double(), ctypes.c_double()
         check(lib.nf_field_timing_split(ctypes.byref(self._h), ctypes.byref(a), ctypes.byref(b)))
         return n.value, ms.value, a.value, b.value
+
+    def readTransectTiming(self):
+        """ms spent in the transect reductions behind the launches of the last readKernelTiming"""
+        k3 = ctypes.c_double()
+        check(lib.nf_field_timing_k3(ctypes.byref(self._h), ctypes.byref(k3)))
+        return k3.value

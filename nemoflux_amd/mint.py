@@ -115,6 +115,14 @@ class PolylineIntegral(object):
         return res.value
 
     # ---- extensions beyond mint
+    def setUnsupportedCells(self, policy='refuse'):
+        """What computeWeights does when the line overlaps a cell the weights are not defined on (not convex in the lon-lat
+        plane / a corner at a geographic pole): 'refuse' (default) raises, 'skip' drops the cell -- getCoverage() then
+        reports < 1 for the segments concerned."""
+        if policy not in ('refuse', 'skip'):
+            raise RuntimeError("ERROR: policy must be 'refuse' or 'skip'")
+        check(lib.mnt_polylineintegral_setUnsupportedCells(ctypes.byref(self.obj), 1 if policy == 'skip' else 0))
+
     def getCoverage(self):
         """Fraction of every target segment that lies inside cells of the grid (1 = inside, each point counted once)."""
         cov = numpy.zeros(max(self.numSegments, 1), numpy.float64)

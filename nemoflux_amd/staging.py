@@ -39,7 +39,10 @@ class StepStager(object):
         self.group = 1
         if gpu_decode and os.environ.get('NF_GPU_INFLATE', '1') != '0':
             from .ingest import ChunkDecoder
-            need = [ChunkDecoder.staging_bytes(s, nt) if hasattr(s, 'device_plan') else None for s in self.src]
+            # A variable takes the device path only when its chunks decode to exactly what the slab holds: elements of the
+            # stager's dtype (uo's; a vo of another type is converted on the host path, like the reference's numpy would)
+            # and slabs of (nz, ny, nx) -- the decoder writes elem_size bytes per element at element offsets of the slab
+            need = [ChunkDecoder.staging_bytes(s, nt) if self._device_ok(s) else None for s in self.src]
             if any(n is not None for n in need):
                 self.decoder = ChunkDecoder()
                 self.comp_bytes = need
@@ -55,6 +58,15 @@ class StepStager(object):
         self._pending = None
         self._pending_slot = -1
         self._pool = None
+
+    def _device_ok(self, src):
+        if not hasattr(src, 'device_plan') or numpy.dtype(getattr(src, 'dtype', None)) != self.dtype:
+            return False
+        if tuple(getattr(src, 'shape', ())) != (self.nt, self.nz, self.ny, self.nx):
+            return False
+        plan = src.device_plan(0)
+        return (plan is not None and plan['elem_size'] == self.dtype.itemsize and
+                tuple(plan['slab_dims']) == (self.nz, self.ny, self.nx))
 
     # ------------------------------------------------------------------------------------------ buffers (caller's thread)
     def _alloc(self, slot):

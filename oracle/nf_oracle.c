@@ -317,7 +317,8 @@ static int rec_cmp(const void *a, const void *b)
  */
 long nfo_polyline_weights(const double *points, long ncell, const double *xyz, int npts, double periodX,
                           int counterclock, long cap, int64_t *cell_edge, double *weight, int *seg, long *status,
-                          double *coverage /* npts-1 values or NULL: sum of coef*(tb-ta) per segment */)
+                          double *coverage /* npts-1 values or NULL: sum of coef*(tb-ta) per segment */,
+                          int skip_unsupported /* 1: non-convex cells contribute nothing instead of being an error */)
 {
     long nrec = 0, rcap = 1024;
     long err = 0, err_cell = -1, err_seg = -1;
@@ -348,7 +349,7 @@ long nfo_polyline_weights(const double *points, long ncell, const double *xyz, i
                 if (cxmin > sxmax + slack || cxmax < sxmin - slack || cymin > symax + slack || cymax < symin - slack)
                     continue;
                 if (quad_is_nonconvex(v)) {
-                    if (segment_overlaps_quad(v, qx, qy, dx, dy) && (err_cell < 0 || c < err_cell)) {
+                    if (!skip_unsupported && segment_overlaps_quad(v, qx, qy, dx, dy) && (err_cell < 0 || c < err_cell)) {
                         err = 1; err_cell = c; err_seg = s;
                     }
                     continue;

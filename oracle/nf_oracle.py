@@ -47,7 +47,7 @@ def lib():
         L.nfo_edge_flux.argtypes = [dp, dp, dp, ctypes.c_long, ctypes.c_long, ctypes.c_int, dp, dp, dp, dp]
         L.nfo_polyline_weights.argtypes = [dp, ctypes.c_long, dp, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                            ctypes.c_long, ctypes.POINTER(ctypes.c_int64), dp,
-                                           ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_long), dp]
+                                           ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_long), dp, ctypes.c_int]
         L.nfo_polyline_weights.restype = ctypes.c_long
         L.nfo_get_integral.argtypes = [dp, ctypes.c_long, ctypes.POINTER(ctypes.c_int64), dp,
                                        ctypes.POINTER(ctypes.c_int), ctypes.c_int, dp]
@@ -144,9 +144,9 @@ class UnsupportedCell(ValueError):
         super().__init__(f'target segment {seg} {what} {cell}')
 
 
-def polyline_weights(points, xyz, periodX=360., counterclock=False):
+def polyline_weights(points, xyz, periodX=360., counterclock=False, skip_unsupported=False):
     """A6 mint.PolylineIntegral.computeWeights (field.py:45-48).  Raises UnsupportedCell instead of returning numbers
-    for a line that crosses a non-convex cell."""
+    for a line that crosses a non-convex cell; skip_unsupported=True drops such cells instead (coverage < 1)."""
     pts = _c64(points)
     ncell = pts.shape[0]
     xyz = _c64(xyz).reshape(-1, 3)
@@ -159,7 +159,8 @@ def polyline_weights(points, xyz, periodX=360., counterclock=False):
         cov = numpy.zeros(max(xyz.shape[0] - 1, 1), numpy.float64)
         n = lib().nfo_polyline_weights(_dp(pts), ncell, _dp(xyz), xyz.shape[0], float(periodX), int(counterclock),
                                        cap, ce.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _dp(w),
-                                       sg.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), status, _dp(cov))
+                                       sg.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), status, _dp(cov),
+                                       1 if skip_unsupported else 0)
         if status[0]:
             raise UnsupportedCell(status[0], status[1], status[2])
         if n >= 0:

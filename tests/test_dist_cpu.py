@@ -104,3 +104,13 @@ def test_bench_transects_are_seeded_and_clear_of_column_zero():
         assert numpy.abs(xy[:, 1]).max() <= 80. + 1e-9
         assert numpy.allclose(numpy.round((xy[:, 0] + 180.) / dx) * dx - 180., xy[:, 0], atol=1e-9)   # on nodes
         assert (poly[0] == poly[-1]) == (k % 2 == 1)                                              # half are closed
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """--gpus N with fewer than N devices visible (and no rehearsal hook) exits non-zero with a message -- it never runs a
+    smaller job under the larger name."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('NF_FORCE_DEVICE', 'WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '64', '--steps', '1'], env=env,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 2 and 'GPU(s) visible' in r.stderr and not r.stdout.strip()

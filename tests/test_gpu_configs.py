@@ -952,6 +952,35 @@ def test_refuses_nonconvex_and_pole_cells(oracle):
     dg = device_case(72, 36, 2, 1, PSI_ZT, (20., 30.))
     with pytest.raises(RuntimeError, match='not convex'):                 # the Field surface raises like the reference
         quiet_field(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, [near_pole])
+    # pinned: round 1's golden transect of rot36_zt (README.md:79's triangle, apex at 80N, 36x18 rotated grid) is refused
+    # with this message; under the 'skip' policy the pole cell drops out, entry by entry like the oracle, coverage < 1
+    from test_oracle_golden import OLD_ROT36_TRIANGLE
+    o36 = oracle.DataGen(36, 18, 1, 1)
+    o36.rotatePole((20., 30.))
+    p36 = oracle.assemble_points(o36.bounds_lon, o36.bounds_lat)
+    with pytest.raises(oracle.UnsupportedCell) as ei:
+        oracle.polyline_weights(p36, OLD_ROT36_TRIANGLE)
+    pl = pli_for(p36, 360.)
+    with pytest.raises(NemofluxError, match=rf'crosses cell {ei.value.cell}, which is not convex in the \(lon,lat\) plane'):
+        pl.computeWeights(OLD_ROT36_TRIANGLE)
+    pl.setUnsupportedCells('skip')
+    pl.computeWeights(OLD_ROT36_TRIANGLE)
+    want = oracle.polyline_weights(p36, OLD_ROT36_TRIANGLE, skip_unsupported=True)
+    ce, w, sg = pl.getWeights()
+    got = {}
+    for a, b, c in zip(ce.tolist(), w.tolist(), sg.tolist()):
+        got[(c, a)] = got.get((c, a), 0.0) + b
+    ref = want.as_dict()
+    assert set(got) == set(ref) and max(abs(got[k] - ref[k]) for k in ref) <= 1e-13
+    assert numpy.allclose(pl.getCoverage(), want.coverage, rtol=0, atol=1e-12) and want.coverage.min() < 1 - 1e-3
+    dg36 = device_case(36, 18, 2, 1, PSI_ZT, (20., 30.))
+    with pytest.raises(RuntimeError, match='not convex'):
+        quiet_field(dg36.bounds_lon, dg36.bounds_lat, dg36.deptht_bounds, dg36.u, dg36.v, [OLD_ROT36_TRIANGLE])
+    from nemoflux_amd.field import Field
+    with pytest.warns(RuntimeWarning, match='not fully inside the grid'):
+        f = Field.fromArrays(dg36.bounds_lon, dg36.bounds_lat, dg36.deptht_bounds, dg36.u, dg36.v, [OLD_ROT36_TRIANGLE],
+                             unsupportedCells='skip')
+    assert f.getCoverage()[0].min() < 1 - 1e-3
     # the closed loop that used to return 0.97 on this grid class through such a cell (rot36: apex at 80 N) is refused too
     g = load_golden('rot36_zt')
     with pytest.raises(RuntimeError, match='not convex'):

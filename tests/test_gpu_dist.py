@@ -144,10 +144,11 @@ def test_plain_c_client_of_the_abi(tmp_path):
     assert 'ingest: decoded 1.0 (status 0)' in r.stdout
 
 
-def _bench_json(extra, nproc=1):
-    """Run bench.py on a small grid -- directly (N=1) or under torch.distributed.run with `nproc` ranks that all use
-    GPU 0 and reduce over gloo (NF_FORCE_DEVICE / NF_DIST_BACKEND: the rehearsal hook of nemoflux_amd.dist) -- exactly
-    the way the driver launches it; returns the parsed JSON line."""
+def _bench_json(extra, nproc=1, launcher='torchrun'):
+    """Run bench.py on a small grid -- directly (N=1), under torch.distributed.run with `nproc` ranks (the driver's N>1
+    command), or as plain `python bench.py --gpus N` (launcher='self': bench.py starts its own ranks); with N>1 all ranks
+    use GPU 0 and reduce over gloo (NF_FORCE_DEVICE / NF_DIST_BACKEND: the rehearsal hook of nemoflux_amd.dist).
+    Returns the parsed JSON line."""
     import json
     import subprocess
     small = ['--nx', '144', '--ny', '72', '--nz', '9', '--batch', '6', '--steps', '2', '--warmup', '1', '--no-cpu',
@@ -160,9 +161,13 @@ def _bench_json(extra, nproc=1):
             s.bind(('127.0.0.1', 0))
             port = s.getsockname()[1]
         env.update(NF_FORCE_DEVICE='0', NF_DIST_BACKEND='gloo')
-        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
-               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
-               '--gpus', str(nproc)] + small
+        env.pop('WORLD_SIZE', None)
+        if launcher == 'self':
+            cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(nproc)] + small
+        else:
+            cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
+                   '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+                   '--gpus', str(nproc)] + small
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -194,3 +199,59 @@ def test_bench_two_ranks_rehearsal(scaling):
     assert abs(two['value'] - units * 2 / (two['ms_per_step'] * 2e-3)) <= 1e-6 * two['value']
     r = two['roofline']            # rank 0's kernel: half of the slabs
     assert r['frac'] > 0 and r['launches'] >= 2
+    _check_rank_records(two, 2, nt_global * 9)
+
+
+def _check_rank_records(line, world, slabs):
+    """one record per rank: the slab ranges tile [0, slabs), every rank timed its own kernels"""
+    recs = line['ranks']
+    assert [r['rank'] for r in recs] == list(range(world)) and line['reduce']['world_size'] == world
+    assert recs[0]['slabs'][0] == 0 and recs[-1]['slabs'][1] == slabs
+    for a, b in zip(recs[:-1], recs[1:]):
+        assert a['slabs'][1] == b['slabs'][0]
+    for r in recs:
+        t0, t1 = r['steps_touched']
+        assert r['device_name'] and t1 > t0 and r['launches_per_pass'] >= 1
+        assert r['k_flux_ms'] > 0 and r['k3_ms'] > 0
+
+
+def test_bench_starts_its_own_ranks():
+    """plain `python bench.py --gpus 2` (no torchrun): the parent -- which makes no GPU call -- starts two ranks as a fresh
+    child torch.distributed.run, relays rank 0's line and exits with the child's code.  Totals equal N=1 to 1e-13."""
+    nt = 4
+    two = _bench_json(['--nt', str(nt)], nproc=2, launcher='self')
+    one = _bench_json(['--nt', str(nt)])
+    assert two['n_gpus'] == 2 and two['scaling'] == 'strong' and one['n_gpus'] == 1
+    a, b = numpy.array(two['totals']), numpy.array(one['totals'])
+    assert a.shape == b.shape == (nt, 7)
+    assert numpy.abs(a - b).max() <= 1e-13 * numpy.abs(b).max()
+    _check_rank_records(two, 2, nt * 9)
+    assert two['reduce']['backend'] == 'gloo' and two['reduce']['path'] == 'torch.distributed.all_reduce'
+    assert 'ranks' not in one
+
+
+def test_native_rccl_reduce_on_one_rank():
+    """nf_rccl_unique_id / nf_rccl_comm_init / nf_rows_allreduce / nf_rccl_comm_info / nf_rccl_comm_destroy of the C ABI on
+    a one-rank communicator (all this box can run of RCCL), through the same librccl the process already holds."""
+    import ctypes
+    import torch
+    from nemoflux_amd._lib import lib, check
+    ident = ctypes.create_string_buffer(128)
+    check(lib.nf_rccl_unique_id(ident))
+    comm = ctypes.c_void_p()
+    check(lib.nf_rccl_comm_init(ctypes.byref(comm), 1, ident, 0))
+    n, r, d = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+    check(lib.nf_rccl_comm_info(comm, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d)))
+    assert (n.value, r.value, d.value) == (1, 0, torch.cuda.current_device())
+    rows = torch.arange(24., dtype=torch.float64, device='cuda').reshape(3, 8)
+    want = rows.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        check(lib.nf_rows_allreduce(comm, ctypes.c_void_p(rows.data_ptr()), rows.numel(), ctypes.c_void_p(s.cuda_stream)))
+    s.synchronize()
+    assert torch.equal(rows, want)
+    path = ctypes.create_string_buffer(512)
+    check(lib.nf_rccl_library(path, 512))
+    assert b'librccl' in path.value
+    assert lib.nf_rows_allreduce(None, ctypes.c_void_p(rows.data_ptr()), 4, None) != 0     # null communicator: an error
+    check(lib.nf_rccl_comm_destroy(comm))

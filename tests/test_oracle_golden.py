@@ -309,6 +309,9 @@ def dart_grid():
     return o_pts, good
 
 
+OLD_ROT36_TRIANGLE = numpy.array([(-100., -80., 0.), (100., -80., 0.), (0., 80., 0.), (-100., -80., 0.)])
+
+
 def test_oracle_refuses_nonconvex_and_pole_cells(oracle):
     """SURVEY 7 "hard parts": cells whose (lon,lat) image is not a convex quad.  mint's behaviour there is pinned by
     nothing in the reference, so the restatement never returns a number for a line that overlaps such a cell: it raises;
@@ -360,6 +363,22 @@ def test_oracle_refuses_nonconvex_and_pole_cells(oracle):
     p0 = oracle.assemble_points(o0.bounds_lon, o0.bounds_lat)
     w = oracle.polyline_weights(p0, numpy.array([(-100., 85., 0.), (100., 88., 0.)]))
     assert numpy.allclose(w.coverage, 1.0, rtol=0, atol=1e-12)
+    # pinned: round 1's golden transect of case rot36_zt -- the README closed triangle (README.md:79) with its apex at 80N
+    # on the 36x18 rotated grid -- clips the (lon,lat) image of a pole cell and used to return 0.97 instead of 0: refused,
+    # with the cell named; the 'skip' policy drops the cell and says so through the coverage
+    o36 = oracle.DataGen(36, 18, 1, 1)
+    o36.rotatePole((20., 30.))
+    p36 = oracle.assemble_points(o36.bounds_lon, o36.bounds_lat)
+    pole36 = set(numpy.nonzero((numpy.abs(p36[:, :, 1]) >= 90 - 1e-9).any(axis=1))[0].tolist())
+    with pytest.raises(oracle.UnsupportedCell, match='overlaps non-convex cell') as ei:
+        oracle.polyline_weights(p36, OLD_ROT36_TRIANGLE)
+    assert ei.value.cell in pole36 and ei.value.kind == 1
+    w = oracle.polyline_weights(p36, OLD_ROT36_TRIANGLE, skip_unsupported=True)
+    assert w.coverage.min() < 1.0 - 1e-3 and w.coverage.max() <= 1.0 + 1e-12
+    assert not (set((w.cell_edge // 4).tolist()) & pole36)
+    # ... and changes nothing for a line that is clear of such cells
+    clear = numpy.array([(-100., -50., 0.), (100., -50., 0.), (0., 50., 0.), (-100., -50., 0.)])
+    assert oracle.polyline_weights(p36, clear, skip_unsupported=True).as_dict() == oracle.polyline_weights(p36, clear).as_dict()
     # partly outside a regional grid: coverage < 1 tells how much of the segment was found (mint only warns [recall])
     reg = oracle.assemble_points(numpy.ascontiguousarray(o0.bounds_lon[:, :12]), numpy.ascontiguousarray(o0.bounds_lat[:, :12]))
     w = oracle.polyline_weights(reg, numpy.array([(-120., 0., 0.), (0., 0., 0.)]), periodX=0.)
