@@ -156,6 +156,9 @@ int nf_field_set_thickness(nf_field **self, const double *thickness, long nz);
  * 0 (field.py:157); pass NaN for "no _FillValue". */
 int nf_field_set_uv(nf_field **self, const void *u, const void *v, long nt, int dtype, int on_device,
                     double fill_value);
+/* A second value that counts as missing -> 0: the CF attribute missing_value when it differs from _FillValue (xarray's
+ * decode_cf, which the reference relies on at field.py:34-35, masks both).  Compared in the fields' dtype; NaN = none. */
+int nf_field_set_missing_value(nf_field **self, double missing_value);
 /* field.py:19,225-228: scale fluxes by 6371000/1e6 */
 int nf_field_set_sverdrup(nf_field **self, int sverdrup);
 /* Compact resident mode (default off).  The reference stores, per time step, the (ncell,4) array whose slots 0 and 3

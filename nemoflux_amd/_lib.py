@@ -91,6 +91,7 @@ _sig('nf_field_set_bounds', [_pp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_lon
 _sig('nf_field_set_thickness', [_pp, c_double_p, ctypes.c_long])
 _sig('nf_field_set_uv', [_pp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                          ctypes.c_double])
+_sig('nf_field_set_missing_value', [_pp, ctypes.c_double])
 _sig('nf_field_set_sverdrup', [_pp, ctypes.c_int])
 _sig('nf_field_set_compact', [_pp, ctypes.c_int])
 _sig('nf_field_set_slab_range', [_pp, ctypes.c_long, ctypes.c_long])

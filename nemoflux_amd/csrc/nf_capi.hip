@@ -635,6 +635,7 @@ struct nf_field {
     const void *u = nullptr, *v = nullptr;
     int uv_dtype = NF_F64, uv_on_device = 1;
     double fill = std::numeric_limits<double>::quiet_NaN();
+    double fill2 = std::numeric_limits<double>::quiet_NaN();   // nf_field_set_missing_value
     void *d_stage_u = nullptr, *d_stage_v = nullptr;
     int sverdrup = 0;
     long s_begin = 0, s_end = -1;
@@ -830,6 +831,7 @@ static int field_step_async(nf_field *f, long t, double *row_dev)
     a.arcE = f->d_arcE;
     a.arcN = f->d_arcN;
     a.fill = f->fill;
+    a.fill2 = f->fill2;
     a.scale = kEarthRadiusSv / 1.e6;  // field.py:226
     a.sverdrup = f->sverdrup;
     a.iV = f->d_iV;
@@ -933,6 +935,7 @@ static int field_all_steps_batched(nf_field *f, double *rows_dev)
     a.arcE = f->d_arcE;
     a.arcN = f->d_arcN;
     a.fill = f->fill;
+    a.fill2 = f->fill2;
     a.scale = kEarthRadiusSv / 1.e6;
     a.sverdrup = f->sverdrup;
     a.iV = f->d_iVb;
@@ -1084,6 +1087,15 @@ try {
     f->uv_on_device = on_device;
     f->fill = fill_value;
     ++f->version;
+    return NF_OK;
+}
+NF_API_CATCH
+
+int nf_field_set_missing_value(nf_field **self, double missing_value)
+try {
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_missing_value: null field");
+    (*self)->fill2 = missing_value;
+    ++(*self)->version;
     return NF_OK;
 }
 NF_API_CATCH

@@ -100,6 +100,7 @@ struct FluxArgs {
     const double *thickness;  // device, nz
     const double *arcE, *arcN;
     double fill;              // NaN = none
+    double fill2 = __builtin_nan("");   // a second missing marker (CF missing_value that differs from _FillValue); NaN = none
     double scale;             // 1 or 6371000/1e6
     int sverdrup;
     double *iV, *absU, *absV; // resident outputs

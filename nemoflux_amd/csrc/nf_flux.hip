@@ -60,6 +60,14 @@ __device__ inline double fixed(T x, T fill)
     return (x != x || x == fill) ? 0.0 : (double)x;
 }
 
+// ... or to the variable's missing_value when the file carries one that differs from _FillValue (xarray's decode_cf, which
+// the reference relies on at field.py:34-35, masks both)
+template <typename T>
+__device__ inline double fixed2(T x, T fill, T fill2)
+{
+    return (x != x || x == fill || x == fill2) ? 0.0 : (double)x;
+}
+
 template <bool NTS = false>
 __device__ inline void store1(double *p, double a)
 {
@@ -137,6 +145,7 @@ __device__ inline void store_cells(long c0, const double *eU, const double *eV, 
 // (-DNF_TUNING_BUILD, `make tuning`, tools/ab_flux.py) and are compiled out of the shipped .so.
 constexpr int kFormSignedOnly = 16;    // store only planes 1 (eU) and 2 (eV): split step and compact resident mode
 constexpr int kFormNestedLoads = 128;  // per-level nested load loop instead of the flat one
+constexpr int kFormTwoFills = 256;     // a second value counts as missing (missing_value != _FillValue)
 #ifdef NF_TUNING_BUILD
 constexpr int kDiagNoStores = 1, kDiagNoFix = 2, kDiagNoMax = 4, kDiagNoArc = 8, kDiagInterleaved = 32, kDiagPlainStores = 64;
 #else
@@ -152,10 +161,10 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
                                                 const double *__restrict__ arcE, const double *__restrict__ arcN,
                                                 T fill, double scale, int sverdrup, double *__restrict__ iV,
                                                 double *__restrict__ absUV, unsigned long long *maxbits,
-                                                unsigned ntiles, int xcd_map, StepBatch sb)
+                                                unsigned ntiles, int xcd_map, StepBatch sb, T fill2)
 {
 #ifndef NF_TUNING_BUILD
-    static_assert((FORM & ~(kFormSignedOnly | kFormNestedLoads)) == 0, "diagnostic forms exist only in tuning builds");
+    static_assert((FORM & ~(kFormSignedOnly | kFormNestedLoads | kFormTwoFills)) == 0, "diagnostic forms exist only in tuning builds");
 #endif
     const unsigned tile = xcd_map ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
     if (sb.zr) {  // several time steps in one launch (small grids are launch-bound): blockIdx.y is the step
@@ -221,8 +230,13 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
                         if (on[q]) {
 #pragma unroll
                             for (int k = 0; k < VEC; ++k) {
-                                accU[q][k] = fma(th, (FORM & kDiagNoFix) ? (double)lu[r][q].x[k] : fixed<T>(lu[r][q].x[k], fill), accU[q][k]);
-                                accV[q][k] = fma(th, (FORM & kDiagNoFix) ? (double)lv[r][q].x[k] : fixed<T>(lv[r][q].x[k], fill), accV[q][k]);
+                                if (FORM & kFormTwoFills) {
+                                    accU[q][k] = fma(th, fixed2<T>(lu[r][q].x[k], fill, fill2), accU[q][k]);
+                                    accV[q][k] = fma(th, fixed2<T>(lv[r][q].x[k], fill, fill2), accV[q][k]);
+                                } else {
+                                    accU[q][k] = fma(th, (FORM & kDiagNoFix) ? (double)lu[r][q].x[k] : fixed<T>(lu[r][q].x[k], fill), accU[q][k]);
+                                    accV[q][k] = fma(th, (FORM & kDiagNoFix) ? (double)lv[r][q].x[k] : fixed<T>(lv[r][q].x[k], fill), accV[q][k]);
+                                }
                             }
                         }
                 }
@@ -362,7 +376,7 @@ static int launch_flux_t(const FluxArgs &a, hipStream_t s)
     hipLaunchKernelGGL((k_flux<T, VEC, UZ, NT, BLOCK, CH, FORM>), dim3(grid, (unsigned)(a.batch.zr ? a.batch.nsteps : 1)),
                        dim3(BLOCK), 0, s, (const T *)a.u, (const T *)a.v, a.ncell, (unsigned)a.ny, (unsigned)a.nx, a.z0,
                        a.z1, a.thickness, a.arcE, a.arcN, (T)a.fill, a.scale, a.sverdrup, a.iV, a.absU, a.maxbits, ntiles,
-                       xcd_map, a.batch);
+                       xcd_map, a.batch, (T)a.fill2);
     NF_HIP(hipGetLastError());
     return NF_OK;
 }
@@ -374,11 +388,28 @@ template <typename T, int VEC>
 static int launch_flux_v(const FluxArgs &a, hipStream_t s)
 {
     const int variant = a.batch.zr ? 0 : g_variant;  // the multi-step launch exists for the default kernel only
+    // a second missing value (compared in the file's dtype, like the first): the default kernels with one more compare
+    const bool two = (T)a.fill2 == (T)a.fill2 && !((T)a.fill2 == (T)a.fill);
     if (a.signed_only) {  // compact resident mode: the caller expands on demand
         NF_REQUIRE(VEC > 1 && !a.batch.zr, NF_ERR_STATE, "flux: the compact mode needs 16-byte aligned fields, an even cell count and one step per launch");
+        if (two) return launch_flux_t<T, VEC, (sizeof(T) == 8 ? 10 : 8), true, 256, 1, kFormSignedOnly | kFormTwoFills>(a, s);
         return launch_flux_t<T, VEC, (sizeof(T) == 8 ? 10 : 8), true, 256, 1, kFormSignedOnly>(a, s);   // same batches as the defaults
     }
-    if (VEC == 1) return launch_flux_t<T, VEC, 8, true, 256, 1>(a, s);  // odd cell counts / unaligned fields: one cell per lane
+    if (VEC == 1) {   // odd cell counts / unaligned fields: one cell per lane
+        if (two) return launch_flux_t<T, VEC, 8, true, 256, 1, kFormTwoFills>(a, s);
+        return launch_flux_t<T, VEC, 8, true, 256, 1>(a, s);
+    }
+    if (two) {
+        constexpr int kLevels = sizeof(T) == 8 ? 10 : 8;
+        if (a.batch.zr || sizeof(T) == 8) return launch_flux_t<T, VEC, kLevels, true, 256, 1, kFormTwoFills>(a, s);
+        const int rc = launch_flux_t<T, VEC, kLevels, true, 256, 1, kFormSignedOnly | kFormTwoFills>(a, s);
+        if (rc != NF_OK) return rc;
+        if (a.mid_event) {
+            NF_HIP(hipEventRecord(a.mid_event, s));
+            if (a.mid_recorded) *a.mid_recorded = true;
+        }
+        return launch_expand_planes(a.iV, a.absU, a.ncell, a.ny, a.nx, s);
+    }
     switch (variant) {
         // measured alternatives (tools/ab_flux.py): all within +-3 % of the default
         case 3: return launch_flux_t<T, VEC, 4, true, 256, 1>(a, s);    // 4 levels in flight (+2..3 %)

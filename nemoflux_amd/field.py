@@ -134,12 +134,23 @@ class Field(object):
         t = open_tfile(tFile)
         if 'deptht_bounds' not in t:
             raise RuntimeError(f'ERROR: {tFile} has no variable deptht_bounds')
-        uo, fu, uvars = open_uvfile(uFile, 'uo', with_all=True)
-        vo, fv = open_uvfile(vFile, 'vo')
-        fill = kw.pop('fill_value', fu if not numpy.isnan(fu) else fv)
+        uo, _, uvars = open_uvfile(uFile, 'uo', with_all=True)
+        vo, _, vvars = open_uvfile(vFile, 'vo', with_all=True)
+        # values that mean 'missing' (xarray's decode_cf masks _FillValue and missing_value, field.py:34-35, 157): the engine
+        # compares every value of uo and vo with up to two markers
+        markers = list(uvars['_markers_uo'])
+        for m in vvars['_markers_vo']:
+            if m not in markers:
+                markers.append(m)
+        if 'fill_value' in kw:
+            markers = [float(kw.pop('fill_value'))] + [m for m in markers[1:2]]
+        if len(markers) > 2:
+            raise RuntimeError(f'ERROR: uo / vo carry {len(markers)} different _FillValue / missing_value markers '
+                               f'({markers}); the engine masks at most two')
         kw.setdefault('timeObj', TimeObj.fromVariables(uvars))   # field.py:38: TimeObj(self.ncU)
         self._setup(t['bounds_lon'], t['bounds_lat'], t['deptht_bounds'], uo, vo, lonLatZPoints, sverdrup,
-                    fill_value=fill, **kw)
+                    fill_value=markers[0] if markers else numpy.nan,
+                    missing_value=markers[1] if len(markers) > 1 else numpy.nan, **kw)
 
     @classmethod
     def fromArrays(cls, bounds_lon, bounds_lat, deptht_bounds, uo, vo, lonLatZPoints, sverdrup=False, **kw):
@@ -151,7 +162,8 @@ class Field(object):
 
     # ------------------------------------------------------------------------------------------
     def _setup(self, bounds_lon, bounds_lat, deptht_bounds, uo, vo, lonLatZPoints, sverdrup,
-               fill_value=numpy.nan, periodX=360., numCellsPerBucket=128, slab_range=None, readback=True,
+               fill_value=numpy.nan, missing_value=numpy.nan, periodX=360., numCellsPerBucket=128, slab_range=None,
+               readback=True,
                timeValues=None, stream=None, timeObj=None, compact=False, prefetch=True, gpu_decode=True,
                unsupportedCells='refuse'):
         _lib.require_gpu()
@@ -219,6 +231,8 @@ class Field(object):
             uv_dev = 1
         if self._lazy is None:
             check(lib.nf_field_set_uv(ctypes.byref(self._h), pu, pv, self.nt, _dtype_code(uo), uv_dev, float(fill_value)))
+        if missing_value == missing_value:   # a second marker (CF missing_value that differs from _FillValue)
+            check(lib.nf_field_set_missing_value(ctypes.byref(self._h), float(missing_value)))
         check(lib.nf_field_set_sverdrup(ctypes.byref(self._h), 1 if sverdrup else 0))
         if compact:   # keep only (eU, eV) resident; the (ncell,4) copies and |.| arrays are derived at read-back
             check(lib.nf_field_set_compact(ctypes.byref(self._h), 1))

@@ -17,6 +17,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import warnings
 
 import numpy
 
@@ -52,6 +53,102 @@ def _convert_with_h5py(path):
     return None
 
 
+# ---------------------------------------------------------------------------------------------- CF decoding
+# xarray.open_dataset (field.py:22-25, 34-35) decodes CF conventions by default (decode_cf / mask_and_scale): values equal to
+# _FillValue OR missing_value become NaN (both, when both are given), then packed data are unpacked as
+# raw * scale_factor + add_offset in a float type.  The attributes travel with the variables as '_<attr>_<name>' entries.
+CF_ATTRS = ('_FillValue', 'missing_value', 'scale_factor', 'add_offset')
+
+
+def _keep_cf(out, name, attrs):
+    for k in CF_ATTRS:
+        v = attrs.get(k)
+        if v is None:
+            continue
+        v = numpy.asarray(v)
+        if v.dtype.kind not in 'fiu' or v.size == 0:
+            continue
+        key = '_FillValue_' + name if k == '_FillValue' else f'_{k}_{name}'
+        out[key] = v.reshape(-1) if (k == 'missing_value' and v.size > 1) else v.reshape(-1)[0]
+
+
+def cf_markers(d, name):
+    """Raw values of `name` that mean 'missing' (the variable's _FillValue and missing_value entries, duplicates merged)."""
+    vals = []
+    for key in ('_FillValue_' + name, '_missing_value_' + name):
+        if key in d:
+            for x in numpy.asarray(d[key]).reshape(-1):
+                if not any(x == y or (x != x and y != y) for y in vals):
+                    vals.append(x)
+    return vals
+
+
+def cf_float_dtype(raw_dtype, has_offset):
+    """The float type xarray decodes into [recall of xarray.coding.variables._choose_float_dtype; xarray is not installed,
+    parity unpinned]: float32 stays; integers of <= 16 bits without add_offset -> float32 (a scale factor vanishes into the
+    mantissa, a large offset may not); everything else float64."""
+    raw_dtype = numpy.dtype(raw_dtype)
+    if raw_dtype.kind == 'f':
+        return numpy.dtype(numpy.float32) if raw_dtype.itemsize <= 4 else numpy.dtype(numpy.float64)
+    if raw_dtype.itemsize <= 2 and not has_offset:
+        return numpy.dtype(numpy.float32)
+    return numpy.dtype(numpy.float64)
+
+
+def cf_is_packed(d, name, dtype):
+    return numpy.dtype(dtype).kind in 'iu' or ('_scale_factor_' + name) in d or ('_add_offset_' + name) in d
+
+
+def cf_decode_array(raw, markers, scale, offset, out_dtype, out=None):
+    """mask (in the raw dtype), then unpack: the order xarray's coders run in when decoding"""
+    raw = numpy.asarray(raw)
+    if out is None:
+        out = numpy.empty(raw.shape, out_dtype)
+    numpy.copyto(out, raw, casting='unsafe')
+    if scale is not None:
+        out *= out.dtype.type(scale)
+    if offset is not None:
+        out += out.dtype.type(offset)
+    for m in markers:
+        if m == m:
+            out[raw == numpy.asarray(m).astype(raw.dtype)] = numpy.nan
+    return out
+
+
+class CFDecodedVariable(object):
+    """uo / vo stored packed (integers, scale_factor / add_offset): decoded one time step at a time on the host, the way
+    xarray hands them to the reference -- masked values are NaN, the rest raw * scale_factor + add_offset.  Same surface as
+    hdf5min.LazyVariable (shape, dtype, read_step) minus device_plan: packed integers take the host staging path."""
+
+    def __init__(self, src, markers, scale, offset):
+        self._src, self.shape = src, tuple(src.shape)
+        self._markers, self._scale, self._offset = list(markers), scale, offset
+        self.dtype = cf_float_dtype(src.dtype, offset is not None)
+
+    def _raw_step(self, t):
+        if hasattr(self._src, 'read_step'):
+            return self._src.read_step(t)
+        return self._src[t] if len(self.shape) == 4 else self._src
+
+    def read_step(self, t, out=None):
+        return cf_decode_array(self._raw_step(t), self._markers, self._scale, self._offset, self.dtype, out)
+
+
+def _cf_apply_whole(d, name):
+    """decode a small variable (bounds_lon / bounds_lat / deptht_bounds) in full, if the file encodes it"""
+    if name not in d:
+        return
+    a = d[name]
+    markers = cf_markers(d, name)
+    if not cf_is_packed(d, name, a.dtype) and not markers:
+        return
+    if numpy.dtype(a.dtype).kind in 'iu' or cf_is_packed(d, name, a.dtype):
+        dt = cf_float_dtype(a.dtype, ('_add_offset_' + name) in d)
+    else:
+        dt = numpy.dtype(a.dtype).newbyteorder('=')
+    d[name] = cf_decode_array(a, markers, d.get('_scale_factor_' + name), d.get('_add_offset_' + name), dt)
+
+
 def _open_hdf5(path, lazy=()):
     """In-process NetCDF-4/HDF5 read; variables named in `lazy` are returned as hdf5min.LazyVariable."""
     out = {}
@@ -71,8 +168,7 @@ def _open_hdf5(path, lazy=()):
         else:
             a = ds.read()
             out[name] = a if a.dtype.isnative else a.astype(a.dtype.newbyteorder('='))
-        if ds.fill_value is not None:
-            out['_FillValue_' + name] = numpy.asarray(ds.fill_value)
+        _keep_cf(out, name, ds.attrs)
         if len(ds.shape) == 1:     # coordinate variables: keep the CF attributes (time axis labelling, timeobj.py:9-13)
             out['_attrs_' + name] = dict(ds.attrs)
     out['_hdf5_file'] = f      # keeps the mapping alive for the views
@@ -109,8 +205,7 @@ def _open_classic(path, lazy=()):
         else:
             out[name] = a if a.dtype.isnative else a.astype(a.dtype.newbyteorder('='))
         attrs = dict(var._attributes)
-        if '_FillValue' in attrs:
-            out['_FillValue_' + name] = numpy.asarray(attrs['_FillValue'])
+        _keep_cf(out, name, attrs)
         if var.data.ndim == 1:
             out['_attrs_' + name] = attrs
     out['_classic_file'] = f       # keeps the mapping alive for the views
@@ -147,9 +242,7 @@ def _open(path, lazy=()):
     with xarray.open_dataset(path, mask_and_scale=False) as nc:
         for k in nc.variables:
             out[k] = numpy.asarray(nc[k].values)
-            fv = nc[k].attrs.get('_FillValue', None)
-            if fv is not None:
-                out['_FillValue_' + k] = numpy.asarray(fv)
+            _keep_cf(out, k, dict(nc[k].attrs))
     return out
 
 
@@ -158,12 +251,25 @@ def open_tfile(path):
     for k in ('bounds_lat', 'bounds_lon'):
         if k not in d:
             raise RuntimeError(f'ERROR: {path} has no variable {k}')
+    for k in ('bounds_lat', 'bounds_lon', 'deptht_bounds'):
+        _cf_apply_whole(d, k)
     return d
 
 
 def open_uvfile(path, name, with_all=False):
+    """(variable, fill value as a float (NaN = none), [all variables of the file]).  The dict also carries
+    '_markers_<name>': every value that means 'missing' (the _FillValue first, then a missing_value that differs from it).
+    A packed variable (integers and / or scale_factor / add_offset) comes back as a CFDecodedVariable whose masked values
+    are NaN (no markers left)."""
     d = _open(path, lazy=(name,))
     if name not in d:
         raise RuntimeError(f'ERROR: could not read {name} field')  # field.py:154
-    fill = d.get('_FillValue_' + name, numpy.array(numpy.nan))
-    return (d[name], float(fill), d) if with_all else (d[name], float(fill))
+    var = d[name]
+    markers = cf_markers(d, name)
+    if cf_is_packed(d, name, var.dtype):
+        var = CFDecodedVariable(var, markers, d.get('_scale_factor_' + name), d.get('_add_offset_' + name))
+        markers = []
+    markers = [float(m) for m in markers if m == m]       # NaN is always missing (field.py:157 fillna)
+    d['_markers_' + name] = markers
+    fill = markers[0] if markers else float('nan')
+    return (var, fill, d) if with_all else (var, fill)

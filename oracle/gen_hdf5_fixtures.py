@@ -78,7 +78,50 @@ def random_file(path, seed, libver, count):
         json.dump(names, f)
 
 
+def cf_files():
+    """CF-encoded uo / vo, the decoding xarray's open_dataset does by default for the reference (field.py:34-35, decode_cf):
+    cf_U.h5  uo int16 packed with scale_factor / add_offset, _FillValue AND a different missing_value (both masked),
+             chunked + shuffled + deflated;  cf_V.h5  vo float32 with _FillValue 1e20 and missing_value -9999, whole-plane
+             deflated chunks (the device-inflate layout);  cf_V64.h5  vo float64 contiguous, missing_value only.
+    Values come from golden case def36_zt; <file>.<name>.raw.npy is what h5py reads back (undecoded)."""
+    g = numpy.load(os.path.join(OUT, '..', 'def36_zt.npz'))
+    u, v = g['u'].astype('<f8'), g['v'].astype('<f4')
+    scale, offset = numpy.float32(0.002), numpy.float32(1.5)
+    packed = numpy.clip(numpy.rint((u - float(offset)) / float(scale)), -32000, 32000).astype('<i2')
+    packed[:, :, 4:9, 10:20] = -32768          # _FillValue
+    packed[:, :, 12:14, 3:8] = -32767          # missing_value
+    with h5py.File(os.path.join(OUT, 'cf_U.h5'), 'w', libver='earliest') as f:
+        d = f.create_dataset('uo', data=packed, chunks=(1, 1, 9, 18), compression='gzip', shuffle=True)
+        d.attrs.create('_FillValue', numpy.int16(-32768))
+        d.attrs.create('missing_value', numpy.int16(-32767))
+        d.attrs.create('scale_factor', scale)
+        d.attrs.create('add_offset', offset)
+        numpy.save(os.path.join(OUT, 'cf_U.h5.uo.raw.npy'), d[...])
+    v[:, :, 4:9, 10:20] = numpy.float32(1.e20)
+    v[:, :, 12:14, 3:8] = numpy.float32(-9999.)
+    with h5py.File(os.path.join(OUT, 'cf_V.h5'), 'w', libver='earliest') as f:
+        d = f.create_dataset('vo', data=v, chunks=(1, 1, 18, 36), compression='gzip', shuffle=True)
+        d.attrs.create('_FillValue', numpy.float32(1.e20))
+        d.attrs.create('missing_value', numpy.float32(-9999.))
+        numpy.save(os.path.join(OUT, 'cf_V.h5.vo.raw.npy'), d[...])
+    v64 = g['v'].astype('<f8')
+    v64[:, :, 12:14, 3:8] = -9999.
+    v64[:, :, 4:9, 10:20] = numpy.nan
+    with h5py.File(os.path.join(OUT, 'cf_V64.h5'), 'w', libver='earliest') as f:
+        d = f.create_dataset('vo', data=v64)
+        d.attrs.create('missing_value', numpy.float64(-9999.))
+    # a float32 uo with whole-plane deflated chunks to pair with cf_V.h5 on the device path (same masks, _FillValue only)
+    u32 = g['u'].astype('<f4')
+    u32[:, :, 4:9, 10:20] = numpy.float32(1.e20)
+    with h5py.File(os.path.join(OUT, 'cf_U32.h5'), 'w', libver='earliest') as f:
+        d = f.create_dataset('uo', data=u32, chunks=(1, 1, 18, 36), compression='gzip', shuffle=True)
+        d.attrs.create('_FillValue', numpy.float32(1.e20))
+    print('wrote the cf_* files')
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == '--cf':
+        return cf_files()
     if len(sys.argv) > 2 and sys.argv[1] == '--big-extensible':
         return big_extensible(sys.argv[2])
     if len(sys.argv) > 5 and sys.argv[1] == '--random':

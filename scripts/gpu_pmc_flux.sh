@@ -3,6 +3,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+make -C nemoflux_amd/csrc tuning -j8 -s   # the diagnostic library is built here, on the GPU box: build/ never travels
 R=${1:-r02f}
 mkdir -p gpurun_out/$R
 i=0

@@ -1054,6 +1054,84 @@ def test_file_backed_field_against_the_oracle(prefetch, gpu_decode, oracle):
     assert numpy.array_equal(tot, tot2)
 
 
+@pytest.mark.parametrize('ufile, vfile', [('cf_U.h5', 'cf_V.h5'), ('cf_U32.h5', 'cf_V.h5'), ('cf_U.h5', 'cf_V64.h5')])
+def test_cf_encoded_files_against_the_oracle(ufile, vfile, oracle):
+    """CF decoding parity with xarray's defaults (field.py:22-25, 34-35, 157) through the file-backed Field: uo packed as
+    int16 with scale_factor / add_offset and both a _FillValue and a missing_value (decoded on the host staging path), vo
+    float32 with _FillValue 1e20 AND missing_value -9999 (deflated chunks, inflated on the device; the flux kernel compares
+    with both markers), vo float64 with a missing_value only -- against the CPU oracle on the DECODED values (markers ->
+    NaN -> 0): full fields bit for bit, transect totals to rounding."""
+    import contextlib
+    import io as _io
+    from nemoflux_amd import hdf5min
+    from nemoflux_amd.field import Field
+    from test_hdf5min import _cf_expected
+    h5 = os.path.join(GOLDEN, 'h5')
+    tr = [transect_xyz(T_OPEN), transect_xyz("(-180,-70),(-160,-10),(-35,40),(20,-50),(60,50),(180,40)")]
+    with contextlib.redirect_stdout(_io.StringIO()):
+        ff = Field(os.path.join(h5, 'nemo_T.h5'), os.path.join(h5, ufile), os.path.join(h5, vfile), tr)
+    with hdf5min.File(os.path.join(h5, 'nemo_T.h5')) as f:
+        blon, blat = f.datasets['bounds_lon'].read(), f.datasets['bounds_lat'].read()
+        db = f.datasets['deptht_bounds'].read()
+    with hdf5min.File(os.path.join(h5, ufile)) as f:
+        ru = numpy.array(f.datasets['uo'].read())
+    with hdf5min.File(os.path.join(h5, vfile)) as f:
+        rv = numpy.array(f.datasets['vo'].read())
+    if ufile == 'cf_U.h5':      # packed: the staging dtype is what the decode gives (float64: add_offset is present)
+        u = _cf_expected(ru, (-32768, -32767), numpy.float32(0.002), numpy.float32(1.5), numpy.float64)
+        assert ff._lazy_dtype == numpy.float64 and ff._stager.comp_bytes[0] is None
+    else:
+        u = _cf_expected(ru, (numpy.float32(1.e20),), None, None, numpy.float32)
+        assert ff._stager.comp_bytes[0] is not None and ff._stager.comp_bytes[1] is not None      # both on the device
+    v = _cf_expected(rv, (rv.dtype.type(1.e20), rv.dtype.type(-9999.)), None, None, rv.dtype.type)
+    assert numpy.isnan(u).any() and numpy.isnan(v).any() and (rv == rv.dtype.type(-9999.)).any()
+    v = v.astype(u.dtype)       # a vo of another type than uo is converted to uo's (the stager's) dtype
+    nt, nz, ny, nx = u.shape
+    pts = oracle.assemble_points(blon.astype(numpy.float64), blat.astype(numpy.float64))
+    th = (db[:, 1] - db[:, 0]).astype(numpy.float64)
+    ows = [oracle.polyline_weights(pts, xyz) for xyz in tr]
+    st = oracle.EdgeFluxState(ny, nx)
+    for t in (0, 2, 1):
+        oracle.edge_flux(st, oracle.vertical_integral(u[t], th), oracle.vertical_integral(v[t], th), ff.arcLengths)
+        got = ff.computeFlux(t, readback=True)
+        assert numpy.array_equal(ff.integratedVelocity, st.integratedVelocity), t
+        want = [oracle.get_integral(w, st.integratedVelocity) for w in ows]
+        bound = 1e-12 * max(numpy.abs(w.weight * st.integratedVelocity.reshape(-1)[w.cell_edge]).sum() for w in ows)
+        assert numpy.abs(numpy.array(got) - numpy.array(want)).max() <= bound
+
+
+def test_two_missing_markers_in_the_flux_kernel(oracle):
+    """nf_field_set_missing_value on HBM-resident fields, every kernel form (float64 / float32, vector / one-cell-per-lane,
+    compact, all steps in one launch): values equal to EITHER marker count as missing, bit-identical to the oracle on the
+    fields with both replaced by NaN."""
+    import torch
+    rng = numpy.random.default_rng(5)
+    for real, (ny, nx) in (('float64', (18, 36)), ('float32', (18, 36)), ('float64', (7, 9)), ('float32', (5, 7))):
+        dg = device_case(nx, ny, 4, 3, PSI_ZT, real=real)
+        u, v = dg.u.cpu().numpy().copy(), dg.v.cpu().numpy().copy()
+        m1 = rng.random(u.shape) < 0.1
+        m2 = rng.random(u.shape) < 0.1
+        u[m1] = 1.e20
+        v[m2] = 1.e20
+        u[m2 & ~m1] = -9999.
+        v[m1 & ~m2] = -9999.
+        un, vn = u.copy(), v.copy()
+        un[m1 | m2] = numpy.nan
+        vn[m1 | m2] = numpy.nan
+        th = dg.zbot - dg.ztop
+        for compact in (False, True):
+            f = quiet_field(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda(),
+                            [transect_xyz(T_OPEN)], fill_value=1.e20, missing_value=-9999., compact=compact)
+            st = oracle.EdgeFluxState(ny, nx)
+            for t in range(3):
+                oracle.edge_flux(st, oracle.vertical_integral(un[t], th), oracle.vertical_integral(vn[t], th), f.arcLengths)
+                f.computeFlux(t, readback=True)
+                assert numpy.array_equal(f.integratedVelocity, st.integratedVelocity), (real, ny, nx, compact, t)
+            tot_steps = numpy.array([f.computeFlux(t)[0] for t in range(3)])
+            tot_all, _ = f.computeAll()          # small grid: all steps in one launch
+            assert numpy.array_equal(tot_all[:, 0], tot_steps)
+
+
 @pytest.mark.parametrize('rotated', [False, True])
 def test_weights_agree_with_quadrature_of_the_interpolated_field_gpu(rotated, oracle):
     """GPU counterpart of test_weights_agree_with_quadrature_of_the_interpolated_field: the device weights (K2/K3) and the

@@ -102,6 +102,61 @@ def test_nemo_like_triple_through_io():
         io.open_uvfile(os.path.join(H5, 'nemo_U.h5'), 'vo')
 
 
+def _cf_expected(raw, markers, scale, offset, dtype):
+    """CF decoding stated independently of nemoflux_amd.io: NaN where the raw value is a marker, else raw*scale + offset"""
+    x = raw.astype(dtype)
+    if scale is not None:
+        x = x * dtype(scale)
+    if offset is not None:
+        x = x + dtype(offset)
+    bad = numpy.zeros(raw.shape, bool)
+    for m in markers:
+        bad |= raw == m
+    x[bad] = numpy.nan
+    return x
+
+
+def test_cf_decoding_like_xarray():
+    """What xarray.open_dataset's default decode_cf gives the reference for free (field.py:22-25, 34-35): _FillValue AND a
+    differing missing_value both mean 'missing'; packed integers are unpacked as raw*scale_factor + add_offset after the
+    masking.  Raw values are pinned by h5py's own read-back (cf_*.raw.npy); xarray itself is not installed (the float type
+    it decodes into is restated from memory: parity unpinned)."""
+    from nemoflux_amd import hdf5min, io
+    # packed int16 with both markers and scale/offset -> a CFDecodedVariable on the host path, masked values NaN
+    raw = numpy.load(os.path.join(H5, 'cf_U.h5.uo.raw.npy'))
+    assert raw.dtype == numpy.int16 and (raw == -32768).any() and (raw == -32767).any()
+    uo, fill, d = io.open_uvfile(os.path.join(H5, 'cf_U.h5'), 'uo', with_all=True)
+    assert isinstance(uo, io.CFDecodedVariable) and not hasattr(uo, 'device_plan')
+    assert uo.shape == raw.shape and uo.dtype == numpy.float64          # add_offset present: float64
+    assert numpy.isnan(fill) and d['_markers_uo'] == []
+    want = _cf_expected(raw, (-32768, -32767), numpy.float32(0.002), numpy.float32(1.5), numpy.float64)
+    for t in range(raw.shape[0]):
+        a = uo.read_step(t)
+        assert a.dtype == numpy.float64 and numpy.array_equal(a, want[t], equal_nan=True)
+        buf = numpy.empty(raw.shape[1:], numpy.float64)
+        assert uo.read_step(t, out=buf) is buf and numpy.array_equal(buf, want[t], equal_nan=True)
+    g = load_golden('def36_zt')
+    ok = ~numpy.isnan(want)
+    assert numpy.abs(want[ok] - g['u'][ok]).max() <= 0.0011             # half a quantum of the packing
+    assert io.cf_float_dtype(numpy.int16, False) == numpy.float32 and io.cf_float_dtype(numpy.int32, False) == numpy.float64
+    assert io.cf_float_dtype(numpy.float32, True) == numpy.float32
+    # float32 with _FillValue 1e20 and missing_value -9999: stays lazy (device-decodable), two markers for the engine
+    rawv = numpy.load(os.path.join(H5, 'cf_V.h5.vo.raw.npy'))
+    vo, fv, dv = io.open_uvfile(os.path.join(H5, 'cf_V.h5'), 'vo', with_all=True)
+    assert isinstance(vo, hdf5min.LazyVariable) and vo.device_plan(0) is not None
+    assert fv == float(numpy.float32(1.e20)) and dv['_markers_vo'] == [float(numpy.float32(1.e20)), -9999.0]
+    assert numpy.array_equal(vo.read_step(1), rawv[1]) and (rawv == numpy.float32(-9999.)).any()
+    # float64 contiguous, missing_value only (no _FillValue): the marker still reaches the engine
+    v64, f64, d64 = io.open_uvfile(os.path.join(H5, 'cf_V64.h5'), 'vo', with_all=True)
+    assert isinstance(v64, numpy.ndarray) and f64 == -9999.0 and d64['_markers_vo'] == [-9999.0]
+    # small T-file variables are decoded whole
+    dd = {'bounds_lon': numpy.array([[1, 2], [3, -5]], numpy.int16), '_FillValue_bounds_lon': numpy.int16(-5),
+          '_scale_factor_bounds_lon': numpy.float64(0.5)}
+    io._cf_apply_whole(dd, 'bounds_lon')
+    assert dd['bounds_lon'].dtype == numpy.float32
+    assert numpy.array_equal(dd['bounds_lon'], numpy.array([[0.5, 1.0], [1.5, numpy.nan]], numpy.float32), equal_nan=True)
+
+
 def test_reference_t_file_in_process():
     """The reference's real NetCDF-4 file (superblock 0, v2 object headers, dense links): hdf5min == committed fixture."""
     from nemoflux_amd import hdf5min

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy, torch
 import bench
 # the tuning build of the library (make -C nemoflux_amd/csrc tuning): diagnostic and writer-wave variants exist only there
-_tun = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libnemoflux_amd_tuning.so')
+_tun = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'build', 'tuning', 'libnemoflux_amd_tuning.so')
 if os.path.exists(_tun):
     os.environ.setdefault('NEMOFLUX_AMD_LIB', _tun)
 from nemoflux_amd._lib import lib, check
