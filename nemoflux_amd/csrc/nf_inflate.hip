@@ -11,6 +11,7 @@
 // per time step in XIOS output).  HDF5's shuffle filter stored the bytes of every element de-interleaved (all first bytes,
 // then all second bytes, ...): k_place gathers them back, one element per lane, coalesced on both sides, and puts the
 // chunk where it belongs in the (nz, ny, nx) slab (chunks may tile y and x, edge chunks hang over).
+#include <type_traits>
 #include <vector>
 
 #include "nf_common.h"
@@ -42,44 +43,94 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     if (threadIdx.x == 0) status[i] = rc;
 }
 
-// Inverse of HDF5's shuffle filter + placement of the chunk in the slab, one chunk per blockIdx.y.  A shuffled chunk holds
+// Inverse of HDF5's shuffle filter + placement of the chunk in the slab; blockIdx.y walks the chunks.  A shuffled chunk holds
 // the ES byte planes of its n elements one after the other; an element of the chunk at (a, b, c) of its (cz, cy, cx) box
 // goes to ((z0+a)*ny + y0+b)*nx + x0+c of the (nz, ny, nx) slab; the parts of an edge chunk that hang over the slab are
-// dropped.  One element per lane: byte-plane reads and element writes are both coalesced along x.
+// dropped.  A lane owns FOUR consecutive elements of a row: one 4-byte load per byte plane (a wave reads 256 contiguous
+// bytes of every plane), a byte transpose in registers, one 16- or 32-byte store.  Chunks whose rows are not a multiple of
+// four elements long take the one-element-per-lane form.
 struct SlabGeom {
     unsigned cz, cy, cx, nz, ny, nx;
 };
 template <int ES, bool SHUFFLED>
 __global__ __launch_bounds__(kBlock) void k_place(const uint8_t *__restrict__ tmp, unsigned chunk_bytes,
-                                                  const InflateJob *__restrict__ jobs, SlabGeom g, uint8_t *__restrict__ dst)
+                                                  const InflateJob *__restrict__ jobs, int njobs, SlabGeom g,
+                                                  uint8_t *__restrict__ dst)
 {
-    const InflateJob job = jobs[blockIdx.y];
     const unsigned long long n = (unsigned long long)g.cz * g.cy * g.cx;
-    const uint8_t *s = tmp + (unsigned long long)blockIdx.y * chunk_bytes;
-    for (unsigned long long e = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; e < n;
-         e += (unsigned long long)gridDim.x * kBlock) {
-        const unsigned c = (unsigned)(e % g.cx);
-        const unsigned long long r = e / g.cx;
-        const unsigned b = (unsigned)(r % g.cy), a = (unsigned)(r / g.cy);
-        const unsigned z = job.z0 + a, y = job.y0 + b, x = job.x0 + c;
-        if (z >= g.nz || y >= g.ny || x >= g.nx) continue;
-        const unsigned long long o = ((unsigned long long)z * g.ny + y) * g.nx + x;
-        if (ES == 1) {
-            dst[o] = s[e];
-        } else if (ES == 4) {
-            uint32_t v;
-            if (SHUFFLED) v = (uint32_t)s[e] | ((uint32_t)s[n + e] << 8) | ((uint32_t)s[2 * n + e] << 16) | ((uint32_t)s[3 * n + e] << 24);
-            else v = reinterpret_cast<const uint32_t *>(s)[e];
-            reinterpret_cast<uint32_t *>(dst)[o] = v;
-        } else {
-            uint64_t v = 0;
-            if (SHUFFLED) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v |= (uint64_t)s[(unsigned long long)k * n + e] << (8 * k);
+    for (int i = blockIdx.y; i < njobs; i += gridDim.y) {
+        const InflateJob job = jobs[i];
+        const uint8_t *s = tmp + (unsigned long long)i * chunk_bytes;
+        for (unsigned long long e = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; e < n;
+             e += (unsigned long long)gridDim.x * kBlock) {
+            const unsigned c = (unsigned)(e % g.cx);
+            const unsigned long long r = e / g.cx;
+            const unsigned b = (unsigned)(r % g.cy), a = (unsigned)(r / g.cy);
+            const unsigned z = job.z0 + a, y = job.y0 + b, x = job.x0 + c;
+            if (z >= g.nz || y >= g.ny || x >= g.nx) continue;
+            const unsigned long long o = ((unsigned long long)z * g.ny + y) * g.nx + x;
+            if (ES == 1) {
+                dst[o] = s[e];
+            } else if (ES == 4) {
+                uint32_t v;
+                if (SHUFFLED) v = (uint32_t)s[e] | ((uint32_t)s[n + e] << 8) | ((uint32_t)s[2 * n + e] << 16) | ((uint32_t)s[3 * n + e] << 24);
+                else v = reinterpret_cast<const uint32_t *>(s)[e];
+                reinterpret_cast<uint32_t *>(dst)[o] = v;
             } else {
-                v = reinterpret_cast<const uint64_t *>(s)[e];
+                uint64_t v = 0;
+                if (SHUFFLED) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v |= (uint64_t)s[(unsigned long long)k * n + e] << (8 * k);
+                } else {
+                    v = reinterpret_cast<const uint64_t *>(s)[e];
+                }
+                reinterpret_cast<uint64_t *>(dst)[o] = v;
             }
-            reinterpret_cast<uint64_t *>(dst)[o] = v;
+        }
+    }
+}
+
+// four elements per lane; needs cx % 4 == 0 (so n % 4 == 0 and a lane's elements share a row)
+template <int ES>
+__global__ __launch_bounds__(kBlock) void k_place4(const uint8_t *__restrict__ tmp, unsigned chunk_bytes,
+                                                   const InflateJob *__restrict__ jobs, int njobs, SlabGeom g,
+                                                   uint8_t *__restrict__ dst)
+{
+    using elem_t = typename std::conditional<ES == 4, uint32_t, uint64_t>::type;
+    const unsigned long long n = (unsigned long long)g.cz * g.cy * g.cx, nq = n / 4;
+    for (int i = blockIdx.y; i < njobs; i += gridDim.y) {
+        const InflateJob job = jobs[i];
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(tmp + (unsigned long long)i * chunk_bytes);
+        for (unsigned long long q = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; q < nq;
+             q += (unsigned long long)gridDim.x * kBlock) {
+            const unsigned long long e = 4 * q;
+            const unsigned c = (unsigned)(e % g.cx);
+            const unsigned long long r = e / g.cx;
+            const unsigned b = (unsigned)(r % g.cy), a = (unsigned)(r / g.cy);
+            const unsigned z = job.z0 + a, y = job.y0 + b, x = job.x0 + c;
+            if (z >= g.nz || y >= g.ny || x >= g.nx) continue;
+            uint32_t w[ES];
+#pragma unroll
+            for (int p = 0; p < ES; ++p) w[p] = __builtin_nontemporal_load(s + (p * n + e) / 4);   // bytes p of elements e .. e+3
+            elem_t out[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                elem_t v = 0;
+#pragma unroll
+                for (int p = 0; p < ES; ++p) v |= (elem_t)((w[p] >> (8 * k)) & 255u) << (8 * p);
+                out[k] = v;
+            }
+            const unsigned long long o = ((unsigned long long)z * g.ny + y) * g.nx + x;
+            elem_t *d = reinterpret_cast<elem_t *>(dst) + o;
+            if (x + 3 < g.nx && (o & 3ull) == 0) {               // whole and 16-byte aligned (the usual case)
+                typedef elem_t vec4 __attribute__((ext_vector_type(4)));
+                const vec4 v = {out[0], out[1], out[2], out[3]};
+                *reinterpret_cast<vec4 *>(d) = v;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (x + k < g.nx) d[k] = out[k];
+            }
         }
     }
 }
@@ -129,6 +180,12 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
     NF_REQUIRE(chunk_bytes == chunk_dims[0] * chunk_dims[1] * chunk_dims[2] * elem_size && chunk_bytes < (1ll << 31), NF_ERR_ARG,
                "inflate: chunk_bytes does not match the chunk dimensions (chunks of up to 2 GiB)");
     if (n == 0) return NF_OK;
+    {   // the decoder's phases are ordered by the issue order of ONE wavefront: a 64-lane workgroup must be exactly that
+        int dev = 0, wave = 0;
+        NF_HIP(hipGetDevice(&dev));
+        NF_HIP(hipDeviceGetAttribute(&wave, hipDeviceAttributeWarpSize, dev));
+        NF_REQUIRE(wave == 64, NF_ERR_NO_DEVICE, "inflate: the device decoder needs 64-lane wavefronts (CDNA)");
+    }
     std::vector<InflateJob> jobs((size_t)n);
     for (int i = 0; i < n; ++i) {
         NF_REQUIRE(in_off[i] >= 0 && in_len[i] >= 0 && (size_t)(in_off[i] + in_len[i]) <= comp_bytes && in_len[i] < (1ll << 31),
@@ -173,16 +230,19 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
                        h->d_jobs, n, h->d_tmp, (unsigned)chunk_bytes, h->d_status);
     const SlabGeom g{(unsigned)chunk_dims[0], (unsigned)chunk_dims[1], (unsigned)chunk_dims[2], (unsigned)slab_dims[0],
                      (unsigned)slab_dims[1], (unsigned)slab_dims[2]};
-    const long long nelem = chunk_bytes / elem_size;
+    const bool four = shuffled && chunk_dims[2] % 4 == 0;             // four elements per lane (k_place4)
+    const long long nelem = chunk_bytes / elem_size / (four ? 4 : 1);
     unsigned gx = (unsigned)std::min<long long>(4096, (nelem + kBlock - 1) / kBlock);
     if (gx == 0) gx = 1;
-    const dim3 grid(gx, (unsigned)n), block(kBlock);
+    const dim3 grid(gx, (unsigned)std::min(n, 65535)), block(kBlock);  // gridDim.y is capped: the kernels walk the chunks
     uint8_t *dst = (uint8_t *)out_dev;
-    if (elem_size == 1) hipLaunchKernelGGL((k_place<1, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, g, dst);
-    else if (elem_size == 4 && shuffled) hipLaunchKernelGGL((k_place<4, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, g, dst);
-    else if (elem_size == 4) hipLaunchKernelGGL((k_place<4, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, g, dst);
-    else if (shuffled) hipLaunchKernelGGL((k_place<8, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, g, dst);
-    else hipLaunchKernelGGL((k_place<8, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, g, dst);
+    if (elem_size == 1) hipLaunchKernelGGL((k_place<1, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
+    else if (elem_size == 4 && four) hipLaunchKernelGGL((k_place4<4>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
+    else if (elem_size == 8 && four) hipLaunchKernelGGL((k_place4<8>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
+    else if (elem_size == 4 && shuffled) hipLaunchKernelGGL((k_place<4, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
+    else if (elem_size == 4) hipLaunchKernelGGL((k_place<4, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
+    else if (shuffled) hipLaunchKernelGGL((k_place<8, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
+    else hipLaunchKernelGGL((k_place<8, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
     NF_HIP(hipGetLastError());
     std::vector<int> status((size_t)n, 0);
     NF_HIP(hipMemcpyAsync(status.data(), h->d_status, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));

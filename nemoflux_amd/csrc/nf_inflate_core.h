@@ -3,14 +3,21 @@
 // Why it exists: real NEMO output is NetCDF-4 = HDF5 with float32 uo/vo stored as shuffled + deflated chunks (one per
 // level in XIOS files); the reference reads them through netCDF4/xarray on the host (nemoflux/field.py:149), and host zlib
 // is what bounds a file-backed pass.  Here the compressed chunks of a time step are copied to HBM
-// as they are and every chunk is inflated by its own wavefront, hundreds at a time, straight into the staging slab the
-// flux kernel reads.  Written from the two RFCs; no zlib code is used.
+// as they are and every chunk is inflated by its own wavefront, a thousand at a time, into the staging slab the flux kernel
+// reads.  Written from the two RFCs; no zlib code is used.
 //
 // Work inside the wavefront (the format is serial per stream, the parallelism is ACROSS streams):
 //   input    all lanes keep the LDS input ring filled (coalesced 4-byte words from HBM)
-//   decode   all lanes run the symbol decoder on UNIFORM values (scalar code): one LDS table lookup per symbol; a literal is
-//            one byte store into the 32 KiB LDS window, a match is copied by the 64 lanes on the spot (overlapping copies by
-//            the period rule) -- stream order, no queue
+//   decode   all lanes run the symbol decoder on UNIFORM values (scalar code).  The decoder is a chain of dependent LDS table
+//            lookups (~50 cycles each), so what it costs is LOOKUPS PER BYTE and what sits between two lookups:
+//              * a table entry carries everything about its symbol -- one literal or TWO (when both codes fit the index),
+//                or a length's base + extra-bit count, or a distance's -- so no symbol needs arithmetic or a second
+//                dependent read to be understood;
+//              * the entry of the NEXT symbol is requested before the current symbol takes effect: a literal's byte store
+//                and a match's 64-lane copy run under that lookup's latency;
+//              * a literal is one byte store into the 32 KiB LDS window, a match is copied by the 64 lanes on the spot
+//                (overlapping copies by the period rule) -- stream order, no queue, no barrier.
+//   stored   stored blocks go from HBM to the window four bytes per lane, without the ring
 //   output   every 8 KiB the new bytes are flushed to HBM as whole 4-byte words and summed into the stream's Adler-32
 //   tables   lane 0 assigns the canonical codes of a dynamic / fixed block, all lanes fill the lookup tables
 //
@@ -21,12 +28,19 @@
 #include <stdint.h>
 
 #ifdef NFI_HOST
+#define NFI_UNROLL
+#define NFI_NOUNROLL
 #define NFI_FN static inline
 #define NFI_CONST static const
 #define NFI_LANE 0
 #define NFI_NLANE 1
 #define NFI_SYNC() ((void)0)
 #else
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "nf_inflate_core.h: one stream = one 64-lane wavefront (gfx9 / CDNA); NFI_SYNC is no barrier on a wave32 target"
+#endif
+#define NFI_UNROLL _Pragma("unroll")
+#define NFI_NOUNROLL _Pragma("nounroll")
 #define NFI_FN __device__ inline
 #define NFI_CONST __constant__ static const
 #define NFI_LANE ((int)threadIdx.x)
@@ -34,7 +48,7 @@
 // One stream = one wavefront = one workgroup, so "all lanes have done their LDS writes" needs no s_barrier and no wait for
 // the LDS queue to drain: a wavefront's LDS instructions execute in issue order, a later read sees an earlier write of
 // another lane.  What is needed is that the compiler keeps that order: a wavefront-scope fence + scheduling barrier (no
-// instruction is emitted).  k_inflate is launched with exactly 64 lanes per workgroup.
+// instruction is emitted).  k_inflate is launched with exactly 64 lanes per workgroup (nf_inflater_run checks warpSize).
 #define NFI_SYNC()                                              \
     do {                                                        \
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  \
@@ -44,8 +58,7 @@
 #define NFI_FOR_LANES(i, n) for (int i = NFI_LANE; i < (int)(n); i += NFI_NLANE)
 // The symbol decoder is serial and every lane would compute the same thing, so it runs as UNIFORM code: all lanes execute it,
 // every value it reads from LDS is passed through readfirstlane, and the compiler keeps the whole bit-buffer arithmetic on
-// the scalar unit (one instruction per cycle, native 64-bit shifts) instead of issuing 64-wide vector instructions for one
-// useful lane -- 300 -> ~110 cycles per literal.
+// the scalar unit (native 64-bit shifts) instead of issuing 64-wide vector instructions for one useful lane.
 #ifdef NFI_HOST
 #define NFI_UNI(x) ((uint32_t)(x))
 #else
@@ -65,14 +78,29 @@ enum {
 };
 
 constexpr int kNfiWindow = 32768;          // RFC 1951: distances up to 32 KiB
-constexpr int kNfiRingWords = 512;         // input ring: two halves of 256 words (1 KiB each); a round reads < 100 words
-constexpr int kNfiHalf = 256;
-constexpr int kNfiQueue = 64;              // symbols decoded per round (between two looks at the input ring and the flush)
+constexpr int kNfiRingWords = 256;         // input ring: two halves of 128 words (512 B each); a round ends when it runs low
+constexpr int kNfiHalf = 128;
 constexpr int kNfiLitBits = 10, kNfiDistBits = 8, kNfiClBits = 7;
-constexpr uint32_t kNfiStoredRound = 512;  // bytes of a stored block moved per round (must stay inside one ring half)
+constexpr uint32_t kNfiStoredRound = 4096; // bytes of a stored block moved per round
 
-template <int N> struct NfiHuffT {   // canonical code of one alphabet, for codes longer than the lookup table
+// ---- lookup-table entries (32 bits): everything the decoder needs to know about the symbol at the head of the bit buffer
+//   bits  0..3   n      bits of Huffman code this entry consumes (both codes of a literal pair); 0 with bit 31
+//   bits  4..7   x      extra bits that follow the code (length codes 0..5, distance codes 0..13)
+//   bits  8..23  v      literal (bits 8..15) and second literal (16..23) | length base 3..258 | distance base 1..24577
+//   bits 24..25  count  literals this entry stores (1 or 2); 0 otherwise
+//   bit  26      bad    a length / distance code the format reserves (286, 287 / 30, 31): an error once met
+//   bit  28      length \
+//   bit  29      end     > anything but a literal makes the entry >= 1 << 28: the literal loop's whole exit test
+//   bit  30      (never in a table: the decoder ORs it into every entry it reads once the round has to end)
+//   bit  31      long   / the code is longer than the table (literal / length table): canonical walk
+constexpr uint32_t kNfiBad = 1u << 26, kNfiIsLen = 1u << 28, kNfiIsEob = 1u << 29, kNfiStop = 1u << 30, kNfiLong = 1u << 31;
+constexpr uint32_t kNfiNotLit = 1u << 28;   // entries below this are literals
+#define NFI_ENTRY(n, x, v, flags) ((uint32_t)(n) | ((uint32_t)(x) << 4) | ((uint32_t)(v) << 8) | (uint32_t)(flags))
+
+template <int N> struct NfiHuffT {   // canonical code of one alphabet
     uint16_t count[16];              // number of codes of each length
+    uint16_t offs[16];               // index in symbol[] of the first code of each length
+    uint16_t first[16];              // canonical code (MSB first) of the first symbol of each length
     uint16_t symbol[N];              // symbols ordered by code
 };
 typedef NfiHuffT<288> NfiHuff;       // literal / length alphabet
@@ -81,13 +109,12 @@ typedef NfiHuffT<32> NfiHuffSmall;   // distance alphabet (30) and the code-leng
 struct NfiCtx {           // lives in LDS (< 40 KiB, so that four fit a CU's 160 KiB): one per wavefront
     uint8_t window[kNfiWindow];
     uint32_t ring[kNfiRingWords];
-    uint16_t lit_tab[1 << kNfiLitBits];    // (symbol << 4) | length, 0 = longer code
-    uint16_t dist_tab[1 << kNfiDistBits];
-    uint16_t cl_tab[1 << kNfiClBits];
+    uint32_t lit_tab[1 << kNfiLitBits];
+    uint32_t dist_tab[1 << kNfiDistBits];  // during a dynamic block's header its first bytes hold the code-length table
     NfiHuff lit;
     NfiHuffSmall dist;
     uint8_t lens[320];                     // code lengths: 288 literal/length + 32 distance
-    uint16_t code[320];                    // canonical code of every symbol (bit-reversed, as it appears in the stream)
+    uint32_t trash;                        // where the second lane of the literal store writes when there is one literal
     // state shared between the phases (written by lane 0, read by all after a barrier)
     uint64_t bitbuf;
     int32_t bitcnt;
@@ -104,6 +131,28 @@ struct NfiCtx {           // lives in LDS (< 40 KiB, so that four fit a CU's 160
 };
 
 NFI_CONST uint8_t kNfiClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// base and extra bits of the length codes 257..285 and the distance codes 0..29 (RFC 1951 3.2.5), by arithmetic
+NFI_FN uint32_t nfi_len_entry(int li, int n)       // li = symbol - 257
+{
+    if (li >= 29) return NFI_ENTRY(n, 0, 3, kNfiIsLen | kNfiBad);
+    const int lx = li < 8 || li == 28 ? 0 : (li - 4) >> 2;
+    const uint32_t base = li < 8 ? 3u + (uint32_t)li : (li == 28 ? 258u : 3u + ((4u + (uint32_t)(li & 3)) << lx));
+    return NFI_ENTRY(n, lx, base, kNfiIsLen);
+}
+NFI_FN uint32_t nfi_dist_entry(int ds, int n)
+{
+    if (ds >= 30) return NFI_ENTRY(n, 0, 1, kNfiBad);
+    const int dx = ds < 4 ? 0 : (ds - 2) >> 1;
+    const uint32_t base = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + (uint32_t)(ds & 1)) << dx);
+    return NFI_ENTRY(n, dx, base, 0);
+}
+NFI_FN uint32_t nfi_lit_entry(int sym, int n)
+{
+    if (sym < 256) return NFI_ENTRY(n, 0, sym, 1u << 24);
+    if (sym == 256) return NFI_ENTRY(n, 0, 0, kNfiIsEob);
+    return nfi_len_entry(sym - 257, n);
+}
 
 // ---------------------------------------------------------------------------------------------- input ring (phase A)
 // words: the stream's bytes seen as 4-byte words starting at the word that holds its first byte; nwords: how many of
@@ -145,17 +194,12 @@ NFI_FN uint32_t nfi_take(NfiBits &b, int n)   // n <= 24, caller made sure cnt >
     return v;
 }
 
-// decode one symbol: lookup table first, canonical walk for the codes that do not fit it (RFC 1951 3.2.2)
-template <class H> NFI_FN int nfi_symbol(NfiBits &b, const uint16_t *tab, int tabbits, const H &h)
+// canonical walk for a code that does not fit its lookup table (RFC 1951 3.2.2); consumes the code, returns the symbol
+template <class H> NFI_FN int nfi_walk(NfiBits &b, const H &h)
 {
-    const uint32_t e = NFI_UNI(tab[b.buf & ((1u << tabbits) - 1u)]);
-    if (e & 15) {
-        b.buf >>= (e & 15);
-        b.cnt -= (int)(e & 15);
-        return (int)(e >> 4);
-    }
     int code = 0, first = 0, index = 0;
     uint64_t bits = b.buf;
+    NFI_NOUNROLL                                 // rare path: keep it small, and its table reads out of the hot loop
     for (int len = 1; len <= 15; ++len) {
         code |= (int)(bits & 1);
         bits >>= 1;
@@ -174,9 +218,9 @@ template <class H> NFI_FN int nfi_symbol(NfiBits &b, const uint16_t *tab, int ta
 }
 
 // ---------------------------------------------------------------------------------------------- table construction
-// lens[0..n) -> canonical description (lane 0) + bit-reversed code of every symbol; returns "left" of the Kraft sum
-// (0 = complete, > 0 = incomplete, < 0 = over-subscribed)
-template <class H, class L> NFI_FN int nfi_canonical(H &h, const L *lens, uint16_t *code, int n)
+// lens[0..n) -> canonical description (one lane); returns "left" of the Kraft sum (0 = complete, > 0 = incomplete,
+// < 0 = over-subscribed)
+template <class H, class L> NFI_FN int nfi_canonical(H &h, const L *lens, int n)
 {
     for (int l = 0; l <= 15; ++l) h.count[l] = 0;
     for (int s = 0; s < n; ++s) h.count[lens[s]]++;
@@ -186,39 +230,81 @@ template <class H, class L> NFI_FN int nfi_canonical(H &h, const L *lens, uint16
         left -= h.count[l];
         if (left < 0) return left;
     }
-    uint16_t offs[16], next[16];
-    offs[1] = 0;
-    for (int l = 1; l < 15; ++l) offs[l + 1] = (uint16_t)(offs[l] + h.count[l]);
+    uint16_t offs[16];
+    offs[0] = offs[1] = 0;
+    h.offs[0] = h.offs[1] = 0;
+    for (int l = 1; l < 15; ++l) {
+        offs[l + 1] = (uint16_t)(offs[l] + h.count[l]);
+        h.offs[l + 1] = offs[l + 1];
+    }
     int cc = 0;                                // RFC 1951 3.2.2: code = (code + bl_count[bits-1]) << 1, bl_count[0] = 0
+    h.first[0] = 0;
     for (int l = 1; l <= 15; ++l) {
         cc = (cc + (l > 1 ? h.count[l - 1] : 0)) << 1;
-        next[l] = (uint16_t)cc;
+        h.first[l] = (uint16_t)cc;
     }
     for (int s = 0; s < n; ++s) {
         const int l = lens[s];
-        if (l) {
-            h.symbol[offs[l]++] = (uint16_t)s;
-            unsigned cw = next[l]++, r = 0;
-            for (int k = 0; k < l; ++k) {        // the stream carries Huffman codes most significant bit first
-                r = (r << 1) | (cw & 1u);
-                cw >>= 1;
-            }
-            code[s] = (uint16_t)r;
-        }
+        if (l) h.symbol[offs[l]++] = (uint16_t)s;
     }
     return left;
 }
 
-// all lanes: lookup table of `bits` bits from (lens, code)
-NFI_FN void nfi_fill_table(uint16_t *tab, int bits, const uint8_t *lens, const uint16_t *code, int n)
+NFI_FN uint32_t nfi_bitrev(uint32_t cw, int l)   // the stream carries Huffman codes most significant bit first
 {
-    NFI_FOR_LANES(k, 1 << bits) tab[k] = 0;
-    NFI_SYNC();
-    NFI_FOR_LANES(s, n) {
-        const int l = lens[s];
-        if (l && l <= bits)
-            for (unsigned k = code[s]; k < (1u << bits); k += (1u << l)) tab[k] = (uint16_t)((s << 4) | l);
+#ifdef NFI_HOST
+    uint32_t r = 0;
+    for (int k = 0; k < l; ++k) {
+        r = (r << 1) | (cw & 1u);
+        cw >>= 1;
     }
+    return r;
+#else
+    return __builtin_bitreverse32(cw) >> (32 - l);
+#endif
+}
+
+// all lanes: lookup table of `bits` bits for the alphabet described by h; LIT: literal/length entries, else distance entries.
+// Lanes walk the symbols in code order: the i-th code of length l is first[l] + (i - offs[l]).
+template <bool LIT, class H> NFI_FN void nfi_fill_table(uint32_t *tab, int bits, const H &h, int nused)
+{
+    NFI_FOR_LANES(k, 1 << bits) tab[k] = LIT ? kNfiLong : 0u;
+    NFI_SYNC();
+    NFI_FOR_LANES(i, nused) {
+        int l = 1;
+        while (l < 15 && i >= (int)h.offs[l] + (int)h.count[l]) ++l;
+        if (l <= bits) {
+            const int s = h.symbol[i];
+            const uint32_t e = LIT ? nfi_lit_entry(s, l) : nfi_dist_entry(s, l);
+            const uint32_t cw = nfi_bitrev((uint32_t)h.first[l] + (uint32_t)(i - (int)h.offs[l]), l);
+            for (uint32_t k = cw; k < (1u << bits); k += (1u << l)) tab[k] = e;
+        }
+    }
+    NFI_SYNC();
+}
+
+// all lanes: where two literals fit the index, the entry carries both (one lookup, two bytes).  The second literal of index
+// k is what the single-symbol table says about the bits that follow the first code, provided its code ends inside the index.
+NFI_FN void nfi_pair_literals(uint32_t *tab, int bits)
+{
+    constexpr int kPer = (1 << kNfiLitBits) / NFI_NLANE;
+    uint32_t fresh[kPer];
+NFI_UNROLL
+    for (int r = 0; r < kPer; ++r) {
+        const uint32_t k = (uint32_t)NFI_LANE + (uint32_t)r * NFI_NLANE;
+        uint32_t e = tab[k];
+        const uint32_t n1 = e & 15u;
+        if (e < kNfiNotLit && (int)n1 < bits) {
+            const uint32_t e2 = tab[k >> n1];
+            const uint32_t n2 = e2 & 15u;
+            if (e2 < kNfiNotLit && (int)(n1 + n2) <= bits)
+                e = NFI_ENTRY(n1 + n2, 0, ((e >> 8) & 255u) | (((e2 >> 8) & 255u) << 8), 2u << 24);
+        }
+        fresh[r] = e;
+    }
+    NFI_SYNC();
+NFI_UNROLL
+    for (int r = 0; r < kPer; ++r) tab[(uint32_t)NFI_LANE + (uint32_t)r * NFI_NLANE] = fresh[r];
     NFI_SYNC();
 }
 
@@ -245,10 +331,9 @@ NFI_FN void nfi_block_header(NfiCtx &c)
         for (int s = 144; s < 256; ++s) c.lens[s] = 9;
         for (int s = 256; s < 280; ++s) c.lens[s] = 7;
         for (int s = 280; s < 288; ++s) c.lens[s] = 8;
-        for (int s = 0; s < 30; ++s) c.lens[288 + s] = 5;
-        c.lens[318] = c.lens[319] = 0;
+        for (int s = 0; s < 32; ++s) c.lens[288 + s] = 5;   // all 32 five-bit codes exist; 30 and 31 never occur in valid data
         c.nlit = 288;
-        c.ndist = 30;
+        c.ndist = 32;
         c.state = 1;
     } else if (type == 2) {                // dynamic codes (3.2.7)
         nfi_refill(c, b);
@@ -263,19 +348,23 @@ NFI_FN void nfi_block_header(NfiCtx &c)
                 cl[kNfiClOrder[k]] = (uint16_t)nfi_take(b, 3);
             }
             NfiHuffSmall &h = c.dist;      // scratch: the distance description is rebuilt right after
-            uint16_t clcode[19];
-            if (nfi_canonical(h, cl, clcode, 19) != 0 && !(h.count[0] == 18)) c.err = NFI_ERR_CODES;   // must be complete
-            for (int k = 0; k < (1 << kNfiClBits); ++k) c.cl_tab[k] = 0;
-            for (int s = 0; s < 19; ++s)
-                if (cl[s])
-                    for (unsigned k = clcode[s]; k < (1u << kNfiClBits); k += (1u << cl[s])) c.cl_tab[k] = (uint16_t)((s << 4) | cl[s]);
+            uint16_t *cl_tab = reinterpret_cast<uint16_t *>(c.dist_tab);       // (symbol << 4) | length, 0 = none
+            if (nfi_canonical(h, cl, 19) != 0 && !(h.count[0] == 18)) c.err = NFI_ERR_CODES;   // must be complete
+            for (int k = 0; k < (1 << kNfiClBits); ++k) cl_tab[k] = 0;
+            for (int i = 0; i < 19 - (int)h.count[0]; ++i) {
+                int l = 1;
+                while (l < 15 && i >= (int)h.offs[l] + (int)h.count[l]) ++l;
+                const uint32_t cw = nfi_bitrev((uint32_t)h.first[l] + (uint32_t)(i - (int)h.offs[l]), l);
+                for (uint32_t k = cw; k < (1u << kNfiClBits); k += (1u << l)) cl_tab[k] = (uint16_t)((h.symbol[i] << 4) | l);
+            }
             int idx = 0;
             while (idx < nlit + ndist && !c.err) {
                 nfi_refill(c, b);
-                const int sym = nfi_symbol(b, c.cl_tab, kNfiClBits, h);
-                if (sym < 0) {
-                    c.err = NFI_ERR_SYMBOL;
-                } else if (sym < 16) {
+                const uint32_t e = cl_tab[b.buf & ((1u << kNfiClBits) - 1u)];     // code lengths of this alphabet are <= 7 bits
+                if (!(e & 15)) { c.err = NFI_ERR_SYMBOL; break; }
+                nfi_take(b, (int)(e & 15));
+                const int sym = (int)(e >> 4);
+                if (sym < 16) {
                     c.lens[idx < nlit ? idx : 288 + (idx - nlit)] = (uint8_t)sym;
                     ++idx;
                 } else {
@@ -312,124 +401,174 @@ NFI_FN void nfi_block_header(NfiCtx &c)
 NFI_FN void nfi_build_tables(NfiCtx &c)
 {
     if (NFI_LANE == 0) {
-        const int l1 = nfi_canonical(c.lit, c.lens, c.code, c.nlit);
-        const int l2 = nfi_canonical(c.dist, c.lens + 288, c.code + 288, c.ndist);
+        const int l1 = nfi_canonical(c.lit, c.lens, c.nlit);
+        const int l2 = nfi_canonical(c.dist, c.lens + 288, c.ndist);
         // over-subscribed sets are errors; an incomplete literal/length set too, unless it has a single code; the
         // distance set may be incomplete (one distance code, or none when the block holds literals only)
         if (l1 < 0 || l2 < 0 || (l1 > 0 && c.nlit - c.lit.count[0] != 1)) c.err = NFI_ERR_CODES;
     }
     NFI_SYNC();
-    nfi_fill_table(c.lit_tab, kNfiLitBits, c.lens, c.code, c.nlit);
-    nfi_fill_table(c.dist_tab, kNfiDistBits, c.lens + 288, c.code + 288, c.ndist);
+    if (c.err) return;                     // uniform
+    nfi_fill_table<true>(c.lit_tab, kNfiLitBits, c.lit, c.nlit - (int)c.lit.count[0]);
+    nfi_pair_literals(c.lit_tab, kNfiLitBits);
+    nfi_fill_table<false>(c.dist_tab, kNfiDistBits, c.dist, c.ndist - (int)c.dist.count[0]);
 }
 
-// ---------------------------------------------------------------------------------------------- phase B: lane 0
-// A match is copied 64 bytes per step by all lanes; an overlapping copy (dist < len) repeats the last dist bytes.
+// ---------------------------------------------------------------------------------------------- phase B: the symbol decoder
+// A match is copied 64 bytes per step by all lanes; an overlapping copy (dist < len) repeats the last dist bytes.  A
+// wavefront's LDS instructions execute in issue order, so a step may read what the previous step wrote.
 NFI_FN void nfi_copy_match(NfiCtx &c, uint32_t pos, uint32_t len, uint32_t dist)
 {
-    const float rcp = 1.0f / (float)dist;            // j < 258: the float quotient is exact to within one, fixed up below
-    NFI_FOR_LANES(j, len) {
-        uint32_t off = (uint32_t)j;                  // overlapping copy (dist < len): the bytes repeat with period dist
+#ifndef NFI_HOST
+    if (len <= (uint32_t)NFI_NLANE && dist >= len) {        // uniform; most matches of real data: one step, no loop
+        if ((uint32_t)NFI_LANE < len)
+            c.window[(pos + (uint32_t)NFI_LANE) & (kNfiWindow - 1)] = c.window[(pos + (uint32_t)NFI_LANE - dist) & (kNfiWindow - 1)];
+        return;
+    }
+#endif
+    if (dist >= len || dist >= (uint32_t)NFI_NLANE) {       // uniform: no lane reads a byte of its own step
+        NFI_FOR_LANES(j, len)
+            c.window[(pos + (uint32_t)j) & (kNfiWindow - 1)] = c.window[(pos + (uint32_t)j - dist) & (kNfiWindow - 1)];
+        return;
+    }
+#ifdef NFI_HOST
+    const float rcp = 1.0f / (float)dist;
+#else
+    const float rcp = __builtin_amdgcn_rcpf((float)dist);
+#endif
+    NFI_FOR_LANES(j, len) {                          // j < 258, dist < 64: the float quotient is exact to within one
+        uint32_t off = (uint32_t)j;                  // the bytes repeat with period dist
         if (off >= dist) {
             const uint32_t q = (uint32_t)((float)off * rcp);
             off -= q * dist;
             if ((int32_t)off < 0) off += dist;
             else if (off >= dist) off -= dist;
         }
-        c.window[(pos + j) & (kNfiWindow - 1)] = c.window[(pos - dist + off) & (kNfiWindow - 1)];
+        c.window[(pos + (uint32_t)j) & (kNfiWindow - 1)] = c.window[(pos - dist + off) & (kNfiWindow - 1)];
     }
 }
 
-// decode up to kNfiQueue symbols of the current Huffman block straight into the LDS window.  Executed by ALL lanes on uniform
-// values: a literal is one byte store (every lane writes the same byte to the same address), a match is copied by the 64
-// lanes on the spot -- the symbols take effect in stream order, and a wavefront's LDS instructions execute in issue order, so
-// no queue, no barrier and no reordering hazard is left.  A wavefront issues one instruction every four cycles at best, so
-// what this loop costs is its instruction count: the run of short-coded literals -- most symbols of real data -- is a loop of
-// its own with one table lookup, one byte store and a handful of scalar instructions per byte.
+// Decode symbols of the current Huffman block straight into the LDS window until the block ends, the input ring runs low,
+// or the window holds as much unflushed output as it can.  Executed by ALL lanes on uniform values (scalar code).
+//
+// A lone wavefront issues one instruction every four cycles, so after the table lookups what a symbol costs is its
+// INSTRUCTION COUNT.  Hence:
+//   * `e` always holds the entry of the symbol at the head of the bit buffer, requested one symbol ahead: the lookup is
+//     issued, THEN the current symbol takes effect (a literal's byte store, a match's 64-lane copy), and only then is the
+//     entry waited for -- the effect runs under the lookup's latency.  The same holds for the next word of the input ring.
+//   * The run of table-coded literals (most symbols of real data) is a loop of its own with ONE exit test: literal entries
+//     are the numbers below 1 << 28, and whatever ends a round (ring low, window full) ORs a stop bit into every entry read.
+//   * Nothing in the hot path branches on an error: reserved codes carry a flag that is OR-ed up, a distance beyond the
+//     start and an output beyond its length are noticed by sticky compares / at the end of the round.  Every index into
+//     LDS is masked, so garbage decodes garbage safely until the round ends (each symbol consumes at least one bit).
 NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
 {
-    NfiBits b;      // executed by ALL lanes on uniform values (see NFI_UNI): scalar code
+    NfiBits b;
     b.buf = ((uint64_t)NFI_UNI((uint32_t)(c.bitbuf >> 32)) << 32) | NFI_UNI((uint32_t)c.bitbuf);
     b.cnt = (int)NFI_UNI(c.bitcnt);
     b.word = NFI_UNI(c.word);
     const int last = (int)NFI_UNI(c.last);
-    uint32_t nextw = NFI_UNI(c.ring[b.word & (kNfiRingWords - 1)]);
+    // ring words [b.word, loaded) are valid; one symbol reads at most three of them, the prefetch one more
+    const uint32_t word_stop = NFI_UNI(c.loaded) - 5u;
+    // The unflushed output must stay inside the window.  The position is looked at after every match; a run of literals
+    // adds at most 32 bytes per 32-bit refill and the ring holds 256 words, i.e. at most 8 KiB per round.
+    const uint32_t hard_stop = NFI_UNI(c.flushed) + (uint32_t)kNfiWindow - 8192u - 1024u;
+    uint32_t nextw_raw = c.ring[b.word & (kNfiRingWords - 1)];          // not waited for until the next refill
+    uint32_t stop = 0;                            // kNfiStop once the round has to end: OR-ed into every entry read
 #define NFI_REFILL()                                                     \
     if (b.cnt <= 32) {                                                   \
-        b.buf |= (uint64_t)nextw << b.cnt;                               \
+        b.buf |= (uint64_t)NFI_UNI(nextw_raw) << b.cnt;                  \
         b.cnt += 32;                                                     \
         ++b.word;                                                        \
-        nextw = NFI_UNI(c.ring[b.word & (kNfiRingWords - 1)]);           \
+        nextw_raw = c.ring[b.word & (kNfiRingWords - 1)];                \
+        if (b.word >= word_stop) stop = kNfiStop;                        \
     }
-    uint32_t pos = NFI_UNI(c.pos);
-    uint32_t nq = 0;                              // symbols of this round
-    int err = 0, state = 1;
     constexpr uint32_t kMask = (1u << kNfiLitBits) - 1u;
+#define NFI_LOOKUP_RAW() (c.lit_tab[(uint32_t)b.buf & kMask])
+    uint32_t pos = NFI_UNI(c.pos);
+    uint32_t flags = 0;                           // OR of every length / distance entry used: kNfiBad = a reserved code
+    int err = 0, state = 1;
+    if (pos >= hard_stop) stop = kNfiStop;
+    NFI_REFILL();
+    uint32_t e = NFI_UNI(NFI_LOOKUP_RAW()) | stop;
     for (;;) {
-        // ---- run of short-coded literals.  A table entry is (symbol << 4) | length, 0 for a code longer than the table:
-        // entries 1 .. 4095 are exactly the literals 0 .. 255.
-        uint32_t rem = kNfiQueue - nq;
-        if (out_len - pos < rem) rem = out_len - pos;
-        uint32_t e = 0;
-        bool have = false;                        // e holds the entry of the symbol at the head of the bit buffer
-        while (rem) {
+        // ---- run of table-coded literals (one or two per lookup)
+        while (e < kNfiNotLit) {
+            const uint32_t n = e & 15u;
+            b.buf >>= n;
+            b.cnt -= (int)n;
             NFI_REFILL();
-            e = NFI_UNI(c.lit_tab[(uint32_t)b.buf & kMask]);
-            have = true;
-            if (e - 1u >= 4095u) break;
-            b.buf >>= (e & 15);
-            b.cnt -= (int)(e & 15);
-            c.window[pos & (kNfiWindow - 1)] = (uint8_t)(e >> 4);
-            ++nq;
-            ++pos;
-            --rem;
-            have = false;
+            const uint32_t raw_next = NFI_LOOKUP_RAW();
+            const uint32_t count = (e >> 24) & 3u;
+#ifdef NFI_HOST
+            c.window[pos & (kNfiWindow - 1)] = (uint8_t)(e >> 8);
+            if (count > 1u) c.window[(pos + 1u) & (kNfiWindow - 1)] = (uint8_t)(e >> 16);
+#else
+            if (NFI_LANE < 2) {                   // one store instruction for both bytes; lane 1 of a single literal hits `trash`
+                uint8_t *at = (uint32_t)NFI_LANE < count ? &c.window[(pos + (uint32_t)NFI_LANE) & (kNfiWindow - 1)]
+                                                         : reinterpret_cast<uint8_t *>(&c.trash);
+                *at = (uint8_t)(e >> (8u + 8u * (uint32_t)NFI_LANE));
+            }
+#endif
+            pos += count;
+            e = NFI_UNI(raw_next) | stop;
         }
-        if (nq == kNfiQueue) break;
-        // ---- any other symbol
-        if (!have) {                              // the output is full: only the end-of-block code may follow
-            NFI_REFILL();
-            e = NFI_UNI(c.lit_tab[(uint32_t)b.buf & kMask]);
-        }
-        int sym;
-        if (e & 15) {
-            b.buf >>= (e & 15);
-            b.cnt -= (int)(e & 15);
-            sym = (int)(e >> 4);
-        } else {
-            sym = nfi_symbol(b, c.lit_tab, kNfiLitBits, c.lit);      // takes the canonical walk (the entry is 0)
+        if (stop) break;                          // the caller refills the ring / flushes, then comes back
+        // ---- anything else: a match, the end of the block, a code longer than the table
+        uint32_t n = e & 15u;
+        if (e >= kNfiIsEob) {                     // rare: end of block or long code
+            if (e & kNfiIsEob) {
+                b.buf >>= n;
+                b.cnt -= (int)n;
+                state = last ? 3 : 0;
+                break;
+            }
+            const int sym = nfi_walk(b, c.lit);   // consumes the code
             if (sym < 0) { err = NFI_ERR_SYMBOL; break; }
+            e = nfi_lit_entry(sym, 0);
+            n = 0;
+            if (e < kNfiNotLit) {                 // a literal with a long code
+                NFI_REFILL();
+                const uint32_t raw_next = NFI_LOOKUP_RAW();
+                c.window[pos & (kNfiWindow - 1)] = (uint8_t)(e >> 8);
+                pos += 1u;
+                e = NFI_UNI(raw_next) | stop;
+                continue;
+            }
+            if (e & kNfiIsEob) {
+                state = last ? 3 : 0;
+                break;
+            }
         }
-        if (sym < 256) {                          // a literal with a long code, or one that does not fit any more
-            if (pos >= out_len) { err = NFI_ERR_OUTPUT; break; }
-            c.window[pos & (kNfiWindow - 1)] = (uint8_t)sym;
-            ++nq;
-            ++pos;
-        } else if (sym == 256) {
-            state = last ? 3 : 0;
-            break;
-        } else {
-            const int li = sym - 257;
-            if (li >= 29) { err = NFI_ERR_SYMBOL; break; }
-            // base and extra bits of the length / distance codes (RFC 1951 3.2.5) by arithmetic: a table in memory would
-            // cost a scalar-memory round trip per symbol
-            const int lx = li < 8 ? 0 : (li - 4) >> 2;
-            const uint32_t lbase = li < 8 ? 3u + (uint32_t)li : (li == 28 ? 258u : 3u + ((4u + (uint32_t)(li & 3)) << lx));
-            const uint32_t len = lbase + nfi_take(b, li == 28 ? 0 : lx);
-            NFI_REFILL();
-            const int ds = nfi_symbol(b, c.dist_tab, kNfiDistBits, c.dist);
-            if (ds < 0 || ds >= 30) { err = NFI_ERR_SYMBOL; break; }
-            const int dx = ds < 4 ? 0 : (ds - 2) >> 1;
-            const uint32_t dbase = ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + (uint32_t)(ds & 1)) << dx);
-            const uint32_t dist = dbase + nfi_take(b, dx);
-            if (dist > pos) { err = NFI_ERR_DISTANCE; break; }
-            if (pos + len > out_len) { err = NFI_ERR_OUTPUT; break; }
-            nfi_copy_match(c, pos, len, dist);          // len in 3 .. 258, dist in 1 .. 32768
-            ++nq;
-            pos += len;
+        // ---- a match: length (base + extra bits), then the distance code
+        b.buf >>= n;
+        b.cnt -= (int)n;
+        flags |= e;
+        const uint32_t len = ((e >> 8) & 0xffffu) + nfi_take(b, (int)((e >> 4) & 15u));
+        NFI_REFILL();
+        uint32_t d = NFI_UNI(c.dist_tab[(uint32_t)b.buf & ((1u << kNfiDistBits) - 1u)]);
+        uint32_t dn = d & 15u;
+        if (dn == 0) {
+            const int ds = nfi_walk(b, c.dist);
+            if (ds < 0) { err = NFI_ERR_SYMBOL; break; }
+            d = nfi_dist_entry(ds, 0);
         }
+        b.buf >>= dn;
+        b.cnt -= (int)dn;
+        flags |= d;
+        const uint32_t dist = ((d >> 8) & 0xffffu) + nfi_take(b, (int)((d >> 4) & 15u));
+        if (dist > pos) err = NFI_ERR_DISTANCE;     // sticky; the copy below reads masked (stale) window bytes
+        NFI_REFILL();
+        const uint32_t raw_next = NFI_LOOKUP_RAW();
+        nfi_copy_match(c, pos, len, dist);          // len in 3 .. 258, dist in 1 .. 32768
+        pos += len;
+        if (pos >= hard_stop) stop = kNfiStop;
+        e = NFI_UNI(raw_next) | stop;
     }
+#undef NFI_LOOKUP_RAW
 #undef NFI_REFILL
+    if (!err && (flags & kNfiBad)) err = NFI_ERR_SYMBOL;
+    if (!err && pos > out_len) err = NFI_ERR_OUTPUT;
     if (err) c.err = err;
     c.state = state;
     c.pos = pos;
@@ -439,49 +578,53 @@ NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
 }
 
 // ---------------------------------------------------------------------------------------------- phase C: all lanes
-// bytes of a stored block: straight from the input ring into the window (all lanes), at most one ring half per call
-NFI_FN void nfi_stored_round(NfiCtx &c, uint32_t out_len)
+// bytes of a stored block: straight from HBM into the window, four bytes per lane and step (the header left the bit buffer
+// on a byte boundary; whatever it still holds is read again from memory).  When the block ends the bit buffer restarts at
+// the byte that follows it and the input ring is re-positioned there.
+NFI_FN void nfi_stored_round(NfiCtx &c, const uint32_t *words, uint32_t nwords, uint32_t out_len)
 {
-    // the bit buffer holds whole bytes here (the header aligned it); give them back to the ring position
-    uint32_t n = c.stored_left < kNfiStoredRound ? c.stored_left : kNfiStoredRound;
-    if (c.pos + n > out_len) {
-        if (NFI_LANE == 0) c.err = NFI_ERR_OUTPUT;
+    const uint32_t n = c.stored_left < kNfiStoredRound ? c.stored_left : kNfiStoredRound;
+    const uint32_t byte_in = c.word * 4u - ((uint32_t)c.bitcnt >> 3);     // next unread byte of the stream
+    const uint32_t pos = c.pos;
+    int err = 0;
+    if (pos + n > out_len) err = NFI_ERR_OUTPUT;
+    else if (byte_in + n > nwords * 4u) err = NFI_ERR_INPUT;
+    if (err) {                                                            // uniform
+        if (NFI_LANE == 0) c.err = err;
         NFI_SYNC();
         return;
     }
-    const uint32_t have = (uint32_t)c.bitcnt >> 3;                       // bytes still in the bit buffer
-    const uint64_t buf = c.bitbuf;
-    const uint32_t byte0 = c.word * 4u;                                   // ring byte that follows the bit buffer
-    const uint32_t pos = c.pos;
-    NFI_FOR_LANES(j, n) {
-        uint8_t v;
-        if ((uint32_t)j < have) v = (uint8_t)(buf >> (8 * j));
-        else {
-            const uint32_t bi = byte0 + ((uint32_t)j - have);
-            v = (uint8_t)(c.ring[(bi >> 2) & (kNfiRingWords - 1)] >> (8 * (bi & 3)));
+    const uint32_t sh = 8u * (byte_in & 3u), w0 = byte_in >> 2;
+    NFI_FOR_LANES(k, (n + 3u) >> 2) {
+        const uint32_t lo = words[w0 + (uint32_t)k];
+        const uint32_t hi = (sh && w0 + (uint32_t)k + 1u < nwords) ? words[w0 + (uint32_t)k + 1u] : 0u;
+        const uint32_t v = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+        const uint32_t p = pos + 4u * (uint32_t)k;
+        if ((pos & 3u) == 0 && 4u * (uint32_t)k + 4u <= n) {
+            *reinterpret_cast<uint32_t *>(&c.window[p & (kNfiWindow - 1)]) = v;
+        } else {
+NFI_UNROLL
+            for (uint32_t q = 0; q < 4; ++q)
+                if (4u * (uint32_t)k + q < n) c.window[(p + q) & (kNfiWindow - 1)] = (uint8_t)(v >> (8u * q));
         }
-        c.window[(pos + j) & (kNfiWindow - 1)] = v;
     }
     NFI_SYNC();
     if (NFI_LANE == 0) {
-        if (n <= have) {
-            c.bitbuf = have == 8 && n == 8 ? 0 : (buf >> (8 * n));
-            c.bitcnt -= 8 * (int)n;
-        } else {
-            const uint32_t bi = byte0 + (n - have);                       // first unread byte
-            c.word = bi >> 2;
-            const uint32_t sub = bi & 3;
-            if (sub) {                                                    // keep the rest of that word in the bit buffer
-                c.bitbuf = (uint64_t)(c.ring[c.word & (kNfiRingWords - 1)] >> (8 * sub));
-                c.bitcnt = 32 - 8 * (int)sub;
-                ++c.word;
-            } else {
-                c.bitbuf = 0;
-                c.bitcnt = 0;
-            }
-        }
         c.pos = pos + n;
         c.stored_left -= n;
+        const uint32_t bi = byte_in + n;                                  // first unread byte
+        uint32_t w = bi >> 2;
+        const uint32_t sub = bi & 3u;
+        if (sub) {                                                        // keep the rest of that word in the bit buffer
+            c.bitbuf = (uint64_t)((w < nwords ? words[w] : 0u) >> (8u * sub));
+            c.bitcnt = 32 - 8 * (int)sub;
+            ++w;
+        } else {
+            c.bitbuf = 0;
+            c.bitcnt = 0;
+        }
+        c.word = w;
+        c.loaded = w & ~(uint32_t)(kNfiHalf - 1);                         // the ring is filled again from the half that holds w
         if (c.stored_left == 0) c.state = c.last ? 3 : 0;
     }
     NFI_SYNC();
@@ -490,23 +633,25 @@ NFI_FN void nfi_stored_round(NfiCtx &c, uint32_t out_len)
 // write the finished part of the window to the output: whole 4-byte words (dst 4-byte aligned), the tail at the end;
 // the Adler-32 of the stream (RFC 1950) is carried along: for n new bytes b_0..b_{n-1}, a += sum b_i and
 // b += n*a_old + sum (n-i) b_i, both modulo 65521 -- per-lane partial sums, added up by lane 0
-constexpr uint32_t kNfiFlushBytes = 8192;   // + one round's output (<= 64 x 258) stays below the 32 KiB the ring holds
+constexpr uint32_t kNfiFlushBytes = 8192;   // flushed when at least this much is new; a round never lets it pass 32 KiB
 NFI_FN void nfi_flush(NfiCtx &c, uint8_t *dst, bool final)
 {
     if (!final && c.pos - c.flushed < kNfiFlushBytes) return;     // uniform: both are read after a barrier
     const uint32_t from = c.flushed, upto = final ? c.pos : (c.pos & ~3u);
     const uint32_t n = upto - from;
     uint32_t pa = 0;
-    uint64_t pb = 0;                            // 64 bits: the host build runs all of a flush (up to 16.5 KiB) on one "lane"
-    if (((uintptr_t)dst & 3u) == 0) {
+    uint64_t pb = 0;                            // 64 bits: the host build runs all of a flush (up to 24 KiB) on one "lane"
+    if (((uintptr_t)dst & 3u) == 0) {           // `from` is a multiple of 4 (every earlier flush ended on one)
         const uint32_t nwords = n >> 2;
         uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + from);
         NFI_FOR_LANES(w, nwords) {
             const uint32_t i0 = 4u * (uint32_t)w, p = (from + i0) & (kNfiWindow - 1);
-            const uint32_t b0 = c.window[p], b1 = c.window[p + 1], b2 = c.window[p + 2], b3 = c.window[p + 3];
-            d32[w] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-            pa += b0 + b1 + b2 + b3;
-            pb += (uint64_t)((n - i0) * b0 + (n - i0 - 1) * b1) + (uint64_t)((n - i0 - 2) * b2 + (n - i0 - 3) * b3);
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(&c.window[p]);
+            d32[w] = v;
+            const uint32_t b0 = v & 255u, b1 = (v >> 8) & 255u, b2 = (v >> 16) & 255u, b3 = v >> 24;
+            const uint32_t s = b0 + b1 + b2 + b3;
+            pa += s;
+            pb += (uint64_t)((n - i0) * s - (b1 + 2u * b2 + 3u * b3));
         }
         const uint32_t done = 4u * nwords;
         NFI_FOR_LANES(j, n - done) {
@@ -525,7 +670,7 @@ NFI_FN void nfi_flush(NfiCtx &c, uint8_t *dst, bool final)
     }
     uint32_t sa = pa, sb = (uint32_t)(pb % 65521u);
 #ifndef NFI_HOST
-    for (int o = 32; o > 0; o >>= 1) {          // wavefront sums (64 x 65520 and 64 x 16.5 KiB x 255 fit 32 bits)
+    for (int o = 32; o > 0; o >>= 1) {          // wavefront sums (64 x 65520 and 64 x 24 KiB x 255 fit 32 bits)
         sa += __shfl_xor(sa, o, 64);
         sb += __shfl_xor(sb, o, 64);
     }
@@ -586,9 +731,9 @@ NFI_FN int nfi_inflate_stream(NfiCtx &c, const uint8_t *src, uint32_t in_len, ui
         } else if (c.state == 1) {
             nfi_decode_round(c, out_len);          // all lanes, uniform
             NFI_SYNC();
-            nfi_flush(c, dst, false);
+            if (!c.err) nfi_flush(c, dst, false);  // uniform; a round that went wrong may have run past out_len
         } else {
-            nfi_stored_round(c, out_len);
+            nfi_stored_round(c, words, nwords, out_len);
             nfi_flush(c, dst, false);
         }
         if (NFI_LANE == 0 && c.word > word_limit) c.err = NFI_ERR_INPUT;

@@ -107,3 +107,44 @@ def exact_segment_fluxes(psi, polys, nz, nt, zmin=0., zmax=1.):
             seg[t] = ((phi[1:] - phi[:-1]) * dz).sum(axis=1)
         out.append(seg)
     return out
+
+
+def deflated_dataset(a, name, chunk, level=4, shuffle=True, attrs=None, threads=None):
+    """An in-memory NetCDF-4-style chunked variable (no HDF5 writer exists in this image): `a` (nt, nz, ny, nx) cut into
+    chunks of shape `chunk` = (1, cz, cy, cx) -- edge chunks are stored whole, as HDF5 does, with arbitrary bytes beyond the
+    edge -- each byte-shuffled and deflated exactly as the HDF5 filter pipeline stores it, behind a real
+    nemoflux_amd.hdf5min.Dataset: the reader code that runs (chunk selection, device plan, gather) is the one files go
+    through; only the metadata parsing is skipped.  Returns (LazyVariable, compressed bytes)."""
+    import concurrent.futures
+    import zlib
+    from nemoflux_amd import hdf5min
+    nt, nz, ny, nx = a.shape
+    _, cz, cy, cx = chunk
+    es = a.dtype.itemsize
+    keys = [(t, z0, y0, x0) for t in range(nt) for z0 in range(0, nz, cz) for y0 in range(0, ny, cy) for x0 in range(0, nx, cx)]
+
+    def pack(key):
+        t, z0, y0, x0 = key
+        sub = a[t, z0:z0 + cz, y0:y0 + cy, x0:x0 + cx]
+        if sub.shape != (cz, cy, cx):
+            blk = numpy.full((cz, cy, cx), 7.25, a.dtype)             # what lies beyond the edge is arbitrary
+            blk[:sub.shape[0], :sub.shape[1], :sub.shape[2]] = sub
+        else:
+            blk = numpy.ascontiguousarray(sub)
+        raw = blk.view(numpy.uint8).reshape(-1, es)
+        return zlib.compress(numpy.ascontiguousarray(raw.T).tobytes() if shuffle else raw.tobytes(), level)
+    with concurrent.futures.ThreadPoolExecutor(threads or hdf5min.io_threads()) as pool:
+        blobs = list(pool.map(pack, keys))
+    chunks, off = [], 0
+    for key, b in zip(keys, blobs):
+        chunks.append((key + (0,), len(b), 0, off))
+        off += len(b)
+
+    class MemFile(object):          # what hdf5min.Dataset needs of its File: the mapped bytes and the base address
+        def __init__(self, blob):
+            self._m, self._base = blob, 0
+    filters = ([(2, [es])] if shuffle else []) + [(1, [level])]
+    ds = hdf5min.Dataset(MemFile(b''.join(blobs)), name, a.shape, numpy.dtype(a.dtype).newbyteorder('<'),
+                         ('chunked', None, (1, cz, cy, cx, es), None), filters, dict(attrs or {}))
+    ds._chunks = chunks
+    return hdf5min.LazyVariable(ds), off

@@ -12,10 +12,20 @@ f = ((numpy.cos(2*numpy.pi*y/360) + numpy.sin(2*numpy.pi*x/360)) * 3.1).astype('
 f *= (1 + 1e-3 * rng.standard_normal(f.shape).astype('<f4'))
 sh = numpy.ascontiguousarray(f.view(numpy.uint8).reshape(-1, 4).T)
 dec = ChunkDecoder()
-cases = [('plane0: noise -> stored blocks', sh[0].tobytes()), ('plane2: Huffman literals', sh[2].tobytes()),
-         ('plane3: long matches', sh[3].tobytes()), ('whole level (4 planes)', sh.tobytes())]
-for name, data in cases:
-    c = zlib.compress(data, 4)
+# calibration streams (1 MB each): Huffman-only literals with ~4-bit and ~8-bit codes, and matches of 8 bytes
+lit4 = rng.integers(0, 16, 1 << 20, dtype=numpy.uint8).tobytes()
+lit8 = rng.integers(0, 256, 1 << 20, dtype=numpy.uint8).tobytes()
+words = rng.integers(0, 256, (4096, 8), dtype=numpy.uint8)
+m8 = words[rng.integers(0, 4096, 1 << 17)].tobytes()
+cases = [('plane0: noise -> stored blocks', sh[0].tobytes(), 4, zlib.Z_DEFAULT_STRATEGY),
+         ('plane2: Huffman literals', sh[2].tobytes(), 4, zlib.Z_DEFAULT_STRATEGY),
+         ('plane3: long matches', sh[3].tobytes(), 4, zlib.Z_DEFAULT_STRATEGY),
+         ('whole level (4 planes)', sh.tobytes(), 4, zlib.Z_DEFAULT_STRATEGY),
+         ('literals, 4-bit codes', lit4, 6, zlib.Z_HUFFMAN_ONLY), ('literals, 8-bit codes', lit8, 6, zlib.Z_HUFFMAN_ONLY),
+         ('matches of 8 bytes', m8, 9, zlib.Z_DEFAULT_STRATEGY)]
+for name, data, level, strategy in cases:
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 9, strategy)
+    c = co.compress(data) + co.flush()
     dec.decode_streams([c] * 4, len(data))
     out = dec.decode_streams([c] * 256, len(data))
     assert bytes(out[5]) == data
