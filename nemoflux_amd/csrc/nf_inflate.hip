@@ -33,6 +33,10 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     __shared__ NfiCtx ctx;
     const int i = blockIdx.x;
     if (i >= njobs) return;
+    if ((uint32_t)(uintptr_t)&ctx != 0u) {      // the decoder's hand-written loop addresses ctx from LDS offset 0
+        if (threadIdx.x == 0) status[i] = NFI_ERR_LAYOUT;
+        return;
+    }
     const InflateJob job = jobs[i];
     const unsigned long long first = job.in_off & ~3ull;                 // the word that holds the stream's first byte
     unsigned long long readable = comp_bytes - first;                    // comp_bytes is a multiple of 4 (padded by the host)
@@ -162,6 +166,7 @@ static const char *inflate_error_name(int rc)
         case NFI_ERR_OUTPUT: return "decoded length differs from the chunk size";
         case NFI_ERR_INPUT: return "compressed stream is truncated";
         case NFI_ERR_CHECKSUM: return "Adler-32 mismatch";
+        case NFI_ERR_LAYOUT: return "decoder state is not at LDS offset 0 (build problem)";
         default: return "unknown error";
     }
 }

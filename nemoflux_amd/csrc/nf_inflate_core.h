@@ -75,6 +75,7 @@ enum {
     NFI_ERR_OUTPUT = 6,      // more (or, at the end, fewer) bytes than the caller expects
     NFI_ERR_INPUT = 7,       // ran past the end of the compressed stream
     NFI_ERR_CHECKSUM = 8,    // Adler-32 of the output differs from the stream's trailer (RFC 1950)
+    NFI_ERR_LAYOUT = 9,      // (device) the decoder state does not start at LDS offset 0
 };
 
 constexpr int kNfiWindow = 32768;          // RFC 1951: distances up to 32 KiB
@@ -87,7 +88,7 @@ constexpr uint32_t kNfiStoredRound = 4096; // bytes of a stored block moved per 
 //   bits  0..3   n      bits of Huffman code this entry consumes (both codes of a literal pair); 0 with bit 31
 //   bits  4..7   x      extra bits that follow the code (length codes 0..5, distance codes 0..13)
 //   bits  8..23  v      literal (bits 8..15) and second literal (16..23) | length base 3..258 | distance base 1..24577
-//   bits 24..25  count  literals this entry stores (1 or 2); 0 otherwise
+//   bits 24..25  lanes  literal entries: mask of the lanes that store (1 = one literal, 3 = two); 0 otherwise
 //   bit  26      bad    a length / distance code the format reserves (286, 287 / 30, 31): an error once met
 //   bit  28      length \
 //   bit  29      end     > anything but a literal makes the entry >= 1 << 28: the literal loop's whole exit test
@@ -298,7 +299,7 @@ NFI_UNROLL
             const uint32_t e2 = tab[k >> n1];
             const uint32_t n2 = e2 & 15u;
             if (e2 < kNfiNotLit && (int)(n1 + n2) <= bits)
-                e = NFI_ENTRY(n1 + n2, 0, ((e >> 8) & 255u) | (((e2 >> 8) & 255u) << 8), 2u << 24);
+                e = NFI_ENTRY(n1 + n2, 0, ((e >> 8) & 255u) | (((e2 >> 8) & 255u) << 8), 3u << 24);
         }
         fresh[r] = e;
     }
@@ -461,7 +462,7 @@ NFI_FN void nfi_copy_match(NfiCtx &c, uint32_t pos, uint32_t len, uint32_t dist)
 //   * Nothing in the hot path branches on an error: reserved codes carry a flag that is OR-ed up, a distance beyond the
 //     start and an output beyond its length are noticed by sticky compares / at the end of the round.  Every index into
 //     LDS is masked, so garbage decodes garbage safely until the round ends (each symbol consumes at least one bit).
-NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
+NFI_FN void nfi_decode_round_cxx(NfiCtx &c, uint32_t out_len)
 {
     NfiBits b;
     b.buf = ((uint64_t)NFI_UNI((uint32_t)(c.bitbuf >> 32)) << 32) | NFI_UNI((uint32_t)c.bitbuf);
@@ -499,7 +500,7 @@ NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
             b.cnt -= (int)n;
             NFI_REFILL();
             const uint32_t raw_next = NFI_LOOKUP_RAW();
-            const uint32_t count = (e >> 24) & 3u;
+            const uint32_t count = (((e >> 24) & 3u) + 1u) >> 1;     // lane mask 1 / 3 -> 1 / 2 literals
 #ifdef NFI_HOST
             c.window[pos & (kNfiWindow - 1)] = (uint8_t)(e >> 8);
             if (count > 1u) c.window[(pos + 1u) & (kNfiWindow - 1)] = (uint8_t)(e >> 16);
@@ -577,6 +578,306 @@ NFI_FN void nfi_decode_round(NfiCtx &c, uint32_t out_len)
     c.word = b.word;
 }
 
+#if !defined(NFI_HOST) && !defined(NFI_PORTABLE_DECODE)
+// ---- the same round, with its hot loop written in gfx9 ISA ------------------------------------------------------------
+// What the compiler makes of nfi_decode_round_cxx costs ~27 instructions and three taken branches per literal lookup and
+// ~100 instructions and a dozen taken branches per match (measured: 107 ns and 320-500 ns); for a lone wavefront every
+// instruction is >= 4 cycles and every taken branch a refetch.  Below: 19 instructions and ONE taken branch per literal
+// lookup, ~60 instructions and two taken branches per match.  The asm block runs literal runs and the common matches
+// (table-coded length and distance, fewer than 64 bytes, source before destination); everything rare leaves the block at a
+// symbol boundary with a reason code and is finished by the C++ statements of the portable version:
+//   reason 0  the round has to end (ring low / window full)        1  head entry is end-of-block or a long code
+//          2  distance code longer than its table (length decoded)  3  copy of >= 64 bytes or overlapping (len, dist decoded)
+// Register plan inside the block (moved in and out at its ends): s[40:41] bit buffer, s42 valid bits, s43 entry at the head,
+// s44 output position, s45 ring word, s46 stop bit, s47-s49 scratch, s50 len, s51 dist, s52 distance entry, s53 OR of the
+// entries used, s54 error, s55 / s56 word / position limits, s57 reason, s[58:59] saved exec; v40-v48 scratch and constants.
+// ctx sits at LDS address 0 (k_inflate checks): the window is addressed from 0, the tables by immediate offsets.
+NFI_FN void nfi_decode_round_asm(NfiCtx &c, uint32_t out_len)
+{
+    uint64_t buf = ((uint64_t)NFI_UNI((uint32_t)(c.bitbuf >> 32)) << 32) | NFI_UNI((uint32_t)c.bitbuf);
+    uint32_t cnt = NFI_UNI(c.bitcnt), word = NFI_UNI(c.word), pos = NFI_UNI(c.pos);
+    const int last = (int)NFI_UNI(c.last);
+    const uint32_t word_stop = NFI_UNI(c.loaded) - 5u;
+    const uint32_t hard_stop = NFI_UNI(c.flushed) + (uint32_t)kNfiWindow - 8192u - 1024u;
+    uint32_t nextw_raw = c.ring[word & (kNfiRingWords - 1)];
+    uint32_t stop = pos >= hard_stop ? kNfiStop : 0u;
+    uint32_t flags = 0, err = 0, reason = 0, len = 0, dist = 0;
+    int state = 1;
+    constexpr uint32_t kMask = (1u << kNfiLitBits) - 1u;
+    const uint32_t lane = (uint32_t)NFI_LANE;
+#define NFI_REFILL_C()                                                   \
+    if (cnt <= 32u) {                                                    \
+        buf |= (uint64_t)NFI_UNI(nextw_raw) << cnt;                      \
+        cnt += 32u;                                                      \
+        ++word;                                                          \
+        nextw_raw = c.ring[word & (kNfiRingWords - 1)];                  \
+        if (word >= word_stop) stop = kNfiStop;                          \
+    }
+    NFI_REFILL_C();
+    uint32_t e = NFI_UNI(c.lit_tab[(uint32_t)buf & kMask]) | stop;
+    for (;;) {
+        // (what enters the block through an "s" operand must be uniform for the compiler too, not just in fact)
+        buf = ((uint64_t)NFI_UNI((uint32_t)(buf >> 32)) << 32) | NFI_UNI((uint32_t)buf);
+        cnt = NFI_UNI(cnt); e = NFI_UNI(e); pos = NFI_UNI(pos); word = NFI_UNI(word); stop = NFI_UNI(stop);
+        flags = NFI_UNI(flags); err = NFI_UNI(err);
+        asm volatile(
+            "s_mov_b64 s[58:59], exec\n\t"
+            "s_mov_b64 s[40:41], %[buf]\n\t"
+            "s_mov_b32 s42, %[cnt]\n\t"
+            "s_mov_b32 s43, %[e]\n\t"
+            "s_mov_b32 s44, %[pos]\n\t"
+            "s_mov_b32 s45, %[word]\n\t"
+            "s_mov_b32 s46, %[stop]\n\t"
+            "s_mov_b32 s53, %[flags]\n\t"
+            "s_mov_b32 s54, %[err]\n\t"
+            "s_mov_b32 s55, %[word_stop]\n\t"
+            "s_mov_b32 s56, %[hard_stop]\n\t"
+            "s_mov_b32 s57, 0\n\t"
+            "s_mov_b32 s50, 0\n\t"
+            "s_mov_b32 s51, 0\n\t"
+            "v_mov_b32 v45, 0xffc\n\t"
+            "v_mov_b32 v46, 0x3fc\n\t"
+            "v_mov_b32 v47, 0x7fff\n\t"
+            "v_lshlrev_b32 v48, 3, %[lane]\n\t"
+            "v_add_u32 v48, 8, v48\n\t"                      // lane 0 stores bits 8.., lane 1 bits 16..
+            "s_mov_b64 exec, 3\n\t"
+            "s_waitcnt lgkmcnt(0)\n"
+            // ---------------------------------------------------------------- dispatch on the entry at the head
+            "1:\n\t"
+            "s_cmp_lt_u32 s43, 0x10000000\n\t"
+            "s_cbranch_scc0 3f\n"
+            // ---------------------------------------------------------------- literal run
+            "2:\n\t"
+            "s_and_b32 s47, s43, 15\n\t"
+            "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+            "s_sub_u32 s42, s42, s47\n\t"
+            "s_cmp_le_u32 s42, 32\n\t"
+            "s_cbranch_scc1 10f\n"
+            "11:\n\t"
+            "s_lshl_b32 s47, s40, 2\n\t"
+            "v_and_b32 v40, s47, v45\n\t"
+            "ds_read_b32 v41, v40 offset:%[lit]\n\t"       // next entry: requested before this one takes effect
+            "s_bfe_u32 s47, s43, 0x20018\n\t"                // lanes that store: 1 or 3
+            "s_mov_b32 exec_lo, s47\n\t"
+            "v_add_u32 v42, s44, %[lane]\n\t"
+            "v_and_b32 v42, v47, v42\n\t"
+            "v_lshrrev_b32_e64 v44, v48, s43\n\t"
+            "ds_write_b8 v42, v44\n\t"
+            "s_bcnt1_i32_b32 s47, s47\n\t"
+            "s_add_u32 s44, s44, s47\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_readfirstlane_b32 s43, v41\n\t"
+            "s_or_b32 s43, s43, s46\n\t"
+            "s_cmp_lt_u32 s43, 0x10000000\n\t"
+            "s_cbranch_scc1 2b\n"
+            // ---------------------------------------------------------------- not a literal
+            "3:\n\t"
+            "s_cmp_lg_u32 s46, 0\n\t"
+            "s_cbranch_scc1 9f\n\t"                          // reason 0: the round ends
+            "s_cmp_ge_u32 s43, 0x20000000\n\t"
+            "s_cbranch_scc1 20f\n\t"                         // reason 1: end of block / long code
+            // ---- a match: length
+            "s_and_b32 s47, s43, 15\n\t"
+            "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+            "s_sub_u32 s42, s42, s47\n\t"
+            "s_or_b32 s53, s53, s43\n\t"
+            "s_bfe_u32 s47, s43, 0x40004\n\t"
+            "s_bfm_b32 s48, s47, 0\n\t"
+            "s_and_b32 s48, s40, s48\n\t"
+            "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+            "s_sub_u32 s42, s42, s47\n\t"
+            "s_bfe_u32 s50, s43, 0x100008\n\t"
+            "s_add_u32 s50, s50, s48\n\t"
+            "s_cmp_le_u32 s42, 32\n\t"
+            "s_cbranch_scc1 12f\n"
+            "13:\n\t"
+            // ---- distance
+            "s_lshl_b32 s47, s40, 2\n\t"
+            "v_and_b32 v40, s47, v46\n\t"
+            "ds_read_b32 v43, v40 offset:%[dtab]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_readfirstlane_b32 s52, v43\n\t"
+            "s_and_b32 s47, s52, 15\n\t"
+            "s_cmp_eq_u32 s47, 0\n\t"
+            "s_cbranch_scc1 21f\n\t"                         // reason 2: long distance code
+            "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+            "s_sub_u32 s42, s42, s47\n\t"
+            "s_or_b32 s53, s53, s52\n\t"
+            "s_bfe_u32 s47, s52, 0x40004\n\t"
+            "s_bfm_b32 s48, s47, 0\n\t"
+            "s_and_b32 s48, s40, s48\n\t"
+            "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+            "s_sub_u32 s42, s42, s47\n\t"
+            "s_bfe_u32 s51, s52, 0x100008\n\t"
+            "s_add_u32 s51, s51, s48\n\t"
+            "s_cmp_gt_u32 s51, s44\n\t"
+            "s_cselect_b32 s54, 5, s54\n\t"                  // NFI_ERR_DISTANCE, sticky
+            "s_cmp_le_u32 s42, 32\n\t"
+            "s_cbranch_scc1 14f\n"
+            "15:\n\t"
+            "s_cmp_ge_u32 s50, 64\n\t"
+            "s_cbranch_scc1 22f\n\t"                         // reason 3: a long copy
+            "s_cmp_lt_u32 s51, s50\n\t"
+            "s_cbranch_scc1 22f\n\t"                         // reason 3: an overlapping copy
+            // ---- next entry requested, then the copy: one step of (len) lanes
+            "s_lshl_b32 s47, s40, 2\n\t"
+            "v_and_b32 v40, s47, v45\n\t"
+            "ds_read_b32 v41, v40 offset:%[lit]\n\t"
+            "s_bfm_b64 exec, s50, 0\n\t"
+            "v_add_u32 v42, s44, %[lane]\n\t"
+            "v_subrev_u32 v43, s51, v42\n\t"
+            "v_and_b32 v43, v47, v43\n\t"
+            "v_and_b32 v42, v47, v42\n\t"
+            "ds_read_u8 v44, v43\n\t"
+            "s_add_u32 s44, s44, s50\n\t"
+            "s_cmp_ge_u32 s44, s56\n\t"
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // window full: the round ends after this symbol
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "ds_write_b8 v42, v44\n\t"
+            "s_mov_b64 exec, 3\n\t"
+            "v_readfirstlane_b32 s43, v41\n\t"
+            "s_or_b32 s43, s43, s46\n\t"
+            "s_branch 1b\n"
+            // ---------------------------------------------------------------- refills of the bit buffer (out of line)
+            "10:\n\t"
+            "s_mov_b32 s57, 11\n\t"
+            "s_branch 16f\n"
+            "12:\n\t"
+            "s_mov_b32 s57, 13\n\t"
+            "s_branch 16f\n"
+            "14:\n\t"
+            "s_mov_b32 s57, 15\n"
+            "16:\n\t"
+            "v_readfirstlane_b32 s48, %[nextw]\n\t"
+            "s_mov_b32 s49, 0\n\t"
+            "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
+            "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
+            "s_add_u32 s42, s42, 32\n\t"
+            "s_add_u32 s45, s45, 1\n\t"
+            "s_and_b32 s47, s45, 0xff\n\t"
+            "s_lshl_b32 s47, s47, 2\n\t"
+            "v_mov_b32 v40, s47\n\t"
+            "ds_read_b32 %[nextw], v40 offset:%[ring]\n\t"
+            "s_cmp_ge_u32 s45, s55\n\t"
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // ring low: the round ends at the next symbol boundary
+            "s_cmp_eq_u32 s57, 11\n\t"
+            "s_cbranch_scc1 11b\n\t"
+            "s_cmp_eq_u32 s57, 13\n\t"
+            "s_cbranch_scc1 13b\n\t"
+            "s_branch 15b\n"
+            // ---------------------------------------------------------------- exits
+            "20:\n\t"
+            "s_mov_b32 s57, 1\n\t"
+            "s_branch 8f\n"
+            "21:\n\t"
+            "s_mov_b32 s57, 2\n\t"
+            "s_branch 8f\n"
+            "22:\n\t"
+            "s_mov_b32 s57, 3\n\t"
+            "s_branch 8f\n"
+            "9:\n\t"
+            "s_mov_b32 s57, 0\n"
+            "8:\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_mov_b64 exec, s[58:59]\n\t"
+            "s_mov_b64 %[buf], s[40:41]\n\t"
+            "s_mov_b32 %[cnt], s42\n\t"
+            "s_mov_b32 %[e], s43\n\t"
+            "s_mov_b32 %[pos], s44\n\t"
+            "s_mov_b32 %[word], s45\n\t"
+            "s_mov_b32 %[stop], s46\n\t"
+            "s_mov_b32 %[flags], s53\n\t"
+            "s_mov_b32 %[err], s54\n\t"
+            "s_mov_b32 %[reason], s57\n\t"
+            "s_mov_b32 %[len], s50\n\t"
+            "s_mov_b32 %[dist], s51\n\t"
+            : [buf] "+s"(buf), [cnt] "+s"(cnt), [e] "+s"(e), [pos] "+s"(pos), [word] "+s"(word), [stop] "+s"(stop),
+              [flags] "+s"(flags), [err] "+s"(err), [reason] "=s"(reason), [len] "=s"(len), [dist] "=s"(dist),
+              [nextw] "+v"(nextw_raw)
+            : [word_stop] "s"(word_stop), [hard_stop] "s"(hard_stop), [lane] "v"(lane),
+              [lit] "n"(__builtin_offsetof(NfiCtx, lit_tab)), [dtab] "n"(__builtin_offsetof(NfiCtx, dist_tab)),
+              [ring] "n"(__builtin_offsetof(NfiCtx, ring))
+            : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52",
+              "s53", "s54", "s55", "s56", "s57", "s58", "s59", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48");
+        // ---- the block left at a symbol boundary: the rare cases, in the portable version's statements
+        if (reason == 0) break;
+        if (reason == 1) {                           // end of block, or a literal / length code longer than the table
+            uint32_t n = e & 15u;
+            NfiBits b{buf, (int)cnt, word};
+            if (e & kNfiIsEob) {
+                buf >>= n;
+                cnt -= n;
+                state = last ? 3 : 0;
+                break;
+            }
+            const int sym = nfi_walk(b, c.lit);
+            buf = b.buf;
+            cnt = (uint32_t)b.cnt;
+            if (sym < 0) { err = NFI_ERR_SYMBOL; break; }
+            e = nfi_lit_entry(sym, 0);
+            if (e < kNfiNotLit) {
+                NFI_REFILL_C();
+                const uint32_t raw_next = c.lit_tab[(uint32_t)buf & kMask];
+                c.window[pos & (kNfiWindow - 1)] = (uint8_t)(e >> 8);
+                pos += 1u;
+                e = NFI_UNI(raw_next) | stop;
+                continue;
+            }
+            if (e & kNfiIsEob) {
+                state = last ? 3 : 0;
+                break;
+            }
+            flags |= e;                              // a length: finish the match here
+            const uint32_t x = (e >> 4) & 15u;
+            len = ((e >> 8) & 0xffffu) + ((uint32_t)buf & ((1u << x) - 1u));
+            buf >>= x;
+            cnt -= x;
+            NFI_REFILL_C();
+            reason = 2;
+        }
+        if (reason == 2) {                           // the distance: table or canonical walk
+            uint32_t d = NFI_UNI(c.dist_tab[(uint32_t)buf & ((1u << kNfiDistBits) - 1u)]);
+            const uint32_t dn = d & 15u;
+            if (dn == 0) {
+                NfiBits b{buf, (int)cnt, word};
+                const int ds = nfi_walk(b, c.dist);
+                buf = b.buf;
+                cnt = (uint32_t)b.cnt;
+                if (ds < 0) { err = NFI_ERR_SYMBOL; break; }
+                d = nfi_dist_entry(ds, 0);
+            }
+            buf >>= dn;
+            cnt -= dn;
+            flags |= d;
+            const uint32_t dx = (d >> 4) & 15u;
+            dist = ((d >> 8) & 0xffffu) + ((uint32_t)buf & ((1u << dx) - 1u));
+            buf >>= dx;
+            cnt -= dx;
+            if (dist > pos) err = NFI_ERR_DISTANCE;
+            NFI_REFILL_C();
+        }
+        // reason 2 (continued) and 3: the copy in its general form, then the next entry
+        const uint32_t raw_next = c.lit_tab[(uint32_t)buf & kMask];
+        nfi_copy_match(c, pos, len, dist);
+        pos += len;
+        if (pos >= hard_stop) stop = kNfiStop;
+        e = NFI_UNI(raw_next) | stop;
+    }
+#undef NFI_REFILL_C
+    if (!err && (flags & kNfiBad)) err = NFI_ERR_SYMBOL;
+    if (!err && pos > out_len) err = NFI_ERR_OUTPUT;
+    if (err) c.err = (int32_t)err;
+    c.state = state;
+    c.pos = pos;
+    c.bitbuf = buf;
+    c.bitcnt = (int32_t)cnt;
+    c.word = word;
+}
+#define nfi_decode_round nfi_decode_round_asm
+#else
+#define nfi_decode_round nfi_decode_round_cxx
+#endif
+
 // ---------------------------------------------------------------------------------------------- phase C: all lanes
 // bytes of a stored block: straight from HBM into the window, four bytes per lane and step (the header left the bit buffer
 // on a byte boundary; whatever it still holds is read again from memory).  When the block ends the bit buffer restarts at
@@ -594,18 +895,26 @@ NFI_FN void nfi_stored_round(NfiCtx &c, const uint32_t *words, uint32_t nwords, 
         NFI_SYNC();
         return;
     }
-    const uint32_t sh = 8u * (byte_in & 3u), w0 = byte_in >> 2;
-    NFI_FOR_LANES(k, (n + 3u) >> 2) {
-        const uint32_t lo = words[w0 + (uint32_t)k];
-        const uint32_t hi = (sh && w0 + (uint32_t)k + 1u < nwords) ? words[w0 + (uint32_t)k + 1u] : 0u;
-        const uint32_t v = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
-        const uint32_t p = pos + 4u * (uint32_t)k;
-        if ((pos & 3u) == 0 && 4u * (uint32_t)k + 4u <= n) {
+    const uint32_t sh = 8u * (byte_in & 3u), w0 = byte_in >> 2, nw = (n + 3u) >> 2;
+    constexpr int kPer = (int)(kNfiStoredRound / 4u) / NFI_NLANE;        // words per lane and round: all loads issued first
+    uint32_t lo[kPer], hi[kPer];
+    NFI_UNROLL
+    for (int r = 0; r < kPer; ++r) {
+        const uint32_t k = (uint32_t)NFI_LANE + (uint32_t)r * NFI_NLANE;
+        lo[r] = k < nw ? words[w0 + k] : 0u;
+        hi[r] = (sh && k < nw && w0 + k + 1u < nwords) ? words[w0 + k + 1u] : 0u;
+    }
+    NFI_UNROLL
+    for (int r = 0; r < kPer; ++r) {
+        const uint32_t k = (uint32_t)NFI_LANE + (uint32_t)r * NFI_NLANE;
+        if (k >= nw) break;
+        const uint32_t v = sh ? (lo[r] >> sh) | (hi[r] << (32u - sh)) : lo[r];
+        const uint32_t p = pos + 4u * k;
+        if ((pos & 3u) == 0 && 4u * k + 4u <= n) {
             *reinterpret_cast<uint32_t *>(&c.window[p & (kNfiWindow - 1)]) = v;
         } else {
-NFI_UNROLL
             for (uint32_t q = 0; q < 4; ++q)
-                if (4u * (uint32_t)k + q < n) c.window[(p + q) & (kNfiWindow - 1)] = (uint8_t)(v >> (8u * q));
+                if (4u * k + q < n) c.window[(p + q) & (kNfiWindow - 1)] = (uint8_t)(v >> (8u * q));
         }
     }
     NFI_SYNC();
