@@ -78,11 +78,18 @@ enum {
     NFI_ERR_LAYOUT = 9,      // (device) the decoder state does not start at LDS offset 0
 };
 
-constexpr int kNfiWindow = 32768;          // RFC 1951: distances up to 32 KiB
+// RFC 1951 lets a match reach 32 KiB back.  Only the most recent kNfiWindow bytes of the output live in LDS; everything older
+// has been flushed to the stream's output in HBM (it is flushed every few KiB anyway) and a match that reaches further back
+// than the window reads its bytes from there (nfi_copy_match: the far path).  With 8 KiB the whole decoder state is under
+// 16 KiB, so TEN streams run per CU (2560 on the chip) instead of the four a 32 KiB window allows: the decoder is a chain
+// of dependent LDS lookups, latency-bound per stream (tools/lds_chain.hip), so its throughput is the number of streams in
+// flight.  The byte-shuffled planes of model output match against the previous grid row (1-6 KB back): far matches are rare.
+constexpr int kNfiWindow = 8192;
+constexpr uint32_t kNfiMaxDist = 32768;
 constexpr int kNfiRingWords = 256;         // input ring: two halves of 128 words (512 B each); a round ends when it runs low
 constexpr int kNfiHalf = 128;
 constexpr int kNfiLitBits = 10, kNfiDistBits = 8, kNfiClBits = 7;
-constexpr uint32_t kNfiStoredRound = 4096; // bytes of a stored block moved per round
+constexpr uint32_t kNfiStoredRound = 2048; // bytes of a stored block moved per round (8 words per lane in registers: the kernel stays under 170 VGPRs = three waves per SIMD)
 
 // ---- lookup-table entries (32 bits): everything the decoder needs to know about the symbol at the head of the bit buffer
 //   bits  0..3   n      bits of Huffman code this entry consumes (both codes of a literal pair); 0 with bit 31
@@ -90,10 +97,10 @@ constexpr uint32_t kNfiStoredRound = 4096; // bytes of a stored block moved per 
 //   bits  8..23  v      literal (bits 8..15) and second literal (16..23) | length base 3..258 | distance base 1..24577
 //   bits 24..25  lanes  literal entries: mask of the lanes that store (1 = one literal, 3 = two); 0 otherwise
 //   bit  26      bad    a length / distance code the format reserves (286, 287 / 30, 31): an error once met
-//   bit  28      length \
-//   bit  29      end     > anything but a literal makes the entry >= 1 << 28: the literal loop's whole exit test
-//   bit  30      (never in a table: the decoder ORs it into every entry it reads once the round has to end)
-//   bit  31      long   / the code is longer than the table (literal / length table): canonical walk
+//   bit  28      a length code          | anything but a literal makes the entry >= 1 << 28:
+//   bit  29      the end-of-block code  | that is the literal loop's whole exit test
+//   bit  30      never in a table: the decoder ORs it into every entry it reads once the round has to end
+//   bit  31      the code is longer than the table (literal / length table): canonical walk
 constexpr uint32_t kNfiBad = 1u << 26, kNfiIsLen = 1u << 28, kNfiIsEob = 1u << 29, kNfiStop = 1u << 30, kNfiLong = 1u << 31;
 constexpr uint32_t kNfiNotLit = 1u << 28;   // entries below this are literals
 #define NFI_ENTRY(n, x, v, flags) ((uint32_t)(n) | ((uint32_t)(x) << 4) | ((uint32_t)(v) << 8) | (uint32_t)(flags))
@@ -107,7 +114,7 @@ template <int N> struct NfiHuffT {   // canonical code of one alphabet
 typedef NfiHuffT<288> NfiHuff;       // literal / length alphabet
 typedef NfiHuffT<32> NfiHuffSmall;   // distance alphabet (30) and the code-length alphabet (19)
 
-struct NfiCtx {           // lives in LDS (< 40 KiB, so that four fit a CU's 160 KiB): one per wavefront
+struct NfiCtx {           // lives in LDS (< 16 KiB, so that ten fit a CU's 160 KiB): one per wavefront
     uint8_t window[kNfiWindow];
     uint32_t ring[kNfiRingWords];
     uint32_t lit_tab[1 << kNfiLitBits];
@@ -418,8 +425,19 @@ NFI_FN void nfi_build_tables(NfiCtx &c)
 // ---------------------------------------------------------------------------------------------- phase B: the symbol decoder
 // A match is copied 64 bytes per step by all lanes; an overlapping copy (dist < len) repeats the last dist bytes.  A
 // wavefront's LDS instructions execute in issue order, so a step may read what the previous step wrote.
-NFI_FN void nfi_copy_match(NfiCtx &c, uint32_t pos, uint32_t len, uint32_t dist)
+NFI_FN void nfi_copy_match(NfiCtx &c, const uint8_t *flushed_out, uint32_t pos, uint32_t len, uint32_t dist)
 {
+    if (dist > (uint32_t)kNfiWindow) {
+        // far: the source is older than the LDS window, i.e. it was flushed to the stream's output in HBM (a round never
+        // leaves more than kNfiWindow - 258 bytes unflushed, so [pos - dist, pos - dist + len) lies below c.flushed); source
+        // and destination cannot overlap.  The flush released its stores at agent scope; this acquires them.
+#ifndef NFI_HOST
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        NFI_FOR_LANES(j, len)
+            c.window[(pos + (uint32_t)j) & (kNfiWindow - 1)] = flushed_out[pos + (uint32_t)j - dist];
+        return;
+    }
 #ifndef NFI_HOST
     if (len <= (uint32_t)NFI_NLANE && dist >= len) {        // uniform; most matches of real data: one step, no loop
         if ((uint32_t)NFI_LANE < len)
@@ -462,7 +480,7 @@ NFI_FN void nfi_copy_match(NfiCtx &c, uint32_t pos, uint32_t len, uint32_t dist)
 //   * Nothing in the hot path branches on an error: reserved codes carry a flag that is OR-ed up, a distance beyond the
 //     start and an output beyond its length are noticed by sticky compares / at the end of the round.  Every index into
 //     LDS is masked, so garbage decodes garbage safely until the round ends (each symbol consumes at least one bit).
-NFI_FN void nfi_decode_round_cxx(NfiCtx &c, uint32_t out_len)
+NFI_FN void nfi_decode_round_cxx(NfiCtx &c, const uint8_t *flushed_out, uint32_t out_len)
 {
     NfiBits b;
     b.buf = ((uint64_t)NFI_UNI((uint32_t)(c.bitbuf >> 32)) << 32) | NFI_UNI((uint32_t)c.bitbuf);
@@ -471,9 +489,10 @@ NFI_FN void nfi_decode_round_cxx(NfiCtx &c, uint32_t out_len)
     const int last = (int)NFI_UNI(c.last);
     // ring words [b.word, loaded) are valid; one symbol reads at most three of them, the prefetch one more
     const uint32_t word_stop = NFI_UNI(c.loaded) - 5u;
-    // The unflushed output must stay inside the window.  The position is looked at after every match; a run of literals
-    // adds at most 32 bytes per 32-bit refill and the ring holds 256 words, i.e. at most 8 KiB per round.
-    const uint32_t hard_stop = NFI_UNI(c.flushed) + (uint32_t)kNfiWindow - 8192u - 1024u;
+    // The unflushed output must stay inside the window.  The position is looked at after every match and at every refill of
+    // the bit buffer, i.e. at least every 32 bits = 32 bytes of literals (one-bit codes): a round ends at least one match
+    // (258) and one such run short of the window.
+    const uint32_t hard_stop = NFI_UNI(c.flushed) + (uint32_t)kNfiWindow - 512u;
     uint32_t nextw_raw = c.ring[b.word & (kNfiRingWords - 1)];          // not waited for until the next refill
     uint32_t stop = 0;                            // kNfiStop once the round has to end: OR-ed into every entry read
 #define NFI_REFILL()                                                     \
@@ -482,7 +501,7 @@ NFI_FN void nfi_decode_round_cxx(NfiCtx &c, uint32_t out_len)
         b.cnt += 32;                                                     \
         ++b.word;                                                        \
         nextw_raw = c.ring[b.word & (kNfiRingWords - 1)];                \
-        if (b.word >= word_stop) stop = kNfiStop;                        \
+        if (b.word >= word_stop || pos >= hard_stop) stop = kNfiStop;    \
     }
     constexpr uint32_t kMask = (1u << kNfiLitBits) - 1u;
 #define NFI_LOOKUP_RAW() (c.lit_tab[(uint32_t)b.buf & kMask])
@@ -559,9 +578,10 @@ NFI_FN void nfi_decode_round_cxx(NfiCtx &c, uint32_t out_len)
         flags |= d;
         const uint32_t dist = ((d >> 8) & 0xffffu) + nfi_take(b, (int)((d >> 4) & 15u));
         if (dist > pos) err = NFI_ERR_DISTANCE;     // sticky; the copy below reads masked (stale) window bytes
+        if (dist > pos) break;                      // (a far copy would read before the start of the output)
         NFI_REFILL();
         const uint32_t raw_next = NFI_LOOKUP_RAW();
-        nfi_copy_match(c, pos, len, dist);          // len in 3 .. 258, dist in 1 .. 32768
+        nfi_copy_match(c, flushed_out, pos, len, dist);          // len in 3 .. 258, dist in 1 .. 32768
         pos += len;
         if (pos >= hard_stop) stop = kNfiStop;
         e = NFI_UNI(raw_next) | stop;
@@ -592,13 +612,13 @@ NFI_FN void nfi_decode_round_cxx(NfiCtx &c, uint32_t out_len)
 // s44 output position, s45 ring word, s46 stop bit, s47-s49 scratch, s50 len, s51 dist, s52 distance entry, s53 OR of the
 // entries used, s54 error, s55 / s56 word / position limits, s57 reason, s[58:59] saved exec; v40-v48 scratch and constants.
 // ctx sits at LDS address 0 (k_inflate checks): the window is addressed from 0, the tables by immediate offsets.
-NFI_FN void nfi_decode_round_asm(NfiCtx &c, uint32_t out_len)
+NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t out_len)
 {
     uint64_t buf = ((uint64_t)NFI_UNI((uint32_t)(c.bitbuf >> 32)) << 32) | NFI_UNI((uint32_t)c.bitbuf);
     uint32_t cnt = NFI_UNI(c.bitcnt), word = NFI_UNI(c.word), pos = NFI_UNI(c.pos);
     const int last = (int)NFI_UNI(c.last);
     const uint32_t word_stop = NFI_UNI(c.loaded) - 5u;
-    const uint32_t hard_stop = NFI_UNI(c.flushed) + (uint32_t)kNfiWindow - 8192u - 1024u;
+    const uint32_t hard_stop = NFI_UNI(c.flushed) + (uint32_t)kNfiWindow - 512u;
     uint32_t nextw_raw = c.ring[word & (kNfiRingWords - 1)];
     uint32_t stop = pos >= hard_stop ? kNfiStop : 0u;
     uint32_t flags = 0, err = 0, reason = 0, len = 0, dist = 0;
@@ -611,7 +631,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, uint32_t out_len)
         cnt += 32u;                                                      \
         ++word;                                                          \
         nextw_raw = c.ring[word & (kNfiRingWords - 1)];                  \
-        if (word >= word_stop) stop = kNfiStop;                          \
+        if (word >= word_stop || pos >= hard_stop) stop = kNfiStop;      \
     }
     NFI_REFILL_C();
     uint32_t e = NFI_UNI(c.lit_tab[(uint32_t)buf & kMask]) | stop;
@@ -637,7 +657,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, uint32_t out_len)
             "s_mov_b32 s51, 0\n\t"
             "v_mov_b32 v45, 0xffc\n\t"
             "v_mov_b32 v46, 0x3fc\n\t"
-            "v_mov_b32 v47, 0x7fff\n\t"
+            "v_mov_b32 v47, %[wmask]\n\t"
             "v_lshlrev_b32 v48, 3, %[lane]\n\t"
             "v_add_u32 v48, 8, v48\n\t"                      // lane 0 stores bits 8.., lane 1 bits 16..
             "s_mov_b64 exec, 3\n\t"
@@ -719,6 +739,8 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, uint32_t out_len)
             "s_cbranch_scc1 22f\n\t"                         // reason 3: a long copy
             "s_cmp_lt_u32 s51, s50\n\t"
             "s_cbranch_scc1 22f\n\t"                         // reason 3: an overlapping copy
+            "s_cmp_gt_u32 s51, %[win]\n\t"
+            "s_cbranch_scc1 22f\n\t"                         // reason 3: a far copy (source older than the LDS window)
             // ---- next entry requested, then the copy: one step of (len) lanes
             "s_lshl_b32 s47, s40, 2\n\t"
             "v_and_b32 v40, s47, v45\n\t"
@@ -760,6 +782,8 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, uint32_t out_len)
             "ds_read_b32 %[nextw], v40 offset:%[ring]\n\t"
             "s_cmp_ge_u32 s45, s55\n\t"
             "s_cselect_b32 s46, 0x40000000, s46\n\t"         // ring low: the round ends at the next symbol boundary
+            "s_cmp_ge_u32 s44, s56\n\t"
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // window nearly full (a run of literals is only checked here)
             "s_cmp_eq_u32 s57, 11\n\t"
             "s_cbranch_scc1 11b\n\t"
             "s_cmp_eq_u32 s57, 13\n\t"
@@ -796,7 +820,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, uint32_t out_len)
               [nextw] "+v"(nextw_raw)
             : [word_stop] "s"(word_stop), [hard_stop] "s"(hard_stop), [lane] "v"(lane),
               [lit] "n"(__builtin_offsetof(NfiCtx, lit_tab)), [dtab] "n"(__builtin_offsetof(NfiCtx, dist_tab)),
-              [ring] "n"(__builtin_offsetof(NfiCtx, ring))
+              [ring] "n"(__builtin_offsetof(NfiCtx, ring)), [win] "n"(kNfiWindow), [wmask] "n"(kNfiWindow - 1)
             : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52",
               "s53", "s54", "s55", "s56", "s57", "s58", "s59", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48");
         // ---- the block left at a symbol boundary: the rare cases, in the portable version's statements
@@ -853,12 +877,13 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, uint32_t out_len)
             dist = ((d >> 8) & 0xffffu) + ((uint32_t)buf & ((1u << dx) - 1u));
             buf >>= dx;
             cnt -= dx;
-            if (dist > pos) err = NFI_ERR_DISTANCE;
+            if (dist > pos) { err = NFI_ERR_DISTANCE; break; }
             NFI_REFILL_C();
         }
+        if (err) break;                              // (reason 3 with the sticky distance error: no far read before the start)
         // reason 2 (continued) and 3: the copy in its general form, then the next entry
         const uint32_t raw_next = c.lit_tab[(uint32_t)buf & kMask];
-        nfi_copy_match(c, pos, len, dist);
+        nfi_copy_match(c, flushed_out, pos, len, dist);
         pos += len;
         if (pos >= hard_stop) stop = kNfiStop;
         e = NFI_UNI(raw_next) | stop;
@@ -942,14 +967,14 @@ NFI_FN void nfi_stored_round(NfiCtx &c, const uint32_t *words, uint32_t nwords, 
 // write the finished part of the window to the output: whole 4-byte words (dst 4-byte aligned), the tail at the end;
 // the Adler-32 of the stream (RFC 1950) is carried along: for n new bytes b_0..b_{n-1}, a += sum b_i and
 // b += n*a_old + sum (n-i) b_i, both modulo 65521 -- per-lane partial sums, added up by lane 0
-constexpr uint32_t kNfiFlushBytes = 8192;   // flushed when at least this much is new; a round never lets it pass 32 KiB
+constexpr uint32_t kNfiFlushBytes = 2048;   // flushed when at least this much is new; a round never lets it pass the window
 NFI_FN void nfi_flush(NfiCtx &c, uint8_t *dst, bool final)
 {
     if (!final && c.pos - c.flushed < kNfiFlushBytes) return;     // uniform: both are read after a barrier
     const uint32_t from = c.flushed, upto = final ? c.pos : (c.pos & ~3u);
     const uint32_t n = upto - from;
     uint32_t pa = 0;
-    uint64_t pb = 0;                            // 64 bits: the host build runs all of a flush (up to 24 KiB) on one "lane"
+    uint64_t pb = 0;                            // 64 bits: the host build runs all of a flush (up to 8 KiB) on one "lane"
     if (((uintptr_t)dst & 3u) == 0) {           // `from` is a multiple of 4 (every earlier flush ended on one)
         const uint32_t nwords = n >> 2;
         uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + from);
@@ -979,10 +1004,13 @@ NFI_FN void nfi_flush(NfiCtx &c, uint8_t *dst, bool final)
     }
     uint32_t sa = pa, sb = (uint32_t)(pb % 65521u);
 #ifndef NFI_HOST
-    for (int o = 32; o > 0; o >>= 1) {          // wavefront sums (64 x 65520 and 64 x 24 KiB x 255 fit 32 bits)
+    for (int o = 32; o > 0; o >>= 1) {          // wavefront sums (64 x 65520 and 64 x 8 KiB x 255 fit 32 bits)
         sa += __shfl_xor(sa, o, 64);
         sb += __shfl_xor(sb, o, 64);
     }
+#endif
+#ifndef NFI_HOST
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // far matches read these bytes back (other lanes' stores)
 #endif
     if (NFI_LANE == 0) {
         const uint32_t a_old = c.adler_a;
@@ -1038,7 +1066,7 @@ NFI_FN int nfi_inflate_stream(NfiCtx &c, const uint8_t *src, uint32_t in_len, ui
             NFI_SYNC();
             if (!c.err && c.state == 1) nfi_build_tables(c);
         } else if (c.state == 1) {
-            nfi_decode_round(c, out_len);          // all lanes, uniform
+            nfi_decode_round(c, dst, out_len);     // all lanes, uniform
             NFI_SYNC();
             if (!c.err) nfi_flush(c, dst, false);  // uniform; a round that went wrong may have run past out_len
         } else {

@@ -139,12 +139,15 @@ def test_tiled_layouts_with_overhanging_edge_chunks_at_c3_size(real, chunk):
 
 
 def test_more_megabyte_streams_than_resident_wavefronts():
-    """(d) a group larger than nf_inflater_capacity: 1200 streams of 1.47 MB (the four byte planes of shuffled float32
-    levels: noise -> stored blocks, Huffman literals + short matches, long matches) in ONE launch, i.e. more than the 1024
-    decoder wavefronts the chip holds at once -- late workgroups start while early ones are mid-stream."""
+    """(d) a group larger than nf_inflater_capacity: capacity + 300 streams of 1.47 MB in ONE launch -- the four byte planes
+    of shuffled float32 levels (noise -> stored blocks, Huffman literals + short matches, long matches) and, for the far
+    path of the copy, data that repeats with periods of 9 000 .. 30 000 bytes (every match reaches further back than the
+    8 KiB of history kept in LDS and reads the stream's own flushed output in HBM) -- late workgroups start while early
+    ones are mid-stream."""
     from nemoflux_amd.ingest import ChunkDecoder
     dec = ChunkDecoder()
-    assert 256 <= dec.capacity() < 1200
+    cap = dec.capacity()
+    assert cap >= 256
     rng = numpy.random.default_rng(7)
     y = numpy.linspace(-90, 90, NY)[:, None]
     x = numpy.linspace(-180, 180, NX)[None, :]
@@ -156,8 +159,15 @@ def test_more_megabyte_streams_than_resident_wavefronts():
         for p in range(4):
             datas.append(sh[p].copy())
             streams.append(zlib.compress(sh[p].tobytes(), 1 + (k + p) % 9))
-    order = [int(i) for i in rng.integers(0, len(streams), 1200)]
+    for period in (9000, 16385, 23456, 30000, 32768):
+        d = numpy.tile(rng.integers(0, 256, period, dtype=numpy.uint8), NY * NX // period + 1)[:NY * NX].copy()
+        d[::4099] ^= 1                                   # break the matches now and then (literals between far matches)
+        datas.append(d)
+        streams.append(zlib.compress(d.tobytes(), 6))
+    n = cap + 300
+    order = [int(i) for i in rng.integers(0, len(streams), n)]
+    order[:len(streams)] = range(len(streams))           # every kind at least once
     out = dec.decode_streams([streams[i] for i in order], datas[0].size)
-    assert out.shape == (1200, NY * NX)
+    assert out.shape == (n, NY * NX)
     for j, i in enumerate(order):
         assert numpy.array_equal(out[j], datas[i]), (j, i)

@@ -21,7 +21,7 @@ def host_inflate(tmp_path_factory):
     subprocess.check_call(['g++', '-O2', '-Wall', '-shared', '-fPIC', '-o', so,
                            os.path.join(ROOT, 'tests', 'native', 'inflate_host.cpp')])
     lib = ctypes.CDLL(so)
-    assert lib.nfi_host_ctx_bytes() <= 40 * 1024          # one decoder state per wavefront in LDS: four fit a CU's 160 KiB
+    assert lib.nfi_host_ctx_bytes() <= 16 * 1024          # one decoder state per wavefront in LDS: ten fit a CU's 160 KiB
 
     def inflate(comp, out_len, skip=0, readable_extra=16):
         buf = numpy.zeros(len(comp) + skip + 64, numpy.uint8)

@@ -1,0 +1,141 @@
+// lds_chain.hip -- what does one step of a SERIAL decoder cost a lone wavefront on gfx950?  (tuning aid, not product)
+//
+// The DEFLATE decoder of nf_inflate_core.h is a chain of dependent LDS table lookups run by one wavefront per stream, four
+// streams per CU.  This probe times the ingredients of such a chain in isolation -- one workgroup of 64 lanes per CU slot,
+// N dependent iterations, hipEvent time / N -- so that the decoder's design can be priced against the hardware instead of
+// against instruction counts:
+//   lds_scalar    index in an SGPR -> v_mov -> ds_read_b32 -> s_waitcnt -> v_readfirstlane -> s_and   (the decoder's lookup)
+//   lds_vector    index in a VGPR -> ds_read_b32 -> s_waitcnt -> v_and                               (all-VALU chain)
+//   +salu8 / +valu8   the same with 8 more dependent SALU / VALU instructions in the chain
+//   +branch2      the same with two taken s_branch hops per iteration
+//   readlane      v_readlane (lane select in an SGPR) -> s_add -> next lane select: the hop of a register-resident chain
+// Build / run (GPU box):  hipcc -O3 --offload-arch=gfx950 tools/lds_chain.hip -o build/lds_chain && build/lds_chain
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x)                                                                   \
+    do {                                                                           \
+        hipError_t e_ = (x);                                                       \
+        if (e_ != hipSuccess) {                                                    \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 1;                                                              \
+        }                                                                          \
+    } while (0)
+
+constexpr int kTab = 1024;
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_chain(const unsigned *init, int iters, unsigned *out)
+{
+    __shared__ unsigned tab[2 * kTab];    // second half: target of the byte stores of mode 8
+    for (int k = threadIdx.x; k < kTab; k += 64) tab[k] = init[k];
+    __syncthreads();
+    unsigned idx = 0;
+    if (MODE == 0) {            // lds_scalar
+        for (int i = 0; i < iters; ++i)
+            asm volatile("v_mov_b32 v40, %0\n\tds_read_b32 v41, v40\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, v41\n\t"
+                         "s_and_b32 %0, %0, 0xffc"
+                         : "+s"(idx)::"v40", "v41", "memory");
+    } else if (MODE == 1) {     // lds_scalar + 8 SALU
+        for (int i = 0; i < iters; ++i)
+            asm volatile("v_mov_b32 v40, %0\n\tds_read_b32 v41, v40\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, v41\n\t"
+                         "s_and_b32 %0, %0, 0xffc\n\ts_add_u32 %0, %0, 4\n\ts_sub_u32 %0, %0, 4\n\ts_add_u32 %0, %0, 8\n\t"
+                         "s_sub_u32 %0, %0, 8\n\ts_add_u32 %0, %0, 4\n\ts_sub_u32 %0, %0, 4\n\ts_add_u32 %0, %0, 8\n\ts_sub_u32 %0, %0, 8"
+                         : "+s"(idx)::"v40", "v41", "scc", "memory");
+    } else if (MODE == 2) {     // lds_scalar + two taken branches
+        for (int i = 0; i < iters; ++i)
+            asm volatile("v_mov_b32 v40, %0\n\tds_read_b32 v41, v40\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, v41\n\t"
+                         "s_and_b32 %0, %0, 0xffc\n\ts_branch 1f\n2:\n\ts_branch 3f\n1:\n\ts_branch 2b\n3:"
+                         : "+s"(idx)::"v40", "v41", "memory");
+    } else if (MODE == 3) {     // lds_vector
+        unsigned v = 0;
+        for (int i = 0; i < iters; ++i)
+            asm volatile("ds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)\n\tv_and_b32 %0, 0xffc, %0" : "+v"(v)::"memory");
+        idx = v;
+    } else if (MODE == 4) {     // lds_vector + 8 VALU
+        unsigned v = 0;
+        for (int i = 0; i < iters; ++i)
+            asm volatile("ds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)\n\tv_and_b32 %0, 0xffc, %0\n\tv_add_u32 %0, 4, %0\n\t"
+                         "v_subrev_u32 %0, 4, %0\n\tv_add_u32 %0, 8, %0\n\tv_subrev_u32 %0, 8, %0\n\tv_add_u32 %0, 4, %0\n\t"
+                         "v_subrev_u32 %0, 4, %0\n\tv_add_u32 %0, 8, %0\n\tv_subrev_u32 %0, 8, %0"
+                         : "+v"(v)::"memory");
+        idx = v;
+    } else if (MODE == 5) {     // readlane hop: lane select from the previous hop
+        unsigned v = (threadIdx.x * 7 + 3) & 63;     // a permutation of the lanes
+        unsigned s = 0;
+        for (int i = 0; i < iters; ++i)
+            asm volatile("s_nop 4\n\tv_readlane_b32 %0, %1, %0\n\ts_and_b32 %0, %0, 63" : "+s"(s) : "v"(v));
+        idx = s;
+    } else if (MODE == 6) {     // SALU only: 16 dependent adds
+        for (int i = 0; i < iters; ++i)
+            asm volatile("s_add_u32 %0, %0, 4\n\ts_sub_u32 %0, %0, 3\n\ts_add_u32 %0, %0, 4\n\ts_sub_u32 %0, %0, 3\n\t"
+                         "s_add_u32 %0, %0, 4\n\ts_sub_u32 %0, %0, 3\n\ts_add_u32 %0, %0, 4\n\ts_sub_u32 %0, %0, 3\n\t"
+                         "s_add_u32 %0, %0, 4\n\ts_sub_u32 %0, %0, 3\n\ts_add_u32 %0, %0, 4\n\ts_sub_u32 %0, %0, 3\n\t"
+                         "s_add_u32 %0, %0, 4\n\ts_sub_u32 %0, %0, 3\n\ts_add_u32 %0, %0, 4\n\ts_sub_u32 %0, %0, 3"
+                         : "+s"(idx)::"scc");
+    } else if (MODE == 7) {     // VALU only: 16 dependent adds
+        unsigned v = threadIdx.x;
+        for (int i = 0; i < iters; ++i)
+            asm volatile("v_add_u32 %0, 4, %0\n\tv_subrev_u32 %0, 3, %0\n\tv_add_u32 %0, 4, %0\n\tv_subrev_u32 %0, 3, %0\n\t"
+                         "v_add_u32 %0, 4, %0\n\tv_subrev_u32 %0, 3, %0\n\tv_add_u32 %0, 4, %0\n\tv_subrev_u32 %0, 3, %0\n\t"
+                         "v_add_u32 %0, 4, %0\n\tv_subrev_u32 %0, 3, %0\n\tv_add_u32 %0, 4, %0\n\tv_subrev_u32 %0, 3, %0\n\t"
+                         "v_add_u32 %0, 4, %0\n\tv_subrev_u32 %0, 3, %0\n\tv_add_u32 %0, 4, %0\n\tv_subrev_u32 %0, 3, %0"
+                         : "+v"(v));
+        idx = v;
+    } else if (MODE == 8) {     // the decoder's literal step, verbatim in shape (lookup, byte store, exit test), on a table of literals
+        unsigned long long buf = 0x123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        for (int i = 0; i < iters; ++i)
+            asm volatile("s_and_b32 s47, %1, 15\n\ts_lshr_b64 %0, %0, s47\n\ts_lshl_b32 s47, %2, 2\n\tv_mov_b32 v40, s47\n\t"
+                         "v_and_b32 v40, 0xffc, v40\n\tds_read_b32 v41, v40\n\tv_mov_b32 v42, %2\n\tv_and_b32 v42, 0xfff, v42\n\t"
+                         "v_mov_b32 v44, %1\n\tds_write_b8 v42, v44 offset:4096\n\ts_add_u32 %2, %2, 1\n\ts_waitcnt lgkmcnt(0)\n\t"
+                         "v_readfirstlane_b32 %1, v41\n\ts_or_b32 %1, %1, 5"
+                         : "+s"(buf), "+s"(e), "+s"(pos)::"s47", "v40", "v41", "v42", "v44", "scc", "memory");
+        idx = e + pos;
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = idx;
+}
+
+template <int MODE>
+static int run(const char *name, const unsigned *d_init, unsigned *d_out, int blocks, int iters, double per_iter_instr)
+{
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(k_chain<MODE>, dim3(blocks), dim3(64), 0, 0, d_init, 1000, d_out);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL(k_chain<MODE>, dim3(blocks), dim3(64), 0, 0, d_init, iters, d_out);
+    CHECK(hipEventRecord(b));
+    CHECK(hipDeviceSynchronize());
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    printf("%-34s %5d workgroups: %8.1f ns per iteration (%4.1f instructions in the chain)\n", name, blocks, ms * 1e6 / iters,
+           per_iter_instr);
+    return 0;
+}
+
+int main()
+{
+    std::vector<unsigned> init(kTab);
+    for (int k = 0; k < kTab; ++k) init[k] = ((k * 37 + 11) % kTab) * 4 | 0x01000005u;   // a permutation, as byte offsets
+    unsigned *d_init, *d_out;
+    CHECK(hipMalloc(&d_init, sizeof(unsigned) * kTab));
+    CHECK(hipMalloc(&d_out, sizeof(unsigned) * 4096));
+    CHECK(hipMemcpy(d_init, init.data(), sizeof(unsigned) * kTab, hipMemcpyHostToDevice));
+    const int iters = 200000;
+    for (int blocks : {1, 1024}) {          // one lone wavefront; four per CU on all 256 CUs (the decoder's occupancy)
+        if (run<0>("lds_scalar", d_init, d_out, blocks, iters, 5)) return 1;
+        if (run<1>("lds_scalar +8 salu", d_init, d_out, blocks, iters, 13)) return 1;
+        if (run<2>("lds_scalar +3 taken branches", d_init, d_out, blocks, iters, 8)) return 1;
+        if (run<3>("lds_vector", d_init, d_out, blocks, iters, 3)) return 1;
+        if (run<4>("lds_vector +8 valu", d_init, d_out, blocks, iters, 11)) return 1;
+        if (run<5>("readlane hop (+s_nop 4)", d_init, d_out, blocks, iters, 3)) return 1;
+        if (run<6>("16 dependent salu", d_init, d_out, blocks, iters, 16)) return 1;
+        if (run<7>("16 dependent valu", d_init, d_out, blocks, iters, 16)) return 1;
+        if (run<8>("decoder literal step", d_init, d_out, blocks, iters, 14)) return 1;
+    }
+    return 0;
+}
