@@ -253,7 +253,8 @@ int nf_rows_allreduce(void *rccl_comm, double *rows_dev, size_t n, void *hip_str
  * xarray inflate one time step on the host at every update (field.py:149: nc[name][timeIndex, :, :, :]).  Here the
  * compressed chunks are handed over as they sit in the file and are inflated on the device, one wavefront per chunk
  * (RFC 1950/1951 decoder with the Adler-32 check, then the inverse of HDF5's shuffle filter), into out_dev.
- *   comp_host  : host buffer (pinned for an asynchronous copy) holding the compressed chunks, comp_bytes long
+ *   comp_host  : host buffer (pinned for an asynchronous copy) holding the compressed chunks, comp_bytes long; NULL = the
+ *                bytes a preceding nf_inflater_upload of the same comp_bytes put in HBM
  *   in_off/in_len[i] : where chunk i's zlib stream sits in comp_host
  *   chunk_bytes      : decoded size of every chunk = cz*cy*cx*elem_size (checked against what each stream inflates to)
  *   elem_size        : 4 or 8 (1 for raw bytes); shuffled != 0: the chunks went through HDF5's shuffle filter
@@ -268,6 +269,10 @@ int nf_inflater_new(nf_inflater **self);
 int nf_inflater_del(nf_inflater **self);
 /* how many chunks the device decodes at once (resident decoder wavefronts): callers batch that many per nf_inflater_run */
 int nf_inflater_capacity(int *streams);
+/* Early upload: copy comp_bytes of compressed chunks to HBM on the inflater's own stream, complete at return.  Meant for a
+ * staging thread that has just gathered the NEXT group while the GPU still decodes this one (the copy then runs under the
+ * decode); a following nf_inflater_run with comp_host = NULL and the same comp_bytes decodes what was uploaded. */
+int nf_inflater_upload(nf_inflater **self, const void *comp_host, size_t comp_bytes);
 int nf_inflater_run(nf_inflater **self, const void *comp_host, size_t comp_bytes, const long long *in_off,
                     const long long *in_len, int nchunks, long long chunk_bytes, int elem_size, int shuffled,
                     const long long *chunk_dims, const long long *slab_dims, const long long *origin, void *out_dev,

@@ -17,6 +17,12 @@
 #include "nf_common.h"
 #include "nf_inflate_core.h"
 
+#define NF_TRY_RC(call)                \
+    do {                              \
+        int rc_ = (call);             \
+        if (rc_ != NF_OK) return rc_; \
+    } while (0)
+
 namespace nf {
 
 struct InflateJob {
@@ -144,16 +150,55 @@ struct Inflater {
     InflateJob *d_jobs = nullptr;
     int *d_status = nullptr;
     size_t comp_cap = 0, tmp_cap = 0, jobs_cap = 0;
+    // early upload (nf_inflater_upload, typically from a staging thread while the GPU decodes another group)
+    hipStream_t copy_stream = nullptr;
+    size_t uploaded = 0;          // bytes of compressed data sitting in d_comp, 0 = none
+    int device = -1;
     void release()
     {
         for (void *p : {(void *)d_comp, (void *)d_tmp, (void *)d_jobs, (void *)d_status})
             if (p) (void)hipFree(p);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        copy_stream = nullptr;
         d_comp = d_tmp = nullptr;
         d_jobs = nullptr;
         d_status = nullptr;
-        comp_cap = tmp_cap = jobs_cap = 0;
+        comp_cap = tmp_cap = jobs_cap = uploaded = 0;
     }
 };
+
+static size_t comp_padded(size_t comp_bytes) { return ((comp_bytes + 3) & ~(size_t)3) + 64; }   // whole words + slack the ring may read
+
+static int comp_reserve(Inflater *h, size_t comp_pad)
+{
+    if (h->comp_cap < comp_pad) {
+        if (h->d_comp) (void)hipFree(h->d_comp);
+        h->d_comp = nullptr;
+        h->comp_cap = 0;
+        h->uploaded = 0;
+        NF_HIP(hipMalloc((void **)&h->d_comp, comp_pad));
+        h->comp_cap = comp_pad;
+    }
+    return NF_OK;
+}
+
+// compressed bytes -> HBM, on the inflater's own stream, complete at return: the call a staging thread makes while the GPU
+// is busy with the previous group (HIP calls are thread-safe; the thread adopts the inflater's device)
+int inflater_upload(Inflater *h, const void *comp_host, size_t comp_bytes)
+{
+    NF_REQUIRE(h && comp_host && comp_bytes > 0, NF_ERR_ARG, "inflate upload: null argument");
+    if (h->device >= 0) NF_HIP(hipSetDevice(h->device));
+    if (!h->copy_stream) NF_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    const size_t comp_pad = comp_padded(comp_bytes);
+    h->uploaded = 0;
+    NF_TRY_RC(comp_reserve(h, comp_pad));
+    const size_t tail = comp_bytes & ~(size_t)3;
+    NF_HIP(hipMemsetAsync(h->d_comp + tail, 0, comp_pad - tail, h->copy_stream));
+    NF_HIP(hipMemcpyAsync(h->d_comp, comp_host, comp_bytes, hipMemcpyHostToDevice, h->copy_stream));
+    NF_HIP(hipStreamSynchronize(h->copy_stream));
+    h->uploaded = comp_bytes;
+    return NF_OK;
+}
 
 static const char *inflate_error_name(int rc)
 {
@@ -175,8 +220,10 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
                  int n, long long chunk_bytes, int elem_size, int shuffled, const long long *chunk_dims,
                  const long long *slab_dims, const long long *origin, void *out_dev, hipStream_t s, int *status_host)
 {
-    NF_REQUIRE(h && chunk_dims && slab_dims && (n == 0 || (comp_host && in_off && in_len && origin && out_dev)), NF_ERR_ARG,
+    NF_REQUIRE(h && chunk_dims && slab_dims && (n == 0 || (in_off && in_len && origin && out_dev)), NF_ERR_ARG,
                "inflate: null argument");
+    NF_REQUIRE(n == 0 || comp_host || (h->uploaded == comp_bytes && comp_bytes > 0), NF_ERR_STATE,
+               "inflate: no compressed buffer given and none of that size uploaded (nf_inflater_upload)");
     NF_REQUIRE(elem_size == 1 || elem_size == 4 || elem_size == 8, NF_ERR_ARG, "inflate: element size must be 1, 4 or 8");
     NF_REQUIRE(!(shuffled && elem_size == 1), NF_ERR_ARG, "inflate: single bytes cannot be shuffled");
     for (int k = 0; k < 3; ++k)
@@ -201,15 +248,9 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
         jobs[i] = InflateJob{(unsigned long long)in_off[i], (unsigned)in_len[i], (unsigned)origin[3 * i], (unsigned)origin[3 * i + 1],
                              (unsigned)origin[3 * i + 2]};
     }
-    const size_t comp_pad = ((comp_bytes + 3) & ~(size_t)3) + 64;      // whole words + slack the ring may read (never interprets)
+    const size_t comp_pad = comp_padded(comp_bytes);
     const size_t tmp_bytes = (size_t)chunk_bytes * (size_t)n;
-    if (h->comp_cap < comp_pad) {
-        if (h->d_comp) (void)hipFree(h->d_comp);
-        h->d_comp = nullptr;
-        h->comp_cap = 0;
-        NF_HIP(hipMalloc((void **)&h->d_comp, comp_pad));
-        h->comp_cap = comp_pad;
-    }
+    if (comp_host) NF_TRY_RC(comp_reserve(h, comp_pad));
     if (h->tmp_cap < tmp_bytes) {
         if (h->d_tmp) (void)hipFree(h->d_tmp);
         h->d_tmp = nullptr;
@@ -227,9 +268,12 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
         NF_HIP(hipMalloc((void **)&h->d_status, sizeof(int) * (size_t)n));
         h->jobs_cap = (size_t)n;
     }
-    const size_t tail = comp_bytes & ~(size_t)3;                        // zero the last partial word and the padding behind the data
-    NF_HIP(hipMemsetAsync(h->d_comp + tail, 0, comp_pad - tail, s));
-    NF_HIP(hipMemcpyAsync(h->d_comp, comp_host, comp_bytes, hipMemcpyHostToDevice, s));
+    if (comp_host) {
+        const size_t tail = comp_bytes & ~(size_t)3;                    // zero the last partial word and the padding behind the data
+        h->uploaded = 0;
+        NF_HIP(hipMemsetAsync(h->d_comp + tail, 0, comp_pad - tail, s));
+        NF_HIP(hipMemcpyAsync(h->d_comp, comp_host, comp_bytes, hipMemcpyHostToDevice, s));
+    }
     NF_HIP(hipMemcpyAsync(h->d_jobs, jobs.data(), sizeof(InflateJob) * (size_t)n, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_inflate, dim3((unsigned)n), dim3(64), 0, s, h->d_comp, (unsigned long long)comp_pad,
                        h->d_jobs, n, h->d_tmp, (unsigned)chunk_bytes, h->d_status);
@@ -278,12 +322,33 @@ int nf_inflater_new(nf_inflater **self)
         set_error("nf_inflater_new: null argument");
         return NF_ERR_ARG;
     }
-    *self = reinterpret_cast<nf_inflater *>(new (std::nothrow) Inflater());
-    if (!*self) {
+    Inflater *h = new (std::nothrow) Inflater();
+    *self = reinterpret_cast<nf_inflater *>(h);
+    if (!h) {
         set_error("out of host memory");
         return NF_ERR_HOST;
     }
+    if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;      // no GPU: every run fails loudly later
     return NF_OK;
+}
+
+int nf_inflater_upload(nf_inflater **self, const void *comp_host, size_t comp_bytes)
+{
+    if (!self || !*self) {
+        set_error("nf_inflater_upload: null handle");
+        return NF_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no usable AMD GPU (hipGetDeviceCount); nemoflux_amd has no CPU fallback");
+        return NF_ERR_NO_DEVICE;
+    }
+    try {
+        return inflater_upload(reinterpret_cast<Inflater *>(*self), comp_host, comp_bytes);
+    } catch (...) {
+        set_error("nf_inflater_upload: out of host memory");
+        return NF_ERR_HOST;
+    }
 }
 
 /* wavefronts (= chunks) the device decodes at once: resident k_inflate workgroups per CU (LDS-limited) x CUs */

@@ -78,18 +78,24 @@ enum {
     NFI_ERR_LAYOUT = 9,      // (device) the decoder state does not start at LDS offset 0
 };
 
-// RFC 1951 lets a match reach 32 KiB back.  Only the most recent kNfiWindow bytes of the output live in LDS; everything older
-// has been flushed to the stream's output in HBM (it is flushed every few KiB anyway) and a match that reaches further back
-// than the window reads its bytes from there (nfi_copy_match: the far path).  With 8 KiB the whole decoder state is under
-// 16 KiB, so TEN streams run per CU (2560 on the chip) instead of the four a 32 KiB window allows: the decoder is a chain
-// of dependent LDS lookups, latency-bound per stream (tools/lds_chain.hip), so its throughput is the number of streams in
-// flight.  The byte-shuffled planes of model output match against the previous grid row (1-6 KB back): far matches are rare.
-constexpr int kNfiWindow = 8192;
+// RFC 1951 lets a match reach 32 KiB back: the LDS window holds the last kNfiWindow = 32 KiB of output, which makes the
+// decoder state 39 KiB and FOUR streams per CU.  The window may be built smaller (a power of two >= 4 KiB): everything older
+// than it has been flushed to the stream's output in HBM, and a match that reaches further back reads its bytes from there
+// (nfi_copy_match: the far path).  Measured with 8 KiB (ten streams per CU, round 3, profiles/r03_inflate_window.txt): the
+// per-stream rate HALVES -- zlib's matches in byte-shuffled model output reach back tens of grid rows, a far match costs
+// 0.6-1.5 us (acquire + a round trip to L2 / HBM) against 0.3 us in LDS -- which eats the 2.5x in streams, and a group
+// must hold 2560 chunks to fill the chip.  Not kept; the far path stays (and stays tested:
+// tests/test_inflate_cpu.py runs the host build with -DNFI_WINDOW=8192 as well).
+#ifndef NFI_WINDOW
+#define NFI_WINDOW 32768
+#endif
+constexpr int kNfiWindow = NFI_WINDOW;
+static_assert(kNfiWindow >= 4096 && kNfiWindow <= 32768 && (kNfiWindow & (kNfiWindow - 1)) == 0, "window: a power of two, 4 .. 32 KiB");
 constexpr uint32_t kNfiMaxDist = 32768;
 constexpr int kNfiRingWords = 256;         // input ring: two halves of 128 words (512 B each); a round ends when it runs low
 constexpr int kNfiHalf = 128;
 constexpr int kNfiLitBits = 10, kNfiDistBits = 8, kNfiClBits = 7;
-constexpr uint32_t kNfiStoredRound = 2048; // bytes of a stored block moved per round (8 words per lane in registers: the kernel stays under 170 VGPRs = three waves per SIMD)
+constexpr uint32_t kNfiStoredRound = 4096; // bytes of a stored block moved per round (16 words per lane, all loads in flight)
 
 // ---- lookup-table entries (32 bits): everything the decoder needs to know about the symbol at the head of the bit buffer
 //   bits  0..3   n      bits of Huffman code this entry consumes (both codes of a literal pair); 0 with bit 31
@@ -114,7 +120,7 @@ template <int N> struct NfiHuffT {   // canonical code of one alphabet
 typedef NfiHuffT<288> NfiHuff;       // literal / length alphabet
 typedef NfiHuffT<32> NfiHuffSmall;   // distance alphabet (30) and the code-length alphabet (19)
 
-struct NfiCtx {           // lives in LDS (< 16 KiB, so that ten fit a CU's 160 KiB): one per wavefront
+struct NfiCtx {           // lives in LDS (< 40 KiB, so that four fit a CU's 160 KiB): one per wavefront
     uint8_t window[kNfiWindow];
     uint32_t ring[kNfiRingWords];
     uint32_t lit_tab[1 << kNfiLitBits];
@@ -967,7 +973,7 @@ NFI_FN void nfi_stored_round(NfiCtx &c, const uint32_t *words, uint32_t nwords, 
 // write the finished part of the window to the output: whole 4-byte words (dst 4-byte aligned), the tail at the end;
 // the Adler-32 of the stream (RFC 1950) is carried along: for n new bytes b_0..b_{n-1}, a += sum b_i and
 // b += n*a_old + sum (n-i) b_i, both modulo 65521 -- per-lane partial sums, added up by lane 0
-constexpr uint32_t kNfiFlushBytes = 2048;   // flushed when at least this much is new; a round never lets it pass the window
+constexpr uint32_t kNfiFlushBytes = kNfiWindow / 4;   // flushed when at least this much is new; a round never lets it pass the window
 NFI_FN void nfi_flush(NfiCtx &c, uint8_t *dst, bool final)
 {
     if (!final && c.pos - c.flushed < kNfiFlushBytes) return;     // uniform: both are read after a barrier

@@ -124,16 +124,21 @@ class ChunkDecoder(object):
             worst = max(worst, sum((c[1] + 7) & ~7 for c in plan['chunks']))
         return worst
 
-    def decode(self, staged, out_ptr, stream=None):
-        """H2D of the gathered bytes, inflate + un-shuffle + placement on the device into the slab at out_ptr.  Synchronous;
-        raises NemofluxError naming the first malformed chunk."""
+    def upload(self, pinned, used):
+        """Copy the gathered compressed bytes to HBM now, on the decoder's own stream (complete at return): what the staging
+        thread does with the NEXT group while the GPU decodes this one.  decode(..., uploaded=True) then skips the copy."""
+        check(lib.nf_inflater_upload(ctypes.byref(self._h), ctypes.c_void_p(pinned.ptr), int(used)))
+
+    def decode(self, staged, out_ptr, stream=None, uploaded=False):
+        """H2D of the gathered bytes (unless upload() already put them in HBM), inflate + un-shuffle + placement on the device
+        into the slab at out_ptr.  Synchronous; raises NemofluxError naming the first malformed chunk."""
         n = len(staged.in_len)
         plan = staged.plan
         status = numpy.zeros(max(n, 1), numpy.int32)
         ll = _lib.c_ll_p
         cd = numpy.array(plan['chunk_dims'], numpy.int64)
         sd = numpy.array(plan['slab_dims'], numpy.int64)
-        check(lib.nf_inflater_run(ctypes.byref(self._h), ctypes.c_void_p(staged.pinned.ptr), int(staged.used),
+        check(lib.nf_inflater_run(ctypes.byref(self._h), None if uploaded else ctypes.c_void_p(staged.pinned.ptr), int(staged.used),
                                   staged.in_off.ctypes.data_as(ll), staged.in_len.ctypes.data_as(ll), n,
                                   int(plan['chunk_bytes']), int(plan['elem_size']), int(plan['shuffled']),
                                   cd.ctypes.data_as(ll), sd.ctypes.data_as(ll), staged.origin.ctypes.data_as(ll),

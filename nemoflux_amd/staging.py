@@ -8,7 +8,8 @@ the next ones in the other (fluxviz's 't' key and fluxplot's loop walk the steps
   read / inflated by nemoflux_amd.hdf5min on all host cores into a pinned buffer and handed to the engine as host memory
   (or copied into the slab when the other variable is on the device path).
 * device path -- deflated (+ shuffled) HDF5 chunks, what netCDF-4 / XIOS write: the host thread only GATHERS the compressed
-  chunks of a group of G steps into pinned memory; the caller's thread copies them to HBM and nf_inflate.hip inflates them
+  chunks of a group of G steps into pinned memory and, when it runs in the background, copies them to HBM at once on the
+  decoder's own stream (the copy then runs under the GPU's decode of the previous group); nf_inflate.hip inflates them
   there, one wavefront per chunk, all G x 2 x (chunks per step) of them in one launch.  The decoder is serial inside a
   chunk, so its throughput comes from the number of chunks in flight (4 per CU = 1024 on the chip): G is chosen to get
   there.
@@ -35,6 +36,7 @@ class StepStager(object):
         self._host_array = host_array
         self._prefetch_on = bool(prefetch)
         self.decoder = None
+        self._early_upload = os.environ.get('NF_EARLY_UPLOAD', '1') != '0'
         self.comp_bytes = [None, None]            # staging size per step of a variable on the device path
         self.group = 1
         if gpu_decode and os.environ.get('NF_GPU_INFLATE', '1') != '0':
@@ -45,6 +47,9 @@ class StepStager(object):
             need = [ChunkDecoder.staging_bytes(s, nt) if self._device_ok(s) else None for s in self.src]
             if any(n is not None for n in need):
                 self.decoder = ChunkDecoder()
+                # one decoder per slot: its compressed-bytes buffer in HBM is filled by the staging thread (early upload)
+                # while the other slot's group is being decoded
+                self._decoders = [self.decoder, ChunkDecoder()]
                 self.comp_bytes = need
                 per_step = sum(len(s.device_plan(0)['chunks']) for s, n in zip(self.src, need) if n is not None)
                 g = max(1, ChunkDecoder.capacity() // max(per_step, 1))    # resident decoder wavefronts: 4 per CU
@@ -113,6 +118,10 @@ class StepStager(object):
         import threading
         nthreads = None if threading.current_thread() is threading.main_thread() else 4
         b['staged'] = self.decoder.gather_many(items, b['comp'], 2 * (g1 - g0) * self.nz, nthreads) if items else []
+        b['early'] = False
+        if items and nthreads is not None and self._early_upload:     # background thread: the H2D copy runs under the GPU's
+            self._decoders[slot].upload(b['comp'], b['staged'][0].used)  # work on the other slot's group
+            b['early'] = True
         self._uploaded[slot] = (-1, -1)
         self._range[slot] = (g0, g1)
         if _TRACE:
@@ -127,7 +136,7 @@ class StepStager(object):
         import time
         t_start = time.perf_counter()
         for staged in b['staged']:
-            self.decoder.decode(staged, b['slab'].ptr)
+            self._decoders[slot].decode(staged, b['slab'].ptr, uploaded=b.get('early', False))
         if _TRACE:
             print(f'# staging: device half of steps [{g0},{g1}) {1e3 * (time.perf_counter() - t_start):.1f} ms '
                   f'({sum(len(x.in_len) for x in b["staged"])} chunks, {sum(int(x.used) for x in b["staged"][:1]) / 1e6:.0f} MB compressed)',

@@ -21,3 +21,5 @@ for k, r in enumerate(rows):
 PY
 python tools/filebacked_timing.py 1440 1021 75 12 > gpurun_out/$R/filebacked_timing.txt 2>&1 || { tail -20 gpurun_out/$R/filebacked_timing.txt; exit 1; }
 cat gpurun_out/$R/filebacked_timing.txt
+NF_STAGE_TRACE=1 python tools/filebacked_timing.py 1440 1021 75 12 2>&1 | grep -a 'staging:' | tail -14 > gpurun_out/$R/stage_trace.txt || true
+cat gpurun_out/$R/stage_trace.txt

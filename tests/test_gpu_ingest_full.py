@@ -77,11 +77,14 @@ def test_c3_levels_inflate_bit_identical_to_zlib(c3):
     slab.free()
 
 
-@pytest.mark.parametrize('prefetch', [True, False])
-def test_c3_file_backed_field_against_the_oracle(c3, prefetch, oracle):
+@pytest.mark.parametrize('prefetch, group', [(True, None), (False, None), (True, 1)])
+def test_c3_file_backed_field_against_the_oracle(c3, prefetch, group, oracle, monkeypatch):
     """(b) the file-backed Field on that image (device inflate, groups of time steps, the pipelined gather when prefetch is
-    on) against the CPU ORACLE on the decoded values: every step's full (ncell, 4) field bit for bit, the transect totals
-    to rounding -- in file order, out of order, and through computeAll."""
+    on; with groups of ONE step the staging thread also uploads the next step's compressed bytes while the GPU decodes
+    this one) against the CPU ORACLE on the decoded values: every step's full (ncell, 4) field bit for bit, the transect
+    totals to rounding -- in file order, out of order, and through computeAll."""
+    if group is not None:
+        monkeypatch.setenv('NF_INFLATE_GROUP', str(group))
     import contextlib
     import io as _io
     from nemoflux_amd.field import Field
@@ -92,7 +95,7 @@ def test_c3_file_backed_field_against_the_oracle(c3, prefetch, oracle):
     with contextlib.redirect_stdout(_io.StringIO()):
         ff = Field.fromArrays(blon, blat, dg.deptht_bounds, lu, lv, tr, fill_value=1.e20, prefetch=prefetch)
     st = ff._stager
-    assert st.on_device and st.comp_bytes[0] is not None and st.comp_bytes[1] is not None and st.group == nt
+    assert st.on_device and st.comp_bytes[0] is not None and st.comp_bytes[1] is not None and st.group == (group or nt)
     pts = oracle.assemble_points(blon, blat)
     th = dg.zbot - dg.ztop
     ows = [oracle.polyline_weights(pts, xyz) for xyz in tr]
@@ -109,6 +112,8 @@ def test_c3_file_backed_field_against_the_oracle(c3, prefetch, oracle):
     st.invalidate()                              # a second pass over the file: the staging buffers are re-used
     ff._lazy_step = -1
     tot, _ = ff.computeAll()
+    if group == 1 and prefetch:                  # steps 1 and 2 were gathered AND uploaded by the staging thread
+        assert st._slots[0]['early'] or st._slots[1]['early']
     for t in range(nt):
         assert numpy.abs(tot[t] - want[t]).max() <= 1e-12 * max(1.0, numpy.abs(want[t]).max()) * 10
 

@@ -15,13 +15,16 @@ import pytest
 from conftest import ROOT
 
 
-@pytest.fixture(scope='module')
-def host_inflate(tmp_path_factory):
-    so = str(tmp_path_factory.mktemp('nfi') / 'libnfi_host.so')
-    subprocess.check_call(['g++', '-O2', '-Wall', '-shared', '-fPIC', '-o', so,
-                           os.path.join(ROOT, 'tests', 'native', 'inflate_host.cpp')])
+@pytest.fixture(scope='module', params=[32768, 8192], ids=['window32k', 'window8k'])
+def host_inflate(request, tmp_path_factory):
+    """the product's 32 KiB LDS window, and an 8 KiB one: matches that reach further back then take the far path of the
+    copy (history read from the stream's flushed output instead of the window)"""
+    so = str(tmp_path_factory.mktemp('nfi') / f'libnfi_host_{request.param}.so')
+    subprocess.check_call(['g++', '-O2', '-Wall', '-Wno-unknown-pragmas', f'-DNFI_WINDOW={request.param}', '-shared', '-fPIC',
+                           '-o', so, os.path.join(ROOT, 'tests', 'native', 'inflate_host.cpp')])
     lib = ctypes.CDLL(so)
-    assert lib.nfi_host_ctx_bytes() <= 16 * 1024          # one decoder state per wavefront in LDS: ten fit a CU's 160 KiB
+    # one decoder state per wavefront in LDS: four fit a CU's 160 KiB (ten with the small window)
+    assert lib.nfi_host_ctx_bytes() <= (40 if request.param == 32768 else 16) * 1024
 
     def inflate(comp, out_len, skip=0, readable_extra=16):
         buf = numpy.zeros(len(comp) + skip + 64, numpy.uint8)
