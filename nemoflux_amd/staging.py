@@ -37,6 +37,7 @@ class StepStager(object):
         self._prefetch_on = bool(prefetch)
         self.decoder = None
         self._early_upload = os.environ.get('NF_EARLY_UPLOAD', '1') != '0'
+        self._bg_threads = int(os.environ.get('NF_GATHER_THREADS_BG', 8))
         self.comp_bytes = [None, None]            # staging size per step of a variable on the device path
         self.group = 1
         if gpu_decode and os.environ.get('NF_GPU_INFLATE', '1') != '0':
@@ -113,10 +114,10 @@ class StepStager(object):
                     items.append((self.src[k].raw_bytes(), self.src[k].device_plan(t), ((t - g0) * 2 + k) * self.nz))
                 else:
                     self._read_host(self.src[k], t, b['host'][k][t - g0])
-        # in the background the gather shares the host's memory system with the H2D copies and launches of the caller's
-        # thread: measured, 4 copy threads there and 16 when the caller itself waits for the gather are the best of both
+        # in the background the gather shares the host's memory system with whatever the caller's thread copies; with the
+        # early upload the caller's thread copies nothing in the steady state (NF_GATHER_THREADS_BG, default 8)
         import threading
-        nthreads = None if threading.current_thread() is threading.main_thread() else 4
+        nthreads = None if threading.current_thread() is threading.main_thread() else self._bg_threads
         b['staged'] = self.decoder.gather_many(items, b['comp'], 2 * (g1 - g0) * self.nz, nthreads) if items else []
         b['early'] = False
         if items and nthreads is not None and self._early_upload:     # background thread: the H2D copy runs under the GPU's
@@ -179,6 +180,10 @@ class StepStager(object):
         b = self._slots[slot]
         g0 = self._range[slot][0]
         if self.on_device:
+            # the NEXT group's host half (gather + early upload) starts now, on the staging thread, so that it runs under
+            # this group's device half (copy + inflate, > 100 ms) and not only under its few milliseconds of flux kernels
+            if self._uploaded[slot] != self._range[slot]:
+                self.prefetch(self.next_after(t))
             self._upload(slot)
             base = b['slab'].ptr + (t - g0) * 2 * self.step_bytes
             return base, base + self.step_bytes, 1

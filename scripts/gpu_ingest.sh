@@ -19,7 +19,7 @@ for k, r in enumerate(rows):
         print(f"{names[k // 2]:32s} 256 streams: k_inflate {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6:8.2f} ms"
               f"   k_place {(int(place[k]['End_Timestamp']) - int(place[k]['Start_Timestamp'])) / 1e6:6.2f} ms")
 PY
-python tools/filebacked_timing.py 1440 1021 75 12 > gpurun_out/$R/filebacked_timing.txt 2>&1 || { tail -20 gpurun_out/$R/filebacked_timing.txt; exit 1; }
+python tools/filebacked_timing.py 1440 1021 75 ${2:-24} > gpurun_out/$R/filebacked_timing.txt 2>&1 || { tail -20 gpurun_out/$R/filebacked_timing.txt; exit 1; }
 cat gpurun_out/$R/filebacked_timing.txt
-NF_STAGE_TRACE=1 python tools/filebacked_timing.py 1440 1021 75 12 2>&1 | grep -a 'staging:' | tail -14 > gpurun_out/$R/stage_trace.txt || true
+NF_STAGE_TRACE=1 NF_TIMING_LEGS=device python tools/filebacked_timing.py 1440 1021 75 ${2:-24} 2>&1 | grep -a 'staging:' | tail -18 > gpurun_out/$R/stage_trace.txt || true
 cat gpurun_out/$R/stage_trace.txt
