@@ -100,25 +100,36 @@ __global__ __launch_bounds__(kBlock) void k_place(const uint8_t *__restrict__ tm
     }
 }
 
-// four elements per lane; needs cx % 4 == 0 (so n % 4 == 0 and a lane's elements share a row)
-template <int ES>
+// four elements per lane; needs cx % 4 == 0 (so n % 4 == 0 and a lane's elements share a row).  PLANES: every chunk holds
+// whole (y, x) planes (cy == ny, cx == nx -- one chunk per level, what XIOS writes): element e of the chunk is element
+// z0*ny*nx + e of the slab, no index arithmetic.  A chunk holds fewer than 2^31 bytes: 32-bit indices throughout.
+template <int ES, bool PLANES>
 __global__ __launch_bounds__(kBlock) void k_place4(const uint8_t *__restrict__ tmp, unsigned chunk_bytes,
                                                    const InflateJob *__restrict__ jobs, int njobs, SlabGeom g,
                                                    uint8_t *__restrict__ dst)
 {
     using elem_t = typename std::conditional<ES == 4, uint32_t, uint64_t>::type;
-    const unsigned long long n = (unsigned long long)g.cz * g.cy * g.cx, nq = n / 4;
+    const unsigned n = g.cz * g.cy * g.cx, nq = n / 4;
+    const unsigned plane = g.ny * g.nx;
     for (int i = blockIdx.y; i < njobs; i += gridDim.y) {
         const InflateJob job = jobs[i];
         const uint32_t *s = reinterpret_cast<const uint32_t *>(tmp + (unsigned long long)i * chunk_bytes);
-        for (unsigned long long q = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; q < nq;
-             q += (unsigned long long)gridDim.x * kBlock) {
-            const unsigned long long e = 4 * q;
-            const unsigned c = (unsigned)(e % g.cx);
-            const unsigned long long r = e / g.cx;
-            const unsigned b = (unsigned)(r % g.cy), a = (unsigned)(r / g.cy);
-            const unsigned z = job.z0 + a, y = job.y0 + b, x = job.x0 + c;
-            if (z >= g.nz || y >= g.ny || x >= g.nx) continue;
+        for (unsigned q = blockIdx.x * kBlock + threadIdx.x; q < nq; q += gridDim.x * kBlock) {
+            const unsigned e = 4 * q;
+            unsigned x, y, z;
+            if (PLANES) {
+                z = job.z0 + e / plane;           // only the bound matters: the level an over-hanging chunk must stop at
+                y = 0;
+                x = 0;
+                if (z >= g.nz) continue;
+            } else {
+                const unsigned c = e % g.cx, r = e / g.cx;
+                const unsigned b = r % g.cy, a = r / g.cy;
+                z = job.z0 + a;
+                y = job.y0 + b;
+                x = job.x0 + c;
+                if (z >= g.nz || y >= g.ny || x >= g.nx) continue;
+            }
             uint32_t w[ES];
 #pragma unroll
             for (int p = 0; p < ES; ++p) w[p] = __builtin_nontemporal_load(s + (p * n + e) / 4);   // bytes p of elements e .. e+3
@@ -130,9 +141,10 @@ __global__ __launch_bounds__(kBlock) void k_place4(const uint8_t *__restrict__ t
                 for (int p = 0; p < ES; ++p) v |= (elem_t)((w[p] >> (8 * k)) & 255u) << (8 * p);
                 out[k] = v;
             }
-            const unsigned long long o = ((unsigned long long)z * g.ny + y) * g.nx + x;
+            const unsigned long long o = PLANES ? (unsigned long long)job.z0 * plane + e
+                                                : ((unsigned long long)z * g.ny + y) * g.nx + x;
             elem_t *d = reinterpret_cast<elem_t *>(dst) + o;
-            if (x + 3 < g.nx && (o & 3ull) == 0) {               // whole and 16-byte aligned (the usual case)
+            if ((PLANES || x + 3 < g.nx) && (o & 3ull) == 0) {   // whole and 16-byte aligned (the usual case)
                 typedef elem_t vec4 __attribute__((ext_vector_type(4)));
                 const vec4 v = {out[0], out[1], out[2], out[3]};
                 *reinterpret_cast<vec4 *>(d) = v;
@@ -280,14 +292,18 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
     const SlabGeom g{(unsigned)chunk_dims[0], (unsigned)chunk_dims[1], (unsigned)chunk_dims[2], (unsigned)slab_dims[0],
                      (unsigned)slab_dims[1], (unsigned)slab_dims[2]};
     const bool four = shuffled && chunk_dims[2] % 4 == 0;             // four elements per lane (k_place4)
+    // whole (y, x) planes per chunk whose plane size is a multiple of four elements: no index arithmetic at all
+    const bool planes = chunk_dims[1] == slab_dims[1] && chunk_dims[2] == slab_dims[2] && (slab_dims[1] * slab_dims[2]) % 4 == 0;
     const long long nelem = chunk_bytes / elem_size / (four ? 4 : 1);
     unsigned gx = (unsigned)std::min<long long>(4096, (nelem + kBlock - 1) / kBlock);
     if (gx == 0) gx = 1;
     const dim3 grid(gx, (unsigned)std::min(n, 65535)), block(kBlock);  // gridDim.y is capped: the kernels walk the chunks
     uint8_t *dst = (uint8_t *)out_dev;
     if (elem_size == 1) hipLaunchKernelGGL((k_place<1, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
-    else if (elem_size == 4 && four) hipLaunchKernelGGL((k_place4<4>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
-    else if (elem_size == 8 && four) hipLaunchKernelGGL((k_place4<8>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
+    else if (elem_size == 4 && four && planes) hipLaunchKernelGGL((k_place4<4, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
+    else if (elem_size == 8 && four && planes) hipLaunchKernelGGL((k_place4<8, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
+    else if (elem_size == 4 && four) hipLaunchKernelGGL((k_place4<4, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
+    else if (elem_size == 8 && four) hipLaunchKernelGGL((k_place4<8, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
     else if (elem_size == 4 && shuffled) hipLaunchKernelGGL((k_place<4, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
     else if (elem_size == 4) hipLaunchKernelGGL((k_place<4, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
     else if (shuffled) hipLaunchKernelGGL((k_place<8, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);

@@ -120,13 +120,16 @@ class StepStager(object):
         nthreads = None if threading.current_thread() is threading.main_thread() else self._bg_threads
         b['staged'] = self.decoder.gather_many(items, b['comp'], 2 * (g1 - g0) * self.nz, nthreads) if items else []
         b['early'] = False
+        t_gather = time.perf_counter()
         if items and nthreads is not None and self._early_upload:     # background thread: the H2D copy runs under the GPU's
             self._decoders[slot].upload(b['comp'], b['staged'][0].used)  # work on the other slot's group
             b['early'] = True
         self._uploaded[slot] = (-1, -1)
         self._range[slot] = (g0, g1)
         if _TRACE:
-            print(f'# staging: host half of steps [{g0},{g1}) {1e3 * (time.perf_counter() - t_start):.1f} ms', flush=True)
+            print(f'# staging: host half of steps [{g0},{g1}) {1e3 * (time.perf_counter() - t_start):.1f} ms (gather '
+                  f'{1e3 * (t_gather - t_start):.1f} ms on {nthreads or self.decoder._threads} threads, early upload '
+                  f'{1e3 * (time.perf_counter() - t_gather):.1f} ms)', flush=True)
 
     # ------------------------------------------------------------------------------------------ device half (caller's thread)
     def _upload(self, slot):

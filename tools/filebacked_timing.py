@@ -88,13 +88,15 @@ legs = (('host zlib, serial (inflate, then H2D + kernels)', False, False),
         ('device inflate, pipelined (next group gathered + uploaded under the GPU work)', True, True))
 if os.environ.get('NF_TIMING_LEGS') == 'device':
     legs = legs[2:]
+if os.environ.get('NF_TIMING_LEGS') == 'pipelined':
+    legs = legs[3:]
 for label, pf, gd in legs:
     cold, steady, tot, grp = passes(lu, lv, prefetch=pf, gpu_decode=gd)
     assert numpy.array_equal(tot, tot_res)
     per = steady / nt
     print(f'{label:84s}: cold pass {cold*1e3:8.1f} ms; steady {per*1e3:7.1f} ms per step = {nz*ny*nx/per:.3e} integrals/s '
           f'({raw/nt/per/1e9:.2f} GB/s of decoded u,v; groups of {grp})')
-if os.environ.get('NF_TIMING_LEGS') == 'device':
+if os.environ.get('NF_TIMING_LEGS') in ('device', 'pipelined'):
     sys.exit(0)
 # parts: inflate alone, H2D + kernels alone
 buf = numpy.empty(u.shape[1:], numpy.float32)
