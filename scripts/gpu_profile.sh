@@ -1,9 +1,11 @@
 # Profile of the headline bench (float64 workload + float32 sub-record in one process): kernel trace + stats, then HBM traffic counters in two separate PMC passes
-# (MI355X_MICROARCH.md: FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2 -- they do not fit one pass).
+# (MI355X_MICROARCH.md: FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2 -- they do not fit one pass); the same three passes for the
+# file-ingest kernels (tools/inflate_rate.py: nf::k_inflate / nf::k_place4 on 256 streams per launch).  Every number that
+# profiles/README.md and DESIGN.md quote is printed by scripts/summarize_profile.py into <tag>_numbers.md.
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-R=${1:-r02}
+R=${1:-r03}
 mkdir -p gpurun_out/$R
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu > gpurun_out/$R/bench_trace.json 2> gpurun_out/$R/bench_trace.err
 echo "trace done"
@@ -11,4 +13,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/p
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu > gpurun_out/$R/bench_write.json 2> gpurun_out/$R/bench_write.err
 echo "write done"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/ingest_trace -- python3 tools/inflate_rate.py > gpurun_out/$R/ingest_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/ingest_fetch -- python3 tools/inflate_rate.py > gpurun_out/$R/ingest_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/ingest_write -- python3 tools/inflate_rate.py > gpurun_out/$R/ingest_write.log 2>&1
+echo "ingest done"
 python3 scripts/summarize_profile.py gpurun_out/$R $R

@@ -80,8 +80,129 @@ for dtype, roof in legs:
                     expand_WRITE_SIZE_KiB_avg=xw_kb, fetch_correction='x2 (gfx950, 16 B/lane coalesced stream)',
                     hbm_bytes_per_launch=hbm,
                     algorithmic_bytes_per_launch=roof['algorithmic_bytes_per_unit'] * c['nz'] * c['ny'] * c['nx'])
+
+# ---- K3 (nf::k_gather_segscan: both dtypes' passes share it): measured bytes against the algorithmic 80 B per record
+# (40 B of record + 4 x 8 B gathered + 8 B out).  The record stream is read 16 B per lane (counted at half by FETCH_SIZE on
+# gfx950), the gathers are 8-B accesses that pull whole 64-B requests (counted in full): the true figure lies between the
+# raw and the doubled counter; both are recorded.
+nrec = c.get('weight_entries', 0) // 4
+kf, kw = counter('pmc_fetch', 'FETCH_SIZE', 'k_gather_segscan'), counter('pmc_write', 'WRITE_SIZE', 'k_gather_segscan')
+if kf and nrec:       # (rocprofv3 leaves a kernel out of the WRITE_SIZE file when the counter reads 0: run sums go out non-temporal)
+    f_kb, w_kb = sum(kf) / len(kf), (sum(kw) / len(kw) if kw else 0.0)
+    alg = 80.0 * nrec
+    res['k_gather_segscan'] = dict(kernel='nf::k_gather_segscan', records=nrec, launches_sampled=[len(kf), len(kw)],
+                                   FETCH_SIZE_KiB_avg=f_kb, WRITE_SIZE_KiB_avg=w_kb,
+                                   hbm_bytes_per_launch_raw=f_kb * 1024 + w_kb * 1024,
+                                   hbm_bytes_per_launch_fetch_x2=2 * f_kb * 1024 + w_kb * 1024,
+                                   algorithmic_bytes_per_launch=alg, record_stream_bytes=40.0 * nrec,
+                                   overfetch_raw=(f_kb * 1024 + w_kb * 1024) / alg,
+                                   overfetch_fetch_x2=(2 * f_kb * 1024 + w_kb * 1024) / alg)
+
+
+# ---- file ingest (tools/inflate_rate.py): per case two launches (4 streams to warm up, 256 measured)
+def per_launch(sub, cname, kernel):
+    fn = find(sub, '*counter_collection.csv')
+    acc = {}
+    if not fn:
+        return []
+    with open(fn) as f:
+        for r in csv.DictReader(f):
+            if kernel in r.get('Kernel_Name', '') and r.get('Counter_Name') == cname:
+                acc.setdefault(int(r['Dispatch_Id']), 0.0)
+                acc[int(r['Dispatch_Id'])] += float(r['Counter_Value'])
+    return [acc[k] for k in sorted(acc)]
+
+
+def durations(sub, kernel):
+    fn = find(sub, '*kernel_trace.csv')
+    if not fn:
+        return []
+    with open(fn) as f:
+        rows_ = [r for r in csv.DictReader(f) if kernel in r['Kernel_Name']]
+    return [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows_]
+
+
+CASES = ['plane0 stored', 'plane2 literals+short matches', 'plane3 long matches', 'whole level (5.88 MB, 4 planes)',
+         'literals, 4-bit codes', 'noise (stored)', 'matches of 8 bytes']
+ingest = {}
+dur_i, dur_p = durations('ingest_trace', 'k_inflate'), durations('ingest_trace', 'k_place')
+fi, wi = per_launch('ingest_fetch', 'FETCH_SIZE', 'k_inflate'), per_launch('ingest_write', 'WRITE_SIZE', 'k_inflate')
+fp, wp = per_launch('ingest_fetch', 'FETCH_SIZE', 'k_place'), per_launch('ingest_write', 'WRITE_SIZE', 'k_place')
+log = os.path.join(src, 'ingest_trace.log')
+sizes = []
+if os.path.exists(log):
+    for line in open(log):
+        if ' bytes from ' in line:
+            a = line.rsplit(':', 1)[1].split()
+            sizes.append((int(a[0]), int(a[3])))
+for k, name in enumerate(CASES):
+    j = 2 * k + 1                        # the 256-stream launch of the case
+    if j >= len(dur_i) or k >= len(sizes):
+        break
+    out_b, in_b = sizes[k]
+    e = dict(streams=256, decoded_bytes_per_stream=out_b, compressed_bytes_per_stream=in_b, k_inflate_ms=dur_i[j],
+             k_place_ms=dur_p[j] if j < len(dur_p) else None, MB_per_s_per_stream=out_b / dur_i[j] / 1e3)
+    if j < len(fi) and j < len(wi):
+        e.update(k_inflate_FETCH_SIZE_KiB=fi[j], k_inflate_WRITE_SIZE_KiB=wi[j],
+                 k_inflate_bytes_algorithmic=256.0 * (in_b + out_b))
+    if j < len(fp) and j < len(wp):
+        e.update(k_place_FETCH_SIZE_KiB=fp[j], k_place_WRITE_SIZE_KiB=wp[j], k_place_bytes_algorithmic=512.0 * out_b)
+    ingest[name] = e
+if ingest:
+    res['ingest'] = ingest
 with open(os.path.join(out, 'pmc_traffic.json'), 'w') as f:
     json.dump(res, f, indent=1)
+
+# ---- the numbers profiles/README.md and DESIGN.md quote, straight from the files above
+def stat(kernel_sub):
+    for r in rows:
+        if kernel_sub in r['kernel']:
+            return r
+    return None
+
+
+lines = [f'# {tag}: numbers quoted in profiles/README.md and DESIGN.md (generated by scripts/summarize_profile.py)', '']
+lines.append('| kernel (rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 1 --no-cpu`) | calls | avg ms |')
+lines.append('|---|---|---|')
+for sub in ('k_flux<double', 'k_flux<float', 'k_expand_planes', 'k_gather_segscan', 'k_finalize_seg', 'k_finalize_tr', 'k_geometry',
+            'k_clip', 'k_uv'):
+    r = stat(sub)
+    if r:
+        lines.append(f"| `{r['kernel'][:70]}` | {r['calls']} | {r['avg_ns'] / 1e6:.4f} |")
+lines.append('')
+for dtype, roof in legs:
+    s_ = 8 if dtype == 'f64' else 4
+    alg = roof['algorithmic_bytes_per_unit'] * c['nz'] * c['ny'] * c['nx']
+    kname = 'k_flux<double' if dtype == 'f64' else 'k_flux<float'
+    r = stat(kname)
+    x = stat('k_expand_planes') if roof['avg_ms_by_kernel'].get('nf::k_expand_planes', 0) > 0 else None
+    t_csv = (r['avg_ns'] + (x['avg_ns'] if x else 0)) / 1e6 if r else None
+    lines.append(f"* {dtype}: algorithmic {alg / 1e9:.4f} GB per launch; HIP events in the profiled run {roof['avg_launch_ms']:.4f} ms -> "
+                 f"frac {roof['frac']:.4f}; kernel-stats CSV {t_csv:.4f} ms -> frac {alg / (t_csv * 1e-3) / 8e12:.4f}; "
+                 f"PMC traffic {res.get(str(c['nx']) + 'x' + str(c['ny']) + 'x' + str(c['nz']) + 'x' + str(c['nt_global']) + '_' + dtype, {}).get('hbm_bytes_per_launch', float('nan')) / 1e9:.4f} GB"
+                 if t_csv else f'* {dtype}: no kernel stats')
+if 'k_gather_segscan' in res:
+    k3 = res['k_gather_segscan']
+    r = stat('k_gather_segscan')
+    lines.append(f"* K3 `k_gather_segscan`: {k3['records']} records, algorithmic {k3['algorithmic_bytes_per_launch'] / 1e6:.1f} MB "
+                 f"(record stream {k3['record_stream_bytes'] / 1e6:.1f} MB); FETCH_SIZE {k3['FETCH_SIZE_KiB_avg'] * 1024 / 1e6:.1f} MB raw, "
+                 f"WRITE_SIZE {k3['WRITE_SIZE_KiB_avg'] * 1024 / 1e6:.1f} MB -> over-fetch {k3['overfetch_raw']:.2f} (raw) .. "
+                 f"{k3['overfetch_fetch_x2']:.2f} (FETCH_SIZE doubled); {r['avg_ns'] / 1e3:.1f} us per launch -> "
+                 f"{k3['algorithmic_bytes_per_launch'] / r['avg_ns']:.0f} GB/s algorithmic, "
+                 f"{k3['hbm_bytes_per_launch_raw'] / r['avg_ns']:.0f} .. {k3['hbm_bytes_per_launch_fetch_x2'] / r['avg_ns']:.0f} GB/s measured" if r else '')
+for name, e in ingest.items():
+    extra = ''
+    if 'k_inflate_FETCH_SIZE_KiB' in e:
+        extra = (f"; k_inflate FETCH_SIZE {e['k_inflate_FETCH_SIZE_KiB'] * 1024 / 1e6:.0f} MB raw + WRITE_SIZE "
+                 f"{e['k_inflate_WRITE_SIZE_KiB'] * 1024 / 1e6:.0f} MB vs {e['k_inflate_bytes_algorithmic'] / 1e6:.0f} MB in + out")
+    if 'k_place_FETCH_SIZE_KiB' in e:
+        extra += (f"; k_place FETCH_SIZE {e['k_place_FETCH_SIZE_KiB'] * 1024 / 1e6:.0f} MB raw + WRITE_SIZE "
+                  f"{e['k_place_WRITE_SIZE_KiB'] * 1024 / 1e6:.0f} MB vs {e['k_place_bytes_algorithmic'] / 1e6:.0f} MB")
+    lines.append(f"* ingest, {name}: k_inflate {e['k_inflate_ms']:.2f} ms for 256 streams = one stream at {e['MB_per_s_per_stream']:.1f} MB/s"
+                 + (f", k_place {e['k_place_ms']:.2f} ms" if e.get('k_place_ms') else '') + extra)
+with open(os.path.join(out, f'{tag}_numbers.md'), 'w') as f:
+    f.write('\n'.join(lines) + '\n')
+print('\n'.join(lines))
 for fn in ('bench_trace.json',):
     with open(os.path.join(src, fn)) as f, open(os.path.join(out, f'{tag}_{fn}'), 'w') as g:
         g.write(f.read())

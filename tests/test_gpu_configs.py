@@ -373,12 +373,12 @@ def test_error_behaviour_matches_reference():
         quiet_field(g['bounds_lon'], g['bounds_lat'], g['deptht_bounds'], g['u'], g['v'], [numpy.zeros((1, 3))])
 
 
-@pytest.mark.parametrize('variant', [3, 4, 5, 6, 11, 12, 14, 21, 28, 29, 45])
+@pytest.mark.parametrize('variant', [3, 4, 5, 6, 11, 12, 14, 45])
 def test_flux_kernel_variants_bit_identical(variant):
     """Every K1 variant the product library accepts (4 / 8 / 16 levels per batch, 2 chunks per lane, temporal loads, the
     other store form, the nested load loop) must produce the same bits as the default kernel: they only reorder memory
-    traffic, never arithmetic.  The diagnostic numbers of the tuning build (21, 28, 29, 45: wrong results on purpose) do
-    not exist in the shipped .so and must run the default kernel there."""
+    traffic, never arithmetic.  One diagnostic number of the tuning build (45: wrong results on purpose there) stands for
+    all of them: it does not exist in the shipped .so, which falls through to the default kernel."""
     import ctypes
     from nemoflux_amd._lib import lib, check
     dg = device_case(360, 180, 11, 2, PSI_ZT, (20., 30.))
