@@ -766,16 +766,9 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "v_readfirstlane_b32 s43, v41\n\t"
             "s_or_b32 s43, s43, s46\n\t"
             "s_branch 1b\n"
-            // ---------------------------------------------------------------- refills of the bit buffer (out of line)
+            // ---------------------------------------------------------------- refills of the bit buffer: out of line, one copy
+            // per site (a taken branch costs a lone wavefront ~21 cycles -- tools/lds_chain.hip -- so no shared trampoline)
             "10:\n\t"
-            "s_mov_b32 s57, 11\n\t"
-            "s_branch 16f\n"
-            "12:\n\t"
-            "s_mov_b32 s57, 13\n\t"
-            "s_branch 16f\n"
-            "14:\n\t"
-            "s_mov_b32 s57, 15\n"
-            "16:\n\t"
             "v_readfirstlane_b32 s48, %[nextw]\n\t"
             "s_mov_b32 s49, 0\n\t"
             "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
@@ -790,10 +783,38 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_cselect_b32 s46, 0x40000000, s46\n\t"         // ring low: the round ends at the next symbol boundary
             "s_cmp_ge_u32 s44, s56\n\t"
             "s_cselect_b32 s46, 0x40000000, s46\n\t"         // window nearly full (a run of literals is only checked here)
-            "s_cmp_eq_u32 s57, 11\n\t"
-            "s_cbranch_scc1 11b\n\t"
-            "s_cmp_eq_u32 s57, 13\n\t"
-            "s_cbranch_scc1 13b\n\t"
+            "s_branch 11b\n"
+            "12:\n\t"
+            "v_readfirstlane_b32 s48, %[nextw]\n\t"
+            "s_mov_b32 s49, 0\n\t"
+            "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
+            "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
+            "s_add_u32 s42, s42, 32\n\t"
+            "s_add_u32 s45, s45, 1\n\t"
+            "s_and_b32 s47, s45, 0xff\n\t"
+            "s_lshl_b32 s47, s47, 2\n\t"
+            "v_mov_b32 v40, s47\n\t"
+            "ds_read_b32 %[nextw], v40 offset:%[ring]\n\t"
+            "s_cmp_ge_u32 s45, s55\n\t"
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // ring low: the round ends at the next symbol boundary
+            "s_cmp_ge_u32 s44, s56\n\t"
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // window nearly full (a run of literals is only checked here)
+            "s_branch 13b\n"
+            "14:\n\t"
+            "v_readfirstlane_b32 s48, %[nextw]\n\t"
+            "s_mov_b32 s49, 0\n\t"
+            "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
+            "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
+            "s_add_u32 s42, s42, 32\n\t"
+            "s_add_u32 s45, s45, 1\n\t"
+            "s_and_b32 s47, s45, 0xff\n\t"
+            "s_lshl_b32 s47, s47, 2\n\t"
+            "v_mov_b32 v40, s47\n\t"
+            "ds_read_b32 %[nextw], v40 offset:%[ring]\n\t"
+            "s_cmp_ge_u32 s45, s55\n\t"
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // ring low: the round ends at the next symbol boundary
+            "s_cmp_ge_u32 s44, s56\n\t"
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // window nearly full (a run of literals is only checked here)
             "s_branch 15b\n"
             // ---------------------------------------------------------------- exits
             "20:\n\t"
