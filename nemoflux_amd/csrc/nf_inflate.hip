@@ -157,6 +157,38 @@ __global__ __launch_bounds__(kBlock) void k_place4(const uint8_t *__restrict__ t
     }
 }
 
+// float32, whole (y, x) planes per chunk, plane size a multiple of 16 elements -- one deflated chunk per level of a NEMO
+// file: a lane owns SIXTEEN consecutive elements: one 16-byte load per byte plane (a wave reads 1 KiB contiguous of each),
+// a byte transpose in registers, four 16-byte stores (a wave writes 4 KiB contiguous).
+__global__ __launch_bounds__(kBlock) void k_place16(const uint8_t *__restrict__ tmp, unsigned chunk_bytes,
+                                                    const InflateJob *__restrict__ jobs, int njobs, SlabGeom g,
+                                                    uint8_t *__restrict__ dst)
+{
+    typedef uint32_t uvec4 __attribute__((ext_vector_type(4)));
+    const unsigned n = g.cz * g.cy * g.cx, nq = n / 16, plane = g.ny * g.nx;
+    for (int i = blockIdx.y; i < njobs; i += gridDim.y) {
+        const InflateJob job = jobs[i];
+        const uint8_t *s = tmp + (unsigned long long)i * chunk_bytes;
+        for (unsigned q = blockIdx.x * kBlock + threadIdx.x; q < nq; q += gridDim.x * kBlock) {
+            const unsigned e = 16 * q;
+            if (job.z0 + e / plane >= g.nz) continue;            // the levels of an over-hanging chunk that lie beyond the slab
+            uvec4 w[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) w[p] = __builtin_nontemporal_load(reinterpret_cast<const uvec4 *>(s + (unsigned long long)p * n + e));
+            uvec4 *d = reinterpret_cast<uvec4 *>(reinterpret_cast<uint32_t *>(dst) + (unsigned long long)job.z0 * plane + e);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                        // word c of every plane holds elements 4c .. 4c+3
+                uvec4 out;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    out[k] = ((w[0][c] >> (8 * k)) & 255u) | (((w[1][c] >> (8 * k)) & 255u) << 8) |
+                             (((w[2][c] >> (8 * k)) & 255u) << 16) | (((w[3][c] >> (8 * k)) & 255u) << 24);
+                d[c] = out;
+            }
+        }
+    }
+}
+
 struct Inflater {
     uint8_t *d_comp = nullptr, *d_tmp = nullptr;
     InflateJob *d_jobs = nullptr;
@@ -294,12 +326,14 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
     const bool four = shuffled && chunk_dims[2] % 4 == 0;             // four elements per lane (k_place4)
     // whole (y, x) planes per chunk whose plane size is a multiple of four elements: no index arithmetic at all
     const bool planes = chunk_dims[1] == slab_dims[1] && chunk_dims[2] == slab_dims[2] && (slab_dims[1] * slab_dims[2]) % 4 == 0;
-    const long long nelem = chunk_bytes / elem_size / (four ? 4 : 1);
+    const bool sixteen = elem_size == 4 && four && planes && (slab_dims[1] * slab_dims[2]) % 16 == 0;
+    const long long nelem = chunk_bytes / elem_size / (sixteen ? 16 : four ? 4 : 1);
     unsigned gx = (unsigned)std::min<long long>(4096, (nelem + kBlock - 1) / kBlock);
     if (gx == 0) gx = 1;
     const dim3 grid(gx, (unsigned)std::min(n, 65535)), block(kBlock);  // gridDim.y is capped: the kernels walk the chunks
     uint8_t *dst = (uint8_t *)out_dev;
     if (elem_size == 1) hipLaunchKernelGGL((k_place<1, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
+    else if (sixteen) hipLaunchKernelGGL(k_place16, grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
     else if (elem_size == 4 && four && planes) hipLaunchKernelGGL((k_place4<4, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
     else if (elem_size == 8 && four && planes) hipLaunchKernelGGL((k_place4<8, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
     else if (elem_size == 4 && four) hipLaunchKernelGGL((k_place4<4, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
