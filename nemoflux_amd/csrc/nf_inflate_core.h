@@ -2,7 +2,7 @@
 //
 // Why it exists: real NEMO output is NetCDF-4 = HDF5 with float32 uo/vo stored as shuffled + deflated chunks (one per
 // level in XIOS files); the reference reads them through netCDF4/xarray on the host (nemoflux/field.py:149), and host zlib
-// is what bounds a file-backed pass.  Here the compressed chunks of a time step are copied to HBM
+// is what bounds a file-backed pass ("Ingest").  Here the compressed chunks of a time step are copied to HBM
 // as they are and every chunk is inflated by its own wavefront, a thousand at a time, into the staging slab the flux kernel
 // reads.  Written from the two RFCs; no zlib code is used.
 //

@@ -1,4 +1,4 @@
-"""GPU parity of the file-ingest path AT THE SIZE DESIGN.md quotes (section 8.3): the C3 grid 1440 x 1021 x 75, float32,
+"""GPU parity of the file-ingest path AT THE SIZE DESIGN.md quotes (section 4, "Ingest"): the C3 grid 1440 x 1021 x 75, float32,
 one byte-shuffled + deflated chunk per level like XIOS output -- 5.9 MB per stream, hundreds of streams per launch, groups
 of time steps, the pipelined gather.  The toy-size suites (tests/test_gpu_inflate.py, test_file_backed_field_against_the_
 oracle) cover the format's corners; this one covers scale and occupancy: the decoder's phases are ordered by the issue
