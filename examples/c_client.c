@@ -117,12 +117,31 @@ int main(void)
     CHECK(nf_inflater_del(&inf));
     printf("ingest: decoded %.1f (status %d)\n", decoded, status);
 
+    /* ---- the multi-GPU collective from plain C: a one-rank communicator (all one GPU can form), the row summed in place.
+     * With N ranks: rank 0 makes the id, hands it to the others (MPI, a file, a socket), every rank calls comm_init. */
+    char id[NF_RCCL_UNIQUE_ID_BYTES];
+    void *comm = NULL, *row_dev = NULL;
+    int nranks = -1, myrank = -1, dev = -1;
+    double reduced[3] = {0, 0, 0};
+    const double part[3] = {1.5, -2.0, 360.0};
+    CHECK(nf_rccl_unique_id(id));
+    CHECK(nf_rccl_comm_init(&comm, 1, id, 0));
+    CHECK(nf_rccl_comm_info(comm, &nranks, &myrank, &dev));
+    CHECK(nf_malloc(&row_dev, sizeof part));
+    CHECK(nf_memcpy_h2d(row_dev, part, sizeof part));
+    CHECK(nf_rows_allreduce(comm, (double *)row_dev, 3, NULL));
+    CHECK(nf_synchronize());
+    CHECK(nf_memcpy_d2h(reduced, row_dev, sizeof reduced));
+    CHECK(nf_free(row_dev));
+    CHECK(nf_rccl_comm_destroy(comm));
+    printf("reduce: %d rank(s), rank %d on device %d, row = %.1f %.1f %.1f\n", nranks, myrank, dev, reduced[0], reduced[1], reduced[2]);
+
     CHECK(mnt_polylineintegral_del(&pli));
     CHECK(mnt_grid_del(&grid));
     CHECK(nf_field_del(&fld));
     free(row);
     const int ok = fabs(flux2 - 360.0) < 1e-9 && fabs(flux1 - 360.0) < 1e-9 && rc == NF_ERR_ARG && ncells == NY * NX &&
-                   decoded == 1.0f && status == 0;
+                   decoded == 1.0f && status == 0 && nranks == 1 && myrank == 0 && reduced[0] == 1.5 && reduced[2] == 360.0;
     printf(ok ? "C client OK\n" : "C client FAILED\n");
     return ok ? 0 : 2;
 }

@@ -81,12 +81,17 @@ class NativeComm(object):
         self._lib, self._check = lib, check
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         ident = [None]
-        if rank == 0:
-            buf = ctypes.create_string_buffer(128)
-            check(lib.nf_rccl_unique_id(buf))
-            ident[0] = buf.raw
+        if rank == 0:       # whatever happens here, the broadcast below is reached: the other ranks are waiting in it
+            try:
+                buf = ctypes.create_string_buffer(128)
+                check(lib.nf_rccl_unique_id(buf))
+                ident[0] = buf.raw
+            except Exception as e:
+                ident[0] = e
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast_object_list(ident, src=src, group=group)
+        if not isinstance(ident[0], bytes):
+            raise RuntimeError(f'rank 0 could not create the RCCL unique id: {ident[0]}')
         self.ptr = ctypes.c_void_p()
         check(lib.nf_rccl_comm_init(ctypes.byref(self.ptr), world, ctypes.c_char_p(ident[0]), rank))
 

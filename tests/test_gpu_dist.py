@@ -142,6 +142,7 @@ def test_plain_c_client_of_the_abi(tmp_path):
     assert r.returncode == 0 and 'C client OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'level 2: 5 segments, flux = 360.0000' in r.stdout and 'level 1: 648 cells, flux = 360.0000' in r.stdout
     assert 'ingest: decoded 1.0 (status 0)' in r.stdout
+    assert 'reduce: 1 rank(s), rank 0 on device 0, row = 1.5 -2.0 360.0' in r.stdout      # nf_rows_allreduce from plain C
 
 
 def _bench_json(extra, nproc=1, launcher='torchrun'):
