@@ -133,6 +133,19 @@ def native_comm(group=None):
             err = f'{type(e).__name__}: {e}'
         ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device='cuda')
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:   # every rank has a communicator: one known-answer all-reduce before it carries real rows
+            try:
+                world, rank = dist.get_world_size(group), dist.get_rank(group)
+                probe = torch.tensor([rank + 1.0, 0.5], dtype=torch.float64, device='cuda')
+                comm.all_reduce_sum(probe)
+                torch.cuda.synchronize()
+                if probe.tolist() != [world * (world + 1) / 2.0, 0.5 * world]:
+                    err = f'self-test gave {probe.tolist()}'
+                    ok.fill_(0)
+            except Exception as e:
+                err = f'{type(e).__name__}: {e}'
+                ok.fill_(0)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         if int(ok.item()) == 1:
             _native[group] = comm
         else:
