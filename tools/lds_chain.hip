@@ -95,6 +95,39 @@ __global__ __launch_bounds__(64) void k_chain(const unsigned *init, int iters, u
                          : "+s"(buf), "+s"(e), "+s"(pos)::"s47", "v40", "v41", "v42", "v44", "scc", "memory");
         idx = e + pos;
     }
+    else if (MODE == 9) {       // the same chase as lds_scalar through a REGISTER-resident table: 1024 entries = 16 VGPRs x 64 lanes,
+                                // row picked by VGPR index mode (s_set_gpr_idx_on), lane by v_readlane -- no LDS in the chain
+        asm volatile("v_lshlrev_b32 v40, 2, %1\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "s_mov_b32 s48, %2\n"
+                     "1:\n\t"
+                     "s_lshr_b32 s46, %0, 8\n\t"              // idx is a byte offset: row = idx >> 8, lane = (idx >> 2) & 63
+                     "s_bfe_u32 s47, %0, 0x60002\n\t"
+                     "s_set_gpr_idx_on s46, 0x1\n\t"
+                     "v_mov_b32 v41, v60\n\t"
+                     "s_set_gpr_idx_off\n\t"
+                     "v_readlane_b32 %0, v41, s47\n\t"
+                     "s_and_b32 %0, %0, 0xffc\n\t"
+                     "s_sub_u32 s48, s48, 1\n\t"
+                     "s_cmp_lg_u32 s48, 0\n\t"
+                     "s_cbranch_scc1 1b"
+                     : "+s"(idx)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s46", "s47", "s48", "v40", "v41", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70",
+                       "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+    } else if (MODE == 10) {    // lds_scalar with the loop inside the asm (like mode 9): the like-for-like partner
+        asm volatile("s_mov_b32 s48, %1\n"
+                     "1:\n\t"
+                     "v_mov_b32 v40, %0\n\tds_read_b32 v41, v40\n\ts_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, v41\n\t"
+                     "s_and_b32 %0, %0, 0xffc\n\t"
+                     "s_sub_u32 s48, s48, 1\n\ts_cmp_lg_u32 s48, 0\n\ts_cbranch_scc1 1b"
+                     : "+s"(idx) : "s"(iters) : "s48", "v40", "v41", "scc", "memory");
+    }
     if (threadIdx.x == 0) out[blockIdx.x] = idx;
 }
 
@@ -112,8 +145,10 @@ static int run(const char *name, const unsigned *d_init, unsigned *d_out, int bl
     CHECK(hipDeviceSynchronize());
     float ms = 0;
     CHECK(hipEventElapsedTime(&ms, a, b));
-    printf("%-34s %5d workgroups: %8.1f ns per iteration (%4.1f instructions in the chain)\n", name, blocks, ms * 1e6 / iters,
-           per_iter_instr);
+    unsigned last = 0;
+    CHECK(hipMemcpy(&last, d_out, sizeof last, hipMemcpyDeviceToHost));
+    printf("%-36s %5d workgroups: %8.1f ns per iteration (%4.1f instructions in the chain; ends at %u)\n", name, blocks,
+           ms * 1e6 / iters, per_iter_instr, last);
     return 0;
 }
 
@@ -136,6 +171,8 @@ int main()
         if (run<6>("16 dependent salu", d_init, d_out, blocks, iters, 16)) return 1;
         if (run<7>("16 dependent valu", d_init, d_out, blocks, iters, 16)) return 1;
         if (run<8>("decoder literal step", d_init, d_out, blocks, iters, 14)) return 1;
+        if (run<10>("lds_scalar, loop in asm", d_init, d_out, blocks, iters, 8)) return 1;
+        if (run<9>("register table (gpr_idx + readlane)", d_init, d_out, blocks, iters, 10)) return 1;
     }
     return 0;
 }
