@@ -691,7 +691,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "ds_write_b8 v42, v44\n\t"
             "s_bcnt1_i32_b32 s47, s47\n\t"
             "s_add_u32 s44, s44, s47\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"                     // LDS returns in order: all but the youngest (the byte store) = the lookup
             "v_readfirstlane_b32 s43, v41\n\t"
             "s_or_b32 s43, s43, s46\n\t"
             "s_cmp_lt_u32 s43, 0x10000000\n\t"

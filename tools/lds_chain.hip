@@ -95,7 +95,17 @@ __global__ __launch_bounds__(64) void k_chain(const unsigned *init, int iters, u
                          : "+s"(buf), "+s"(e), "+s"(pos)::"s47", "v40", "v41", "v42", "v44", "scc", "memory");
         idx = e + pos;
     }
-    else if (MODE == 9) {       // the same chase as lds_scalar through a REGISTER-resident table: 1024 entries = 16 VGPRs x 64 lanes,
+    else if (MODE == 11) {      // mode 8 waiting only for the LOOKUP (lgkmcnt(1)): the younger byte store stays in flight
+        unsigned long long buf = 0x123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        for (int i = 0; i < iters; ++i)
+            asm volatile("s_and_b32 s47, %1, 15\n\ts_lshr_b64 %0, %0, s47\n\ts_lshl_b32 s47, %2, 2\n\tv_mov_b32 v40, s47\n\t"
+                         "v_and_b32 v40, 0xffc, v40\n\tds_read_b32 v41, v40\n\tv_mov_b32 v42, %2\n\tv_and_b32 v42, 0xfff, v42\n\t"
+                         "v_mov_b32 v44, %1\n\tds_write_b8 v42, v44 offset:4096\n\ts_add_u32 %2, %2, 1\n\ts_waitcnt lgkmcnt(1)\n\t"
+                         "v_readfirstlane_b32 %1, v41\n\ts_or_b32 %1, %1, 5"
+                         : "+s"(buf), "+s"(e), "+s"(pos)::"s47", "v40", "v41", "v42", "v44", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 9) {       // the same chase as lds_scalar through a REGISTER-resident table: 1024 entries = 16 VGPRs x 64 lanes,
                                 // row picked by VGPR index mode (s_set_gpr_idx_on), lane by v_readlane -- no LDS in the chain
         asm volatile("v_lshlrev_b32 v40, 2, %1\n\t"
                      "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
@@ -171,6 +181,7 @@ int main()
         if (run<6>("16 dependent salu", d_init, d_out, blocks, iters, 16)) return 1;
         if (run<7>("16 dependent valu", d_init, d_out, blocks, iters, 16)) return 1;
         if (run<8>("decoder literal step", d_init, d_out, blocks, iters, 14)) return 1;
+        if (run<11>("decoder literal step, lgkmcnt(1)", d_init, d_out, blocks, iters, 14)) return 1;
         if (run<10>("lds_scalar, loop in asm", d_init, d_out, blocks, iters, 8)) return 1;
         if (run<9>("register table (gpr_idx + readlane)", d_init, d_out, blocks, iters, 10)) return 1;
     }
