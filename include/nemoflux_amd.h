@@ -64,6 +64,10 @@ int nf_memset(void *dev, int value, size_t bytes);
 int nf_synchronize(void);
 /* host-side file decoding helper: undo HDF5's shuffle filter (es byte planes of n elements -> n elements) */
 int nf_host_unshuffle(const void *src, void *dst, size_t n, int es);
+/* host-side file staging helper: copy n byte ranges (addresses as integers) with nthreads native threads -- the compressed
+ * chunks of a group of time steps out of the mapped file into a pinned staging buffer (field.py:149 reads them one by one) */
+int nf_host_gather(const unsigned long long *src_addr, const unsigned long long *dst_addr, const long long *len, long long n,
+                   int nthreads);
 /* tuning knobs for A/B measurements inside one process: "flux_variant" (0 = default; see nf_flux.hip),
  * "xcd_map" (1 = on), "ww_blocks_per_cu", "batch_steps" (1 = small grids run all time steps in one launch) */
 int nf_tuning_set(const char *name, int value);

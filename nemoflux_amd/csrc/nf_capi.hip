@@ -10,6 +10,7 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "nf_common.h"
@@ -1498,6 +1499,44 @@ try {
         const unsigned char *pj = s + (size_t)j * n;
         for (size_t i = 0; i < n; ++i) d[i * es + j] = pj[i];
     }
+    return NF_OK;
+}
+NF_API_CATCH
+
+// Gather n byte ranges into a staging buffer with `nthreads` native threads (file ingest: the compressed chunks of a group
+// of time steps, copied out of the mapped file into pinned memory).  One call, no interpreter lock between the copies: the
+// Python thread pool this replaces took the GIL twice per chunk and stalled for hundreds of milliseconds whenever the
+// caller's thread was busy in the interpreter.  Ranges are dealt to the threads in contiguous runs of about equal bytes.
+int nf_host_gather(const unsigned long long *src_addr, const unsigned long long *dst_addr, const long long *len, long long n,
+                   int nthreads)
+try {
+    NF_REQUIRE(n == 0 || (src_addr && dst_addr && len), NF_ERR_ARG, "nf_host_gather: null argument");
+    NF_REQUIRE(n >= 0 && nthreads >= 1 && nthreads <= 256, NF_ERR_ARG, "nf_host_gather: bad counts");
+    long long total = 0;
+    for (long long i = 0; i < n; ++i) {
+        NF_REQUIRE(len[i] >= 0, NF_ERR_ARG, "nf_host_gather: negative length");
+        total += len[i];
+    }
+    if (total == 0) return NF_OK;
+    const int nt = (int)std::min<long long>(nthreads, n);
+    auto work = [&](long long lo, long long hi) {
+        for (long long i = lo; i < hi; ++i)
+            if (len[i]) memcpy((void *)(uintptr_t)dst_addr[i], (const void *)(uintptr_t)src_addr[i], (size_t)len[i]);
+    };
+    if (nt <= 1) {
+        work(0, n);
+        return NF_OK;
+    }
+    std::vector<std::thread> pool;
+    const long long share = (total + nt - 1) / nt;
+    long long lo = 0;
+    for (int t = 0; t < nt && lo < n; ++t) {
+        long long hi = lo, acc = 0;
+        while (hi < n && (acc < share || t == nt - 1)) acc += len[hi++];
+        pool.emplace_back(work, lo, hi);
+        lo = hi;
+    }
+    for (auto &th : pool) th.join();
     return NF_OK;
 }
 NF_API_CATCH

@@ -7,7 +7,6 @@ by nf_inflate.hip, one wavefront per chunk -- instead of zlib on the host cores,
     staged = dec.gather(lazy_variable.raw_bytes(), plan)     # host only (runs on the prefetch thread)
     dec.decode(staged, device_pointer, nbytes)     # H2D of the compressed bytes + inflate + un-shuffle, synchronous
 """
-import concurrent.futures
 import ctypes
 
 import numpy
@@ -79,31 +78,32 @@ class ChunkDecoder(object):
         copied into `pinned` back to back; slabs of the same chunk geometry are merged into ONE StagedChunks (= one launch,
         one wavefront per chunk); returns the list of StagedChunks (one per distinct geometry)."""
         groups = {}
-        copies = []
+        src_addr, dst_addr, lens = [], [], []
+        keep = []
         pos = 0
         for raw, plan, zoff in items:
             key = (tuple(plan['chunk_dims']), tuple(plan['slab_dims'][1:]), plan['elem_size'], plan['shuffled'])
             g = groups.setdefault(key, dict(in_off=[], in_len=[], origin=[], plan=plan))
             src = numpy.frombuffer(raw, numpy.uint8)
+            keep.append(src)
+            base = src.ctypes.data
             for a, ln, org in plan['chunks']:
+                if a < 0 or a + ln > src.size:
+                    raise RuntimeError('ERROR: a chunk of the device plan lies outside the mapped file')
                 g['in_off'].append(pos)
                 g['in_len'].append(ln)
                 g['origin'].append((org[0] + zoff, org[1], org[2]))
-                copies.append((src, a, ln, pos))
+                src_addr.append(base + a)
+                dst_addr.append(pinned.ptr + pos)
+                lens.append(ln)
                 pos += (ln + 7) & ~7
         if pos > pinned.nbytes:
             raise RuntimeError('ERROR: staging buffer too small for the compressed chunks of this group of time steps')
-
-        def copy(c):
-            src, a, ln, at = c
-            pinned.array[at:at + ln] = src[a:a + ln]
+        # one native call (nf_host_gather: its own threads, no interpreter lock between the copies)
         threads = self._threads if threads is None else threads
-        if len(copies) > 1 and threads > 1:
-            with concurrent.futures.ThreadPoolExecutor(min(threads, len(copies))) as pool:
-                list(pool.map(copy, copies))
-        else:
-            for c in copies:
-                copy(c)
+        sa, da = numpy.array(src_addr, numpy.uint64), numpy.array(dst_addr, numpy.uint64)
+        ll = numpy.array(lens, numpy.int64)
+        check(lib.nf_host_gather(sa.ctypes.data, da.ctypes.data, ll.ctypes.data, len(lens), max(1, int(threads))))
         out = []
         for key, g in groups.items():
             plan = dict(g['plan'])

@@ -233,3 +233,30 @@ def test_host_unshuffle_helper_matches_numpy():
                 assert _lib.lib.nf_host_unshuffle(shuffled.ctypes.data, dst.ctypes.data, n, es) == 0
                 assert numpy.array_equal(dst.reshape(n, es), elems)
     assert _lib.lib.nf_host_unshuffle(None, None, 4, 4) == 1 and _lib.lib.nf_host_unshuffle(shuffled.ctypes.data, dst.ctypes.data, 4, 0) == 1
+
+
+def test_host_gather_helper():
+    """nf_host_gather (file staging on the host, no GPU involved): n byte ranges copied by native threads -- ragged lengths,
+    empty ranges, more threads than ranges, one thread; bad arguments are errors."""
+    import ctypes
+    from nemoflux_amd._lib import lib
+    rng = numpy.random.default_rng(11)
+    src = rng.integers(0, 256, 1 << 20, dtype=numpy.uint8)
+    for n, threads in ((1, 4), (7, 3), (900, 8), (900, 1), (3, 64)):
+        lens = rng.integers(0, 3000, n).astype(numpy.int64)
+        lens[rng.integers(0, n)] = 0
+        offs = rng.integers(0, src.size - 3000, n)
+        dst = numpy.full(int(lens.sum()) + 8 * n + 16, 0xAB, numpy.uint8)
+        pos, dpos = 0, []
+        for ln in lens:
+            dpos.append(pos)
+            pos += (int(ln) + 7) & ~7
+        sa = (src.ctypes.data + offs).astype(numpy.uint64)
+        da = (dst.ctypes.data + numpy.array(dpos)).astype(numpy.uint64)
+        assert lib.nf_host_gather(sa.ctypes.data, da.ctypes.data, lens.ctypes.data, n, threads) == 0
+        want = numpy.full_like(dst, 0xAB)
+        for o, p, ln in zip(offs, dpos, lens):
+            want[p:p + ln] = src[o:o + ln]
+        assert numpy.array_equal(dst, want), (n, threads)
+    assert lib.nf_host_gather(None, None, None, 0, 1) == 0
+    assert lib.nf_host_gather(None, None, None, 5, 1) == 1 and lib.nf_host_gather(sa.ctypes.data, da.ctypes.data, lens.ctypes.data, n, 0) == 1
