@@ -110,6 +110,11 @@ def cf_files():
     with h5py.File(os.path.join(OUT, 'cf_V64.h5'), 'w', libver='earliest') as f:
         d = f.create_dataset('vo', data=v64)
         d.attrs.create('missing_value', numpy.float64(-9999.))
+    # the same float64 vo chunked + shuffled + deflated (device-decodable on its own): paired with a float32 uo it must NOT
+    # take the device path of a float32 stager (8-byte elements into a 4-byte slab)
+    with h5py.File(os.path.join(OUT, 'cf_V64c.h5'), 'w', libver='earliest') as f:
+        d = f.create_dataset('vo', data=v64, chunks=(1, 1, 18, 36), compression='gzip', shuffle=True)
+        d.attrs.create('missing_value', numpy.float64(-9999.))
     # a float32 uo with whole-plane deflated chunks to pair with cf_V.h5 on the device path (same masks, _FillValue only)
     u32 = g['u'].astype('<f4')
     u32[:, :, 4:9, 10:20] = numpy.float32(1.e20)

@@ -1054,7 +1054,8 @@ def test_file_backed_field_against_the_oracle(prefetch, gpu_decode, oracle):
     assert numpy.array_equal(tot, tot2)
 
 
-@pytest.mark.parametrize('ufile, vfile', [('cf_U.h5', 'cf_V.h5'), ('cf_U32.h5', 'cf_V.h5'), ('cf_U.h5', 'cf_V64.h5')])
+@pytest.mark.parametrize('ufile, vfile', [('cf_U.h5', 'cf_V.h5'), ('cf_U32.h5', 'cf_V.h5'), ('cf_U.h5', 'cf_V64.h5'),
+                                          ('cf_U32.h5', 'cf_V64c.h5')])
 def test_cf_encoded_files_against_the_oracle(ufile, vfile, oracle):
     """CF decoding parity with xarray's defaults (field.py:22-25, 34-35, 157) through the file-backed Field: uo packed as
     int16 with scale_factor / add_offset and both a _FillValue and a missing_value (decoded on the host staging path), vo
@@ -1082,7 +1083,10 @@ def test_cf_encoded_files_against_the_oracle(ufile, vfile, oracle):
         assert ff._lazy_dtype == numpy.float64 and ff._stager.comp_bytes[0] is None
     else:
         u = _cf_expected(ru, (numpy.float32(1.e20),), None, None, numpy.float32)
-        assert ff._stager.comp_bytes[0] is not None and ff._stager.comp_bytes[1] is not None      # both on the device
+        assert ff._stager.comp_bytes[0] is not None
+        # vo float32: on the device too; vo float64 (deflated, device-decodable on its own) next to a float32 uo: its
+        # 8-byte elements must not be decoded into the float32 slab -- host path, converted to uo's dtype
+        assert (ff._stager.comp_bytes[1] is not None) == (vfile == 'cf_V.h5')
     v = _cf_expected(rv, (rv.dtype.type(1.e20), rv.dtype.type(-9999.)), None, None, rv.dtype.type)
     assert numpy.isnan(u).any() and numpy.isnan(v).any() and (rv == rv.dtype.type(-9999.)).any()
     v = v.astype(u.dtype)       # a vo of another type than uo is converted to uo's (the stager's) dtype
