@@ -32,9 +32,20 @@ if st:
             rows.append(dict(kernel=short(r['Name']), calls=int(r['Calls']), total_ns=int(r['TotalDurationNs']),
                              avg_ns=float(r['AverageNs']), pct=float(r['Percentage']), min_ns=int(r['MinNs']),
                              max_ns=int(r['MaxNs'])))
+# ... and of the file-ingest kernels, from the same kind of pass over tools/inflate_rate.py (7 kinds of streams, 4 + 256 streams
+# each: the averages mix the kinds -- per-kind durations are in <tag>_numbers.md / pmc_traffic.json -> ingest)
+ingest_rows = []
+st2 = find('ingest_trace', '*kernel_stats.csv')
+if st2:
+    with open(st2) as f:
+        for r in csv.DictReader(f):
+            if 'k_inflate' in r['Name'] or 'k_place' in r['Name']:
+                ingest_rows.append(dict(kernel=short(r['Name']) + ' [tools/inflate_rate.py]', calls=int(r['Calls']),
+                                        total_ns=int(r['TotalDurationNs']), avg_ns=float(r['AverageNs']),
+                                        pct=float(r['Percentage']), min_ns=int(r['MinNs']), max_ns=int(r['MaxNs'])))
 with open(os.path.join(out, f'{tag}_kernel_stats.csv'), 'w') as f:
     f.write('kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n')
-    for r in rows:
+    for r in rows + ingest_rows:
         f.write('"{kernel}",{calls},{total_ns},{avg_ns:.1f},{pct},{min_ns},{max_ns}\n'.format(**r))
 
 
