@@ -661,47 +661,71 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_mov_b32 s57, 0\n\t"
             "s_mov_b32 s50, 0\n\t"
             "s_mov_b32 s51, 0\n\t"
-            "v_mov_b32 v45, 0xffc\n\t"
-            "v_mov_b32 v46, 0x3fc\n\t"
+            "s_mov_b32 s63, 0\n\t"
+            "s_mov_b64 exec, -1\n\t"
             "v_mov_b32 v47, %[wmask]\n\t"
             "v_lshlrev_b32 v48, 3, %[lane]\n\t"
-            "v_add_u32 v48, 8, v48\n\t"                      // lane 0 stores bits 8.., lane 1 bits 16..
-            "s_mov_b64 exec, 3\n\t"
-            "s_waitcnt lgkmcnt(0)\n"
+            "v_add_u32 v48, 8, v48\n\t"
+            "v_lshlrev_b32 v40, 2, %[lane]\n\t"
+            // the lookup tables move into registers: 1024 literal / length entries = v60..v75 x 64 lanes, 256 distance entries =
+            // v76..v79; a lookup is VGPR index mode for the row + v_readlane for the lane: 33 ns against 50 for the LDS round trip
+            "ds_read_b32 v60, v40 offset:%[lit]+0\n\t"
+            "ds_read_b32 v61, v40 offset:%[lit]+256\n\t"
+            "ds_read_b32 v62, v40 offset:%[lit]+512\n\t"
+            "ds_read_b32 v63, v40 offset:%[lit]+768\n\t"
+            "ds_read_b32 v64, v40 offset:%[lit]+1024\n\t"
+            "ds_read_b32 v65, v40 offset:%[lit]+1280\n\t"
+            "ds_read_b32 v66, v40 offset:%[lit]+1536\n\t"
+            "ds_read_b32 v67, v40 offset:%[lit]+1792\n\t"
+            "ds_read_b32 v68, v40 offset:%[lit]+2048\n\t"
+            "ds_read_b32 v69, v40 offset:%[lit]+2304\n\t"
+            "ds_read_b32 v70, v40 offset:%[lit]+2560\n\t"
+            "ds_read_b32 v71, v40 offset:%[lit]+2816\n\t"
+            "ds_read_b32 v72, v40 offset:%[lit]+3072\n\t"
+            "ds_read_b32 v73, v40 offset:%[lit]+3328\n\t"
+            "ds_read_b32 v74, v40 offset:%[lit]+3584\n\t"
+            "ds_read_b32 v75, v40 offset:%[lit]+3840\n\t"
+            "ds_read_b32 v76, v40 offset:%[dtab]+0\n\t"
+            "ds_read_b32 v77, v40 offset:%[dtab]+256\n\t"
+            "ds_read_b32 v78, v40 offset:%[dtab]+512\n\t"
+            "ds_read_b32 v79, v40 offset:%[dtab]+768\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
             // ---------------------------------------------------------------- dispatch on the entry at the head
-            "1:\n\t"
+            "1:\n"
             "s_cmp_lt_u32 s43, 0x10000000\n\t"
-            "s_cbranch_scc0 3f\n"
-            // ---------------------------------------------------------------- literal run
-            "2:\n\t"
+            "s_cbranch_scc0 3f\n\t"
+            // ---------------------------------------------------------------- literal run (exec = all lanes between the stores)
+            "2:\n"
             "s_and_b32 s47, s43, 15\n\t"
             "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
             "s_sub_u32 s42, s42, s47\n\t"
             "s_cmp_le_u32 s42, 32\n\t"
-            "s_cbranch_scc1 10f\n"
-            "11:\n\t"
-            "s_lshl_b32 s47, s40, 2\n\t"
-            "v_and_b32 v40, s47, v45\n\t"
-            "ds_read_b32 v41, v40 offset:%[lit]\n\t"       // next entry: requested before this one takes effect
-            "s_bfe_u32 s47, s43, 0x20018\n\t"                // lanes that store: 1 or 3
-            "s_mov_b32 exec_lo, s47\n\t"
+            "s_cbranch_scc1 10f\n\t"
+            "11:\n"
+            "s_bfe_u32 s60, s40, 0x40006\n\t"
+            "s_and_b32 s61, s40, 63\n\t"
+            "s_set_gpr_idx_on s60, 0x1\n\t"
+            "v_mov_b32 v41, v60\n\t"
+            "s_set_gpr_idx_off\n\t"
+            "s_bfe_u32 s62, s43, 0x20018\n\t"
+            "s_mov_b64 exec, s[62:63]\n\t"
             "v_add_u32 v42, s44, %[lane]\n\t"
             "v_and_b32 v42, v47, v42\n\t"
             "v_lshrrev_b32_e64 v44, v48, s43\n\t"
             "ds_write_b8 v42, v44\n\t"
-            "s_bcnt1_i32_b32 s47, s47\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "s_bcnt1_i32_b32 s47, s62\n\t"
             "s_add_u32 s44, s44, s47\n\t"
-            "s_waitcnt lgkmcnt(1)\n\t"                     // LDS returns in order: all but the youngest (the byte store) = the lookup
-            "v_readfirstlane_b32 s43, v41\n\t"
+            "v_readlane_b32 s43, v41, s61\n\t"
             "s_or_b32 s43, s43, s46\n\t"
             "s_cmp_lt_u32 s43, 0x10000000\n\t"
-            "s_cbranch_scc1 2b\n"
+            "s_cbranch_scc1 2b\n\t"
             // ---------------------------------------------------------------- not a literal
-            "3:\n\t"
+            "3:\n"
             "s_cmp_lg_u32 s46, 0\n\t"
-            "s_cbranch_scc1 9f\n\t"                          // reason 0: the round ends
+            "s_cbranch_scc1 9f\n\t"
             "s_cmp_ge_u32 s43, 0x20000000\n\t"
-            "s_cbranch_scc1 20f\n\t"                         // reason 1: end of block / long code
+            "s_cbranch_scc1 20f\n\t"
             // ---- a match: length
             "s_and_b32 s47, s43, 15\n\t"
             "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
@@ -715,17 +739,18 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_bfe_u32 s50, s43, 0x100008\n\t"
             "s_add_u32 s50, s50, s48\n\t"
             "s_cmp_le_u32 s42, 32\n\t"
-            "s_cbranch_scc1 12f\n"
-            "13:\n\t"
-            // ---- distance
-            "s_lshl_b32 s47, s40, 2\n\t"
-            "v_and_b32 v40, s47, v46\n\t"
-            "ds_read_b32 v43, v40 offset:%[dtab]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_readfirstlane_b32 s52, v43\n\t"
+            "s_cbranch_scc1 12f\n\t"
+            // ---- distance (table in v76..v79)
+            "13:\n"
+            "s_bfe_u32 s60, s40, 0x20006\n\t"
+            "s_and_b32 s61, s40, 63\n\t"
+            "s_set_gpr_idx_on s60, 0x1\n\t"
+            "v_mov_b32 v43, v76\n\t"
+            "s_set_gpr_idx_off\n\t"
+            "v_readlane_b32 s52, v43, s61\n\t"
             "s_and_b32 s47, s52, 15\n\t"
             "s_cmp_eq_u32 s47, 0\n\t"
-            "s_cbranch_scc1 21f\n\t"                         // reason 2: long distance code
+            "s_cbranch_scc1 21f\n\t"
             "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
             "s_sub_u32 s42, s42, s47\n\t"
             "s_or_b32 s53, s53, s52\n\t"
@@ -737,38 +762,50 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_bfe_u32 s51, s52, 0x100008\n\t"
             "s_add_u32 s51, s51, s48\n\t"
             "s_cmp_gt_u32 s51, s44\n\t"
-            "s_cselect_b32 s54, 5, s54\n\t"                  // NFI_ERR_DISTANCE, sticky
+            "s_cselect_b32 s54, 5, s54\n\t"
             "s_cmp_le_u32 s42, 32\n\t"
-            "s_cbranch_scc1 14f\n"
-            "15:\n\t"
-            "s_cmp_ge_u32 s50, 64\n\t"
-            "s_cbranch_scc1 22f\n\t"                         // reason 3: a long copy
+            "s_cbranch_scc1 14f\n\t"
+            "15:\n"
             "s_cmp_lt_u32 s51, s50\n\t"
-            "s_cbranch_scc1 22f\n\t"                         // reason 3: an overlapping copy
+            "s_cbranch_scc1 22f\n\t"
             "s_cmp_gt_u32 s51, %[win]\n\t"
-            "s_cbranch_scc1 22f\n\t"                         // reason 3: a far copy (source older than the LDS window)
-            // ---- next entry requested, then the copy: one step of (len) lanes
-            "s_lshl_b32 s47, s40, 2\n\t"
-            "v_and_b32 v40, s47, v45\n\t"
-            "ds_read_b32 v41, v40 offset:%[lit]\n\t"
-            "s_bfm_b64 exec, s50, 0\n\t"
+            "s_cbranch_scc1 22f\n\t"
+            // ---- next entry looked up, then the copy: steps of up to 64 lanes (source before destination: dist >= len here)
+            "s_bfe_u32 s60, s40, 0x40006\n\t"
+            "s_and_b32 s61, s40, 63\n\t"
+            "s_set_gpr_idx_on s60, 0x1\n\t"
+            "v_mov_b32 v41, v60\n\t"
+            "s_set_gpr_idx_off\n\t"
             "v_add_u32 v42, s44, %[lane]\n\t"
             "v_subrev_u32 v43, s51, v42\n\t"
-            "v_and_b32 v43, v47, v43\n\t"
-            "v_and_b32 v42, v47, v42\n\t"
-            "ds_read_u8 v44, v43\n\t"
             "s_add_u32 s44, s44, s50\n\t"
             "s_cmp_ge_u32 s44, s56\n\t"
-            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // window full: the round ends after this symbol
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"
+            "17:\n"
+            "s_min_u32 s47, s50, 64\n\t"
+            "s_bfm_b64 exec, s47, 0\n\t"
+            "s_cmp_ge_u32 s50, 64\n\t"
+            "s_cselect_b64 exec, -1, exec\n\t"
+            "v_and_b32 v46, v47, v43\n\t"
+            "v_and_b32 v45, v47, v42\n\t"
+            "ds_read_u8 v44, v46\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
-            "ds_write_b8 v42, v44\n\t"
-            "s_mov_b64 exec, 3\n\t"
-            "v_readfirstlane_b32 s43, v41\n\t"
+            "ds_write_b8 v45, v44\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "s_sub_u32 s50, s50, s47\n\t"
+            "v_add_u32 v42, 64, v42\n\t"
+            "v_add_u32 v43, 64, v43\n\t"
+            "s_cmp_lg_u32 s50, 0\n\t"
+            "s_cbranch_scc1 17b\n\t"
+            "v_readlane_b32 s43, v41, s61\n\t"
             "s_or_b32 s43, s43, s46\n\t"
-            "s_branch 1b\n"
-            // ---------------------------------------------------------------- refills of the bit buffer: out of line, one copy
-            // per site (a taken branch costs a lone wavefront ~21 cycles -- tools/lds_chain.hip -- so no shared trampoline)
-            "10:\n\t"
+            "s_cmp_lt_u32 s43, 0x10000000\n\t"
+            "s_cbranch_scc1 2b\n\t"
+            "s_branch 3b\n\t"
+            // ---------------------------------------------------------------- refills of the bit buffer: out of line, one copy per
+            // site (a taken branch costs a lone wavefront ~21 cycles -- tools/lds_chain.hip -- so no shared trampoline)
+            "10:\n"
+            "s_waitcnt lgkmcnt(0)\n\t"
             "v_readfirstlane_b32 s48, %[nextw]\n\t"
             "s_mov_b32 s49, 0\n\t"
             "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
@@ -780,11 +817,12 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "v_mov_b32 v40, s47\n\t"
             "ds_read_b32 %[nextw], v40 offset:%[ring]\n\t"
             "s_cmp_ge_u32 s45, s55\n\t"
-            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // ring low: the round ends at the next symbol boundary
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"
             "s_cmp_ge_u32 s44, s56\n\t"
-            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // window nearly full (a run of literals is only checked here)
-            "s_branch 11b\n"
-            "12:\n\t"
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"
+            "s_branch 11b\n\t"
+            "12:\n"
+            "s_waitcnt lgkmcnt(0)\n\t"
             "v_readfirstlane_b32 s48, %[nextw]\n\t"
             "s_mov_b32 s49, 0\n\t"
             "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
@@ -796,11 +834,12 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "v_mov_b32 v40, s47\n\t"
             "ds_read_b32 %[nextw], v40 offset:%[ring]\n\t"
             "s_cmp_ge_u32 s45, s55\n\t"
-            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // ring low: the round ends at the next symbol boundary
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"
             "s_cmp_ge_u32 s44, s56\n\t"
-            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // window nearly full (a run of literals is only checked here)
-            "s_branch 13b\n"
-            "14:\n\t"
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"
+            "s_branch 13b\n\t"
+            "14:\n"
+            "s_waitcnt lgkmcnt(0)\n\t"
             "v_readfirstlane_b32 s48, %[nextw]\n\t"
             "s_mov_b32 s49, 0\n\t"
             "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
@@ -812,23 +851,23 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "v_mov_b32 v40, s47\n\t"
             "ds_read_b32 %[nextw], v40 offset:%[ring]\n\t"
             "s_cmp_ge_u32 s45, s55\n\t"
-            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // ring low: the round ends at the next symbol boundary
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"
             "s_cmp_ge_u32 s44, s56\n\t"
-            "s_cselect_b32 s46, 0x40000000, s46\n\t"         // window nearly full (a run of literals is only checked here)
-            "s_branch 15b\n"
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"
+            "s_branch 15b\n\t"
             // ---------------------------------------------------------------- exits
-            "20:\n\t"
+            "20:\n"
             "s_mov_b32 s57, 1\n\t"
-            "s_branch 8f\n"
-            "21:\n\t"
+            "s_branch 8f\n\t"
+            "21:\n"
             "s_mov_b32 s57, 2\n\t"
-            "s_branch 8f\n"
-            "22:\n\t"
+            "s_branch 8f\n\t"
+            "22:\n"
             "s_mov_b32 s57, 3\n\t"
-            "s_branch 8f\n"
-            "9:\n\t"
-            "s_mov_b32 s57, 0\n"
-            "8:\n\t"
+            "s_branch 8f\n\t"
+            "9:\n"
+            "s_mov_b32 s57, 0\n\t"
+            "8:\n"
             "s_waitcnt lgkmcnt(0)\n\t"
             "s_mov_b64 exec, s[58:59]\n\t"
             "s_mov_b64 %[buf], s[40:41]\n\t"
@@ -849,7 +888,9 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
               [lit] "n"(__builtin_offsetof(NfiCtx, lit_tab)), [dtab] "n"(__builtin_offsetof(NfiCtx, dist_tab)),
               [ring] "n"(__builtin_offsetof(NfiCtx, ring)), [win] "n"(kNfiWindow), [wmask] "n"(kNfiWindow - 1)
             : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52",
-              "s53", "s54", "s55", "s56", "s57", "s58", "s59", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48");
+              "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v41", "v42", "v43", "v44", "v45",
+              "v46", "v47", "v48", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73",
+              "v74", "v75", "v76", "v77", "v78", "v79");
         // ---- the block left at a symbol boundary: the rare cases, in the portable version's statements
         if (reason == 0) break;
         if (reason == 1) {                           // end of block, or a literal / length code longer than the table
