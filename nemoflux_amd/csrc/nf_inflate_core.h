@@ -663,12 +663,14 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_mov_b32 s51, 0\n\t"
             "s_mov_b32 s63, 0\n\t"
             "s_mov_b64 exec, -1\n\t"
-            "v_mov_b32 v47, %[wmask]\n\t"
             "v_lshlrev_b32 v48, 3, %[lane]\n\t"
             "v_add_u32 v48, 8, v48\n\t"
             "v_lshlrev_b32 v40, 2, %[lane]\n\t"
-            // the lookup tables move into registers: 1024 literal / length entries = v60..v75 x 64 lanes, 256 distance entries =
-            // v76..v79; a lookup is VGPR index mode for the row + v_readlane for the lane: 33 ns against 50 for the LDS round trip
+            // The lookup tables move into registers: 1024 literal / length entries = v60..v75 x 64 lanes, 256 distance entries =
+            // v76..v79.  VGPR index mode stays ON for the whole block with M0 = the row of the pending lookup, so a lookup is
+            // s_set_gpr_idx_idx (row) + v_readlane ..., v60 / v76, lane: no LDS round trip in the chain (tools/lds_chain.hip: 33 ns
+            // against 50).  While the mode is on every other vector instruction of the block takes an SGPR or a constant as its
+            // first source (only VGPR first sources are indexed); the refill, which reads one, sets the index to 0 first.
             "ds_read_b32 v60, v40 offset:%[lit]+0\n\t"
             "ds_read_b32 v61, v40 offset:%[lit]+256\n\t"
             "ds_read_b32 v62, v40 offset:%[lit]+512\n\t"
@@ -690,11 +692,13 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "ds_read_b32 v78, v40 offset:%[dtab]+512\n\t"
             "ds_read_b32 v79, v40 offset:%[dtab]+768\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
+            "s_mov_b64 exec, 3\n\t"
+            "s_set_gpr_idx_on s63, 0x1\n\t"
             // ---------------------------------------------------------------- dispatch on the entry at the head
             "1:\n"
             "s_cmp_lt_u32 s43, 0x10000000\n\t"
             "s_cbranch_scc0 3f\n\t"
-            // ---------------------------------------------------------------- literal run (exec = all lanes between the stores)
+            // ---------------------------------------------------------------- literal run: lanes 0 and 1 store, exec_hi stays 0
             "2:\n"
             "s_and_b32 s47, s43, 15\n\t"
             "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
@@ -704,19 +708,16 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "11:\n"
             "s_bfe_u32 s60, s40, 0x40006\n\t"
             "s_and_b32 s61, s40, 63\n\t"
-            "s_set_gpr_idx_on s60, 0x1\n\t"
-            "v_mov_b32 v41, v60\n\t"
-            "s_set_gpr_idx_off\n\t"
+            "s_set_gpr_idx_idx s60\n\t"
             "s_bfe_u32 s62, s43, 0x20018\n\t"
-            "s_mov_b64 exec, s[62:63]\n\t"
+            "s_mov_b32 exec_lo, s62\n\t"
             "v_add_u32 v42, s44, %[lane]\n\t"
-            "v_and_b32 v42, v47, v42\n\t"
-            "v_lshrrev_b32_e64 v44, v48, s43\n\t"
+            "v_and_b32 v42, %[wmask], v42\n\t"
+            "v_bfe_u32 v44, s43, v48, 8\n\t"
             "ds_write_b8 v42, v44\n\t"
-            "s_mov_b64 exec, -1\n\t"
             "s_bcnt1_i32_b32 s47, s62\n\t"
             "s_add_u32 s44, s44, s47\n\t"
-            "v_readlane_b32 s43, v41, s61\n\t"
+            "v_readlane_b32 s43, v60, s61\n\t"
             "s_or_b32 s43, s43, s46\n\t"
             "s_cmp_lt_u32 s43, 0x10000000\n\t"
             "s_cbranch_scc1 2b\n\t"
@@ -744,10 +745,8 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "13:\n"
             "s_bfe_u32 s60, s40, 0x20006\n\t"
             "s_and_b32 s61, s40, 63\n\t"
-            "s_set_gpr_idx_on s60, 0x1\n\t"
-            "v_mov_b32 v43, v76\n\t"
-            "s_set_gpr_idx_off\n\t"
-            "v_readlane_b32 s52, v43, s61\n\t"
+            "s_set_gpr_idx_idx s60\n\t"
+            "v_readlane_b32 s52, v76, s61\n\t"
             "s_and_b32 s47, s52, 15\n\t"
             "s_cmp_eq_u32 s47, 0\n\t"
             "s_cbranch_scc1 21f\n\t"
@@ -770,12 +769,8 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_cbranch_scc1 22f\n\t"
             "s_cmp_gt_u32 s51, %[win]\n\t"
             "s_cbranch_scc1 22f\n\t"
-            // ---- next entry looked up, then the copy: steps of up to 64 lanes (source before destination: dist >= len here)
-            "s_bfe_u32 s60, s40, 0x40006\n\t"
-            "s_and_b32 s61, s40, 63\n\t"
-            "s_set_gpr_idx_on s60, 0x1\n\t"
-            "v_mov_b32 v41, v60\n\t"
-            "s_set_gpr_idx_off\n\t"
+            // ---- the copy: steps of up to 64 lanes (source before destination: dist >= len here), then the next entry
+            "s_mov_b64 exec, -1\n\t"                        // every lane needs its addresses
             "v_add_u32 v42, s44, %[lane]\n\t"
             "v_subrev_u32 v43, s51, v42\n\t"
             "s_add_u32 s44, s44, s50\n\t"
@@ -786,18 +781,21 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_bfm_b64 exec, s47, 0\n\t"
             "s_cmp_ge_u32 s50, 64\n\t"
             "s_cselect_b64 exec, -1, exec\n\t"
-            "v_and_b32 v46, v47, v43\n\t"
-            "v_and_b32 v45, v47, v42\n\t"
+            "v_and_b32 v46, %[wmask], v43\n\t"
+            "v_and_b32 v45, %[wmask], v42\n\t"
             "ds_read_u8 v44, v46\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "ds_write_b8 v45, v44\n\t"
-            "s_mov_b64 exec, -1\n\t"
             "s_sub_u32 s50, s50, s47\n\t"
             "v_add_u32 v42, 64, v42\n\t"
             "v_add_u32 v43, 64, v43\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "ds_write_b8 v45, v44\n\t"
             "s_cmp_lg_u32 s50, 0\n\t"
             "s_cbranch_scc1 17b\n\t"
-            "v_readlane_b32 s43, v41, s61\n\t"
+            "s_mov_b64 exec, 3\n\t"
+            "s_bfe_u32 s60, s40, 0x40006\n\t"
+            "s_and_b32 s61, s40, 63\n\t"
+            "s_set_gpr_idx_idx s60\n\t"
+            "v_readlane_b32 s43, v60, s61\n\t"
             "s_or_b32 s43, s43, s46\n\t"
             "s_cmp_lt_u32 s43, 0x10000000\n\t"
             "s_cbranch_scc1 2b\n\t"
@@ -806,6 +804,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             // site (a taken branch costs a lone wavefront ~21 cycles -- tools/lds_chain.hip -- so no shared trampoline)
             "10:\n"
             "s_waitcnt lgkmcnt(0)\n\t"
+            "s_set_gpr_idx_idx s63\n\t"
             "v_readfirstlane_b32 s48, %[nextw]\n\t"
             "s_mov_b32 s49, 0\n\t"
             "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
@@ -823,6 +822,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_branch 11b\n\t"
             "12:\n"
             "s_waitcnt lgkmcnt(0)\n\t"
+            "s_set_gpr_idx_idx s63\n\t"
             "v_readfirstlane_b32 s48, %[nextw]\n\t"
             "s_mov_b32 s49, 0\n\t"
             "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
@@ -840,6 +840,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_branch 13b\n\t"
             "14:\n"
             "s_waitcnt lgkmcnt(0)\n\t"
+            "s_set_gpr_idx_idx s63\n\t"
             "v_readfirstlane_b32 s48, %[nextw]\n\t"
             "s_mov_b32 s49, 0\n\t"
             "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
@@ -868,6 +869,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "9:\n"
             "s_mov_b32 s57, 0\n\t"
             "8:\n"
+            "s_set_gpr_idx_off\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "s_mov_b64 exec, s[58:59]\n\t"
             "s_mov_b64 %[buf], s[40:41]\n\t"
@@ -889,7 +891,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
               [ring] "n"(__builtin_offsetof(NfiCtx, ring)), [win] "n"(kNfiWindow), [wmask] "n"(kNfiWindow - 1)
             : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52",
               "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v41", "v42", "v43", "v44", "v45",
-              "v46", "v47", "v48", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73",
+              "v46", "v48", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73",
               "v74", "v75", "v76", "v77", "v78", "v79");
         // ---- the block left at a symbol boundary: the rare cases, in the portable version's statements
         if (reason == 0) break;
