@@ -662,6 +662,8 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_mov_b32 s50, 0\n\t"
             "s_mov_b32 s51, 0\n\t"
             "s_mov_b32 s63, 0\n\t"
+            "s_cmp_eq_u32 s46, 0\n\t"
+            "s_cselect_b32 s39, 0x10000000, 0\n\t"
             "s_mov_b64 exec, -1\n\t"
             "v_lshlrev_b32 v48, 3, %[lane]\n\t"
             "v_add_u32 v48, 8, v48\n\t"
@@ -696,7 +698,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_set_gpr_idx_on s63, 0x1\n\t"
             // ---------------------------------------------------------------- dispatch on the entry at the head
             "1:\n"
-            "s_cmp_lt_u32 s43, 0x10000000\n\t"
+            "s_cmp_lt_u32 s43, s39\n\t"
             "s_cbranch_scc0 3f\n\t"
             // ---------------------------------------------------------------- literal run: lanes 0 and 1 store, exec_hi stays 0
             "2:\n"
@@ -718,10 +720,9 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_bcnt1_i32_b32 s47, s62\n\t"
             "s_add_u32 s44, s44, s47\n\t"
             "v_readlane_b32 s43, v60, s61\n\t"
-            "s_or_b32 s43, s43, s46\n\t"
-            "s_cmp_lt_u32 s43, 0x10000000\n\t"
+            "s_cmp_lt_u32 s43, s39\n\t"
             "s_cbranch_scc1 2b\n\t"
-            // ---------------------------------------------------------------- not a literal
+            // ---------------------------------------------------------------- not a literal (or the round has to end)
             "3:\n"
             "s_cmp_lg_u32 s46, 0\n\t"
             "s_cbranch_scc1 9f\n\t"
@@ -767,16 +768,43 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "15:\n"
             "s_cmp_lt_u32 s51, s50\n\t"
             "s_cbranch_scc1 22f\n\t"
+            ".if %[win] < 32768\n"
             "s_cmp_gt_u32 s51, %[win]\n\t"
             "s_cbranch_scc1 22f\n\t"
-            // ---- the copy: steps of up to 64 lanes (source before destination: dist >= len here), then the next entry
-            "s_mov_b64 exec, -1\n\t"                        // every lane needs its addresses
+            ".endif\n"
+            "s_cmp_ge_u32 s50, 64\n\t"
+            "s_cbranch_scc1 17f\n\t"
+            // ---- the copy, one step of len < 64 lanes (source before destination: dist >= len here), then the next entry
+            "s_bfm_b64 exec, s50, 0\n\t"
+            "v_add_u32 v42, s44, %[lane]\n\t"
+            "v_subrev_u32 v43, s51, v42\n\t"
+            "v_and_b32 v43, %[wmask], v43\n\t"
+            "v_and_b32 v42, %[wmask], v42\n\t"
+            "ds_read_u8 v44, v43\n\t"
+            "s_add_u32 s44, s44, s50\n\t"
+            "s_cmp_ge_u32 s44, s56\n\t"
+            "s_cselect_b32 s46, 0x40000000, s46\n\t"
+            "s_cselect_b32 s39, 0, s39\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "ds_write_b8 v42, v44\n\t"
+            "s_mov_b64 exec, 3\n\t"
+            "s_bfe_u32 s60, s40, 0x40006\n\t"
+            "s_and_b32 s61, s40, 63\n\t"
+            "s_set_gpr_idx_idx s60\n\t"
+            "v_readlane_b32 s43, v60, s61\n\t"
+            "s_cmp_lt_u32 s43, s39\n\t"
+            "s_cbranch_scc1 2b\n\t"
+            "s_branch 3b\n\t"
+            // ---- copies of 64 bytes and more: steps of 64 lanes (out of line)
+            "17:\n"
+            "s_mov_b64 exec, -1\n\t"
             "v_add_u32 v42, s44, %[lane]\n\t"
             "v_subrev_u32 v43, s51, v42\n\t"
             "s_add_u32 s44, s44, s50\n\t"
             "s_cmp_ge_u32 s44, s56\n\t"
             "s_cselect_b32 s46, 0x40000000, s46\n\t"
-            "17:\n"
+            "s_cselect_b32 s39, 0, s39\n\t"
+            "18:\n"
             "s_min_u32 s47, s50, 64\n\t"
             "s_bfm_b64 exec, s47, 0\n\t"
             "s_cmp_ge_u32 s50, 64\n\t"
@@ -790,14 +818,13 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_waitcnt lgkmcnt(0)\n\t"
             "ds_write_b8 v45, v44\n\t"
             "s_cmp_lg_u32 s50, 0\n\t"
-            "s_cbranch_scc1 17b\n\t"
+            "s_cbranch_scc1 18b\n\t"
             "s_mov_b64 exec, 3\n\t"
             "s_bfe_u32 s60, s40, 0x40006\n\t"
             "s_and_b32 s61, s40, 63\n\t"
             "s_set_gpr_idx_idx s60\n\t"
             "v_readlane_b32 s43, v60, s61\n\t"
-            "s_or_b32 s43, s43, s46\n\t"
-            "s_cmp_lt_u32 s43, 0x10000000\n\t"
+            "s_cmp_lt_u32 s43, s39\n\t"
             "s_cbranch_scc1 2b\n\t"
             "s_branch 3b\n\t"
             // ---------------------------------------------------------------- refills of the bit buffer: out of line, one copy per
@@ -817,8 +844,10 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "ds_read_b32 %[nextw], v40 offset:%[ring]\n\t"
             "s_cmp_ge_u32 s45, s55\n\t"
             "s_cselect_b32 s46, 0x40000000, s46\n\t"
+            "s_cselect_b32 s39, 0, s39\n\t"
             "s_cmp_ge_u32 s44, s56\n\t"
             "s_cselect_b32 s46, 0x40000000, s46\n\t"
+            "s_cselect_b32 s39, 0, s39\n\t"
             "s_branch 11b\n\t"
             "12:\n"
             "s_waitcnt lgkmcnt(0)\n\t"
@@ -835,8 +864,10 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "ds_read_b32 %[nextw], v40 offset:%[ring]\n\t"
             "s_cmp_ge_u32 s45, s55\n\t"
             "s_cselect_b32 s46, 0x40000000, s46\n\t"
+            "s_cselect_b32 s39, 0, s39\n\t"
             "s_cmp_ge_u32 s44, s56\n\t"
             "s_cselect_b32 s46, 0x40000000, s46\n\t"
+            "s_cselect_b32 s39, 0, s39\n\t"
             "s_branch 13b\n\t"
             "14:\n"
             "s_waitcnt lgkmcnt(0)\n\t"
@@ -853,8 +884,10 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "ds_read_b32 %[nextw], v40 offset:%[ring]\n\t"
             "s_cmp_ge_u32 s45, s55\n\t"
             "s_cselect_b32 s46, 0x40000000, s46\n\t"
+            "s_cselect_b32 s39, 0, s39\n\t"
             "s_cmp_ge_u32 s44, s56\n\t"
             "s_cselect_b32 s46, 0x40000000, s46\n\t"
+            "s_cselect_b32 s39, 0, s39\n\t"
             "s_branch 15b\n\t"
             // ---------------------------------------------------------------- exits
             "20:\n"
@@ -874,6 +907,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_mov_b64 exec, s[58:59]\n\t"
             "s_mov_b64 %[buf], s[40:41]\n\t"
             "s_mov_b32 %[cnt], s42\n\t"
+            "s_or_b32 s43, s43, s46\n\t"
             "s_mov_b32 %[e], s43\n\t"
             "s_mov_b32 %[pos], s44\n\t"
             "s_mov_b32 %[word], s45\n\t"
@@ -889,9 +923,9 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             : [word_stop] "s"(word_stop), [hard_stop] "s"(hard_stop), [lane] "v"(lane),
               [lit] "n"(__builtin_offsetof(NfiCtx, lit_tab)), [dtab] "n"(__builtin_offsetof(NfiCtx, dist_tab)),
               [ring] "n"(__builtin_offsetof(NfiCtx, ring)), [win] "n"(kNfiWindow), [wmask] "n"(kNfiWindow - 1)
-            : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52",
-              "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v41", "v42", "v43", "v44", "v45",
-              "v46", "v48", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73",
+            : "memory", "scc", "vcc", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+              "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v41", "v42", "v43", "v44",
+              "v45", "v46", "v48", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73",
               "v74", "v75", "v76", "v77", "v78", "v79");
         // ---- the block left at a symbol boundary: the rare cases, in the portable version's statements
         if (reason == 0) break;
