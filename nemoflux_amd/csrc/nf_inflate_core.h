@@ -8,13 +8,14 @@
 //
 // Work inside the wavefront (the format is serial per stream, the parallelism is ACROSS streams):
 //   input    all lanes keep the LDS input ring filled (coalesced 4-byte words from HBM)
-//   decode   all lanes run the symbol decoder on UNIFORM values (scalar code).  The decoder is a chain of dependent LDS table
-//            lookups (~50 cycles each), so what it costs is LOOKUPS PER BYTE and what sits between two lookups:
+//   decode   all lanes run the symbol decoder on UNIFORM values (scalar code).  The decoder is a chain of dependent table
+//            lookups, so what it costs is LOOKUPS PER BYTE and what sits between two lookups:
 //              * a table entry carries everything about its symbol -- one literal or TWO (when both codes fit the index),
 //                or a length's base + extra-bit count, or a distance's -- so no symbol needs arithmetic or a second
 //                dependent read to be understood;
-//              * the entry of the NEXT symbol is requested before the current symbol takes effect: a literal's byte store
-//                and a match's 64-lane copy run under that lookup's latency;
+//              * the device's hot loop is hand-written ISA with the tables held in REGISTERS (nfi_decode_round_asm: a lookup
+//                is VGPR index mode + v_readlane, no LDS round trip); the portable form (nfi_decode_round_cxx: the host build,
+//                and the rare cases on the device) requests the entry of the NEXT symbol before the current one takes effect;
 //              * a literal is one byte store into the 32 KiB LDS window, a match is copied by the 64 lanes on the spot
 //                (overlapping copies by the period rule) -- stream order, no queue, no barrier.
 //   stored   stored blocks go from HBM to the window four bytes per lane, without the ring
@@ -607,16 +608,26 @@ NFI_FN void nfi_decode_round_cxx(NfiCtx &c, const uint8_t *flushed_out, uint32_t
 #if !defined(NFI_HOST) && !defined(NFI_PORTABLE_DECODE)
 // ---- the same round, with its hot loop written in gfx9 ISA ------------------------------------------------------------
 // What the compiler makes of nfi_decode_round_cxx costs ~27 instructions and three taken branches per literal lookup and
-// ~100 instructions and a dozen taken branches per match (measured: 107 ns and 320-500 ns); for a lone wavefront every
-// instruction is >= 4 cycles and every taken branch a refetch.  Below: 19 instructions and ONE taken branch per literal
-// lookup, ~60 instructions and two taken branches per match.  The asm block runs literal runs and the common matches
-// (table-coded length and distance, fewer than 64 bytes, source before destination); everything rare leaves the block at a
-// symbol boundary with a reason code and is finished by the C++ statements of the portable version:
-//   reason 0  the round has to end (ring low / window full)        1  head entry is end-of-block or a long code
-//          2  distance code longer than its table (length decoded)  3  copy of >= 64 bytes or overlapping (len, dist decoded)
-// Register plan inside the block (moved in and out at its ends): s[40:41] bit buffer, s42 valid bits, s43 entry at the head,
-// s44 output position, s45 ring word, s46 stop bit, s47-s49 scratch, s50 len, s51 dist, s52 distance entry, s53 OR of the
-// entries used, s54 error, s55 / s56 word / position limits, s57 reason, s[58:59] saved exec; v40-v48 scratch and constants.
+// ~100 instructions and a dozen taken branches per match; for a lone wavefront every instruction is >= 4 cycles, every taken
+// branch ~21 and every dependent LDS lookup ~116 (tools/lds_chain.hip).  Below:
+//   * the LOOKUP TABLES LIVE IN REGISTERS inside the block: 1024 literal / length entries = v60..v75 x 64 lanes, 256 distance
+//     entries = v76..v79 (loaded from the LDS tables on entry).  VGPR index mode is ON for the whole block with M0 = the row
+//     of the pending lookup, so a lookup is  s_set_gpr_idx_idx (row)  +  v_readlane ..., v60 / v76, lane  -- no LDS round
+//     trip in the chain.  Every other vector instruction of the block takes an SGPR or a constant as its first source (only
+//     VGPR first sources are indexed); the refill, which reads one, sets the index to 0 first.
+//   * a literal lookup is 19 instructions and ONE taken branch: both bytes of a pair go out in one ds_write_b8 (lanes 0 and 1,
+//     exec_lo straight from the entry); literal entries are the numbers below s39, which drops to 0 when the round has to end;
+//   * a short match is ~55 instructions and two taken branches (s_bfm_b64 exec = the copy's lanes); copies of 64 bytes and
+//     more loop out of line; the only LDS wait in the block is a copy's own read-before-write;
+//   * the block runs literal runs and matches with table-coded length and distance whose source lies before the destination
+//     (and inside the LDS window); everything rare leaves the block at a symbol boundary with a reason code and is finished
+//     by the C++ statements of the portable version:
+//       reason 0  the round has to end (ring low / window full)        1  head entry is end-of-block or a long code
+//              2  distance code longer than its table (length decoded)  3  overlapping or far copy (len, dist decoded)
+// Register plan inside the block (moved in and out at its ends): s39 literal limit, s[40:41] bit buffer, s42 valid bits, s43
+// entry at the head, s44 output position, s45 ring word, s46 stop bit, s47-s49 scratch, s50 len, s51 dist, s52 distance
+// entry, s53 OR of the entries used, s54 error, s55 / s56 word / position limits, s57 reason, s[58:59] saved exec, s60 / s61
+// row / lane of the pending lookup, s[62:63] lane mask of a literal store; v40-v48 scratch, v60-v79 the tables.
 // ctx sits at LDS address 0 (k_inflate checks): the window is addressed from 0, the tables by immediate offsets.
 NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t out_len)
 {
