@@ -203,6 +203,8 @@ class Dataset(object):
         expected = int(numpy.prod([-(-n // c) for n, c in zip(slab, cdim)]))
         if len(todo) != expected or any(c[2] != 0 or c[3] == UNDEF for c in todo):
             return None                           # chunks never written / stored unfiltered: the host path fills them in
+        if int(numpy.prod(cdim)) * es >= 1 << 31 or any(c[1] >= 1 << 31 for c in todo):
+            return None                           # the device decoder addresses a chunk with 32 bits: the host path takes these
         chunks = [(self._h5._base + c[3], c[1], (0,) * pad + tuple(int(o) for o in c[0][1:rank])) for c in todo]
         chunks.sort(key=lambda c: c[2])
         return dict(chunks=chunks, chunk_dims=cdim, slab_dims=slab, chunk_bytes=int(numpy.prod(cdim)) * es, elem_size=es,
