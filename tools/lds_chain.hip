@@ -9,6 +9,9 @@
 //   +salu8 / +valu8   the same with 8 more dependent SALU / VALU instructions in the chain
 //   +branch2      the same with two taken s_branch hops per iteration
 //   readlane      v_readlane (lane select in an SGPR) -> s_add -> next lane select: the hop of a register-resident chain
+//   register table   the same chase through a table held in 16 VGPRs (VGPR index mode + v_readlane): what the decoder ships
+//   literal step ... the decoder's literal iteration as shipped, and with one ingredient removed or replaced at a time
+//                    (modes 20-32): what a lone wavefront pays for mixing scalar and vector instructions in a dependent loop
 // Build / run (GPU box):  hipcc -O3 --offload-arch=gfx950 tools/lds_chain.hip -o build/lds_chain && build/lds_chain
 #include <hip/hip_runtime.h>
 
@@ -137,6 +140,409 @@ __global__ __launch_bounds__(64) void k_chain(const unsigned *init, int iters, u
                      "s_and_b32 %0, %0, 0xffc\n\t"
                      "s_sub_u32 s48, s48, 1\n\ts_cmp_lg_u32 s48, 0\n\ts_cbranch_scc1 1b"
                      : "+s"(idx) : "s"(iters) : "s48", "v40", "v41", "scc", "memory");
+    } else if (MODE == 20) {    // the decoder literal step as shipped (register table, exec_lo from the entry, one ds_write_b8)
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_set_gpr_idx_on s63, 0x1\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     "s_bfe_u32 s60, s40, 0x40006\n\ts_and_b32 s61, s40, 63\n\ts_set_gpr_idx_idx s60\n\t"
+                     "s_bfe_u32 s62, %1, 0x20018\n\ts_mov_b32 exec_lo, s62\n\tv_add_u32 v42, %2, %3\n\tv_and_b32 v42, 0xfff, v42\n\tv_bfe_u32 v44, %1, v48, 8\n\tds_write_b8 v42, v44 offset:4096\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "v_readlane_b32 %1, v60, s61\n\ts_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 21) {    // the same without the exec write (both lanes always store)
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_set_gpr_idx_on s63, 0x1\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     "s_bfe_u32 s60, s40, 0x40006\n\ts_and_b32 s61, s40, 63\n\ts_set_gpr_idx_idx s60\n\t"
+                     "s_bfe_u32 s62, %1, 0x20018\n\tv_add_u32 v42, %2, %3\n\tv_and_b32 v42, 0xfff, v42\n\tv_bfe_u32 v44, %1, v48, 8\n\tds_write_b8 v42, v44 offset:4096\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "v_readlane_b32 %1, v60, s61\n\ts_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 22) {    // the same without the store
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_set_gpr_idx_on s63, 0x1\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     "s_bfe_u32 s60, s40, 0x40006\n\ts_and_b32 s61, s40, 63\n\ts_set_gpr_idx_idx s60\n\t"
+                     "s_bfe_u32 s62, %1, 0x20018\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "v_readlane_b32 %1, v60, s61\n\ts_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 23) {    // the same without the lookup (entry constant)
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_set_gpr_idx_on s63, 0x1\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     ""
+                     "s_bfe_u32 s62, %1, 0x20018\n\ts_mov_b32 exec_lo, s62\n\tv_add_u32 v42, %2, %3\n\tv_and_b32 v42, 0xfff, v42\n\tv_bfe_u32 v44, %1, v48, 8\n\tds_write_b8 v42, v44 offset:4096\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "s_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 31) {    // no lookup AND VGPR index mode never switched on: the plain cost of the store sequence
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_nop 0\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     ""
+                     "s_bfe_u32 s62, %1, 0x20018\n\ts_mov_b32 exec_lo, s62\n\tv_add_u32 v42, %2, %3\n\tv_and_b32 v42, 0xfff, v42\n\tv_bfe_u32 v44, %1, v48, 8\n\tds_write_b8 v42, v44 offset:4096\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "s_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_nop 0\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 32) {    // index mode switched on only around the lookup (on, v_mov, off, v_readlane); the store runs in normal mode
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_nop 0\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     "s_bfe_u32 s60, s40, 0x40006\n\ts_and_b32 s61, s40, 63\n\ts_mov_b64 exec, -1\n\ts_set_gpr_idx_on s60, 0x1\n\tv_mov_b32 v41, v60\n\ts_set_gpr_idx_off\n\t"
+                     "s_bfe_u32 s62, %1, 0x20018\n\ts_mov_b32 exec_lo, s62\n\tv_add_u32 v42, %2, %3\n\tv_and_b32 v42, 0xfff, v42\n\tv_bfe_u32 v44, %1, v48, 8\n\tds_write_b8 v42, v44 offset:4096\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "v_readlane_b32 %1, v41, s61\n\ts_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_nop 0\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v41", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 24) {    // the shipped step with the store reduced to the ds_write_b8 (constant address and data)
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_set_gpr_idx_on s63, 0x1\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     "s_bfe_u32 s60, s40, 0x40006\n\ts_and_b32 s61, s40, 63\n\ts_set_gpr_idx_idx s60\n\t"
+                     "s_bfe_u32 s62, %1, 0x20018\n\ts_mov_b32 exec_lo, s62\n\tds_write_b8 v42, v44 offset:4096\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "v_readlane_b32 %1, v60, s61\n\ts_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 25) {    // the shipped step with the store reduced to its three vector instructions (no ds_write_b8)
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_set_gpr_idx_on s63, 0x1\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     "s_bfe_u32 s60, s40, 0x40006\n\ts_and_b32 s61, s40, 63\n\ts_set_gpr_idx_idx s60\n\t"
+                     "s_bfe_u32 s62, %1, 0x20018\n\ts_mov_b32 exec_lo, s62\n\tv_add_u32 v42, %2, %3\n\tv_and_b32 v42, 0xfff, v42\n\tv_bfe_u32 v44, %1, v48, 8\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "v_readlane_b32 %1, v60, s61\n\ts_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 27) {    // vector part = v_add (position-dependent) only
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_set_gpr_idx_on s63, 0x1\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     "s_bfe_u32 s60, s40, 0x40006\n\ts_and_b32 s61, s40, 63\n\ts_set_gpr_idx_idx s60\n\t"
+                     "s_bfe_u32 s62, %1, 0x20018\n\ts_mov_b32 exec_lo, s62\n\tv_add_u32 v42, %2, %3\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "v_readlane_b32 %1, v60, s61\n\ts_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 28) {    // vector part = v_bfe (entry-dependent) only
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_set_gpr_idx_on s63, 0x1\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     "s_bfe_u32 s60, s40, 0x40006\n\ts_and_b32 s61, s40, 63\n\ts_set_gpr_idx_idx s60\n\t"
+                     "s_bfe_u32 s62, %1, 0x20018\n\ts_mov_b32 exec_lo, s62\n\tv_bfe_u32 v44, %1, v48, 8\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "v_readlane_b32 %1, v60, s61\n\ts_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 29) {    // vector part = s_lshr + v_mov of the entry (SALU copy first)
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_set_gpr_idx_on s63, 0x1\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     "s_bfe_u32 s60, s40, 0x40006\n\ts_and_b32 s61, s40, 63\n\ts_set_gpr_idx_idx s60\n\t"
+                     "s_bfe_u32 s62, %1, 0x20018\n\ts_mov_b32 exec_lo, s62\n\ts_lshr_b32 s38, %1, 8\n\tv_mov_b32 v44, s38\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "v_readlane_b32 %1, v60, s61\n\ts_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 30) {    // vector part = three vector instructions that read no SGPR
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_set_gpr_idx_on s63, 0x1\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     "s_bfe_u32 s60, s40, 0x40006\n\ts_and_b32 s61, s40, 63\n\ts_set_gpr_idx_idx s60\n\t"
+                     "s_bfe_u32 s62, %1, 0x20018\n\ts_mov_b32 exec_lo, s62\n\tv_add_u32 v42, 5, v48\n\tv_and_b32 v42, 0xfff, v42\n\tv_add_u32 v44, 7, v48\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "v_readlane_b32 %1, v60, s61\n\ts_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
+    } else if (MODE == 26) {    // the shipped step without the address mask (two vector instructions + ds_write_b8)
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_set_gpr_idx_on s63, 0x1\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     "s_bfe_u32 s60, s40, 0x40006\n\ts_and_b32 s61, s40, 63\n\ts_set_gpr_idx_idx s60\n\t"
+                     "s_bfe_u32 s62, %1, 0x20018\n\ts_mov_b32 exec_lo, s62\n\tv_add_u32 v42, %2, %3\n\tv_bfe_u32 v44, %1, v48, 8\n\tds_write_b8 v42, v44 offset:4096\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "v_readlane_b32 %1, v60, s61\n\ts_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
     }
     if (threadIdx.x == 0) out[blockIdx.x] = idx;
 }
@@ -182,6 +588,19 @@ int main()
         if (run<7>("16 dependent valu", d_init, d_out, blocks, iters, 16)) return 1;
         if (run<8>("decoder literal step", d_init, d_out, blocks, iters, 14)) return 1;
         if (run<11>("decoder literal step, lgkmcnt(1)", d_init, d_out, blocks, iters, 14)) return 1;
+        if (run<20>("literal step as shipped", d_init, d_out, blocks, iters, 24)) return 1;
+        if (run<21>("  .. without the exec write", d_init, d_out, blocks, iters, 23)) return 1;
+        if (run<22>("  .. without the store", d_init, d_out, blocks, iters, 19)) return 1;
+        if (run<23>("  .. without the lookup", d_init, d_out, blocks, iters, 20)) return 1;
+        if (run<24>("  .. store = ds_write_b8 only", d_init, d_out, blocks, iters, 21)) return 1;
+        if (run<25>("  .. store = 3 vector instr. only", d_init, d_out, blocks, iters, 23)) return 1;
+        if (run<26>("  .. store without the mask", d_init, d_out, blocks, iters, 23)) return 1;
+        if (run<27>("  .. vector part = v_add(pos) only", d_init, d_out, blocks, iters, 21)) return 1;
+        if (run<28>("  .. vector part = v_bfe(entry) only", d_init, d_out, blocks, iters, 21)) return 1;
+        if (run<29>("  .. vector part = s_lshr + v_mov(entry)", d_init, d_out, blocks, iters, 22)) return 1;
+        if (run<30>("  .. vector part reads no SGPR", d_init, d_out, blocks, iters, 23)) return 1;
+        if (run<31>("  .. no lookup, index mode never on", d_init, d_out, blocks, iters, 20)) return 1;
+        if (run<32>("  .. index mode on only around lookup", d_init, d_out, blocks, iters, 27)) return 1;
         if (run<10>("lds_scalar, loop in asm", d_init, d_out, blocks, iters, 8)) return 1;
         if (run<9>("register table (gpr_idx + readlane)", d_init, d_out, blocks, iters, 10)) return 1;
     }
