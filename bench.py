@@ -249,6 +249,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='number of extra seeded transects')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--no-f32', action='store_true', help='skip the float32 sub-record (N=1, --dtype f64 only)')
+    ap.add_argument('--no-ingest', action='store_true', help='skip the file-ingest sub-record (N=1)')
     ap.add_argument('--dump-totals', action='store_true', help='add the (nt, ntransect) totals to the JSON (small grids)')
     ap.add_argument('--compact', action='store_true',
                     help='NOT the headline configuration: keep only (eU, eV) resident per step (nf_field_set_compact); the '
@@ -318,11 +319,65 @@ def main():
                                                     'kernel', 'avg_launch_ms', 'launches', 'avg_ms_by_kernel',
                                                     'algorithmic_bytes_per_unit', 'wall_frac')},
                       'accuracy': m32['accuracy']}
+    # ---- file ingest (N=1): what a file-backed pass adds in front of the kernels above -- one launch of the device DEFLATE
+    # decoder on 256 copies of a NEMO-like level (field.py:149's lazy NetCDF read: HDF5 shuffle + deflate)
+    if world == 1 and not args.no_ingest:
+        try:
+            out['ingest'] = ingest_record()
+        except Exception as e:      # never costs the headline line
+            out['ingest'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         nfdist.destroy_native_comms()
         dist.destroy_process_group()
+
+
+def ingest_record(streams=256):
+    """One launch of the device decoder (nf_inflate.hip) on `streams` copies of one 1440 x 1021 float32 level, byte-shuffled
+    and deflated at zlib level 4 the way XIOS / netCDF-4 store NEMO output: all streams are resident at once (4 per CU), so
+    the launch takes the time of ONE stream.  The compressed bytes are uploaded first; the timed part is inflate +
+    un-shuffle + placement (torch events on the launch stream); the result is compared with the source bit for bit."""
+    import zlib
+    import torch
+    from nemoflux_amd._lib import DeviceBuffer
+    from nemoflux_amd.ingest import ChunkDecoder, StagedChunks
+    ny, nx = 1021, 1440
+    rng = numpy.random.default_rng(1)
+    y = numpy.linspace(-90, 90, ny)[:, None]
+    x = numpy.linspace(-180, 180, nx)[None, :]
+    f = ((numpy.cos(2 * numpy.pi * y / 360) + numpy.sin(2 * numpy.pi * x / 360)) * 3.1).astype('<f4')
+    f *= (1 + numpy.float32(1e-3) * rng.standard_normal(f.shape, dtype=numpy.float32))
+    comp = zlib.compress(numpy.ascontiguousarray(f.view(numpy.uint8).reshape(-1, 4).T).tobytes(), 4)
+    dec = ChunkDecoder()
+    pad = (len(comp) + 7) & ~7
+    pinned = dec.new_pinned(streams * pad + 64)
+    in_off = numpy.arange(streams, dtype=numpy.int64) * pad
+    for i in range(streams):
+        pinned.array[in_off[i]:in_off[i] + len(comp)] = numpy.frombuffer(comp, numpy.uint8)
+    origin = numpy.zeros((streams, 3), numpy.int64)
+    origin[:, 0] = numpy.arange(streams)
+    plan = dict(chunk_dims=(1, ny, nx), slab_dims=(streams, ny, nx), chunk_bytes=f.nbytes, elem_size=4, shuffled=1)
+    staged = StagedChunks(pinned, streams * pad, in_off, numpy.full(streams, len(comp), numpy.int64), origin, plan)
+    slab = DeviceBuffer(streams * f.nbytes)
+    best = 1e30
+    for rep in range(3):
+        dec.upload(pinned, staged.used)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dec.decode(staged, slab.ptr, uploaded=True)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    got = slab.download((streams, ny, nx), '<f4')
+    ok = bool(numpy.array_equal(got[0].view(numpy.uint32), f.view(numpy.uint32)) and
+              numpy.array_equal(got[streams - 1].view(numpy.uint32), f.view(numpy.uint32)))
+    slab.free()
+    return {'workload': f'{streams} copies of one {nx}x{ny} float32 level, HDF5 shuffle + zlib level 4 ({f.nbytes} bytes from '
+                        f'{len(comp)}): one wavefront per stream, all resident at once',
+            'inflate_unshuffle_place_ms': round(best, 3), 'MB_per_s_per_stream': round(f.nbytes / best / 1e3, 2),
+            'decoded_GB_per_s_per_launch': round(streams * f.nbytes / best / 1e6, 2), 'bit_identical': ok,
+            'kernels': 'nf::k_inflate + nf::k_place16', 'resident_streams_capacity': ChunkDecoder.capacity()}
 
 
 def self_launch(ngpus):

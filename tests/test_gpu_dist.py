@@ -111,6 +111,8 @@ def test_bench_contract_small_workload():
     assert f['dtype'] == 'f32' and f['value'] > 0 and f['roofline']['frac'] > 0
     assert abs(f['roofline']['algorithmic_bytes_per_unit'] - (8 + 64.0 / 9)) < 1e-3
     assert f['accuracy']['max_abs_err_vs_fluxexact'] <= 1e-5 * max(1.0, f['accuracy']['max_abs_exact'])
+    g = d['ingest']                                                   # file-ingest sub-record: one launch of the device decoder
+    assert g.get('bit_identical') is True and g['MB_per_s_per_stream'] > 10 and g['inflate_unshuffle_place_ms'] > 0, g
 
 
 def test_readme_examples_script():
@@ -153,7 +155,7 @@ def _bench_json(extra, nproc=1, launcher='torchrun'):
     import json
     import subprocess
     small = ['--nx', '144', '--ny', '72', '--nz', '9', '--batch', '6', '--steps', '2', '--warmup', '1', '--no-cpu',
-             '--no-f32', '--dump-totals'] + extra
+             '--no-f32', '--no-ingest', '--dump-totals'] + extra
     env = dict(os.environ)
     if nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + small
