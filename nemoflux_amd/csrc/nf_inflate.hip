@@ -11,7 +11,6 @@
 // per time step in XIOS output).  HDF5's shuffle filter stored the bytes of every element de-interleaved (all first bytes,
 // then all second bytes, ...): k_place gathers them back, one element per lane, coalesced on both sides, and puts the
 // chunk where it belongs in the (nz, ny, nx) slab (chunks may tile y and x, edge chunks hang over).
-#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -30,8 +29,6 @@ struct InflateJob {
     unsigned long long in_off;    // first byte of the zlib stream in the compressed buffer
     unsigned in_len;
     unsigned z0, y0, x0;          // origin of the chunk in the slab (elements)
-    unsigned slot;                // the chunk's number as the caller gave it: its place in tmp and in the status array
-    unsigned pad_;
 };
 
 // inflate chunk i into slot i of tmp (chunk_bytes each)
@@ -43,7 +40,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     const int i = blockIdx.x;
     if (i >= njobs) return;
     if ((uint32_t)(uintptr_t)&ctx != 0u) {      // the decoder's hand-written loop addresses ctx from LDS offset 0
-        if (threadIdx.x == 0) status[jobs[i].slot] = NFI_ERR_LAYOUT;
+        if (threadIdx.x == 0) status[i] = NFI_ERR_LAYOUT;
         return;
     }
     const InflateJob job = jobs[i];
@@ -52,8 +49,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ comp
     const unsigned long long want = (job.in_off - first) + job.in_len + 16ull;
     if (readable > want) readable = want & ~3ull;
     const int rc = nfi_inflate_stream(ctx, comp + job.in_off, job.in_len, (uint32_t)readable,
-                                      tmp + (unsigned long long)job.slot * chunk_bytes, chunk_bytes);
-    if (threadIdx.x == 0) status[job.slot] = rc;
+                                      tmp + (unsigned long long)i * chunk_bytes, chunk_bytes);
+    if (threadIdx.x == 0) status[i] = rc;
 }
 
 // Inverse of HDF5's shuffle filter + placement of the chunk in the slab; blockIdx.y walks the chunks.  A shuffled chunk holds
@@ -73,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void k_place(const uint8_t *__restrict__ tm
     const unsigned long long n = (unsigned long long)g.cz * g.cy * g.cx;
     for (int i = blockIdx.y; i < njobs; i += gridDim.y) {
         const InflateJob job = jobs[i];
-        const uint8_t *s = tmp + (unsigned long long)job.slot * chunk_bytes;
+        const uint8_t *s = tmp + (unsigned long long)i * chunk_bytes;
         for (unsigned long long e = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; e < n;
              e += (unsigned long long)gridDim.x * kBlock) {
             const unsigned c = (unsigned)(e % g.cx);
@@ -116,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void k_place4(const uint8_t *__restrict__ t
     const unsigned plane = g.ny * g.nx;
     for (int i = blockIdx.y; i < njobs; i += gridDim.y) {
         const InflateJob job = jobs[i];
-        const uint32_t *s = reinterpret_cast<const uint32_t *>(tmp + (unsigned long long)job.slot * chunk_bytes);
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(tmp + (unsigned long long)i * chunk_bytes);
         for (unsigned q = blockIdx.x * kBlock + threadIdx.x; q < nq; q += gridDim.x * kBlock) {
             const unsigned e = 4 * q;
             unsigned x, y, z;
@@ -171,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void k_place16(const uint8_t *__restrict__ 
     const unsigned n = g.cz * g.cy * g.cx, nq = n / 16, plane = g.ny * g.nx;
     for (int i = blockIdx.y; i < njobs; i += gridDim.y) {
         const InflateJob job = jobs[i];
-        const uint8_t *s = tmp + (unsigned long long)job.slot * chunk_bytes;
+        const uint8_t *s = tmp + (unsigned long long)i * chunk_bytes;
         for (unsigned q = blockIdx.x * kBlock + threadIdx.x; q < nq; q += gridDim.x * kBlock) {
             const unsigned e = 16 * q;
             if (job.z0 + e / plane >= g.nz) continue;            // the levels of an over-hanging chunk that lie beyond the slab
@@ -293,11 +290,8 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
             NF_REQUIRE(origin[3 * i + k] >= 0 && origin[3 * i + k] < slab_dims[k], NF_ERR_ARG,
                        "inflate: a chunk starts outside the slab");
         jobs[i] = InflateJob{(unsigned long long)in_off[i], (unsigned)in_len[i], (unsigned)origin[3 * i], (unsigned)origin[3 * i + 1],
-                             (unsigned)origin[3 * i + 2], (unsigned)i, 0u};
+                             (unsigned)origin[3 * i + 2]};
     }
-    // longest streams first: workgroups are dispatched in order, and when a launch holds more streams than the chip has
-    // decoder slots the later ones start as the earlier ones finish -- the big ones must not be the last to start
-    std::stable_sort(jobs.begin(), jobs.end(), [](const InflateJob &a, const InflateJob &b) { return a.in_len > b.in_len; });
     const size_t comp_pad = comp_padded(comp_bytes);
     const size_t tmp_bytes = (size_t)chunk_bytes * (size_t)n;
     if (comp_host) NF_TRY_RC(comp_reserve(h, comp_pad));
