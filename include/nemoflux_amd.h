@@ -277,6 +277,10 @@ int nf_inflater_capacity(int *streams);
  * staging thread that has just gathered the NEXT group while the GPU still decodes this one (the copy then runs under the
  * decode); a following nf_inflater_run with comp_host = NULL and the same comp_bytes decodes what was uploaded. */
 int nf_inflater_upload(nf_inflater **self, const void *comp_host, size_t comp_bytes);
+/* The same straight from the mapped file, without a staging copy: range i (src_addr[i], len[i] bytes of ordinary host memory)
+ * goes to byte dst_off[i] of the compressed buffer of comp_bytes bytes; what lies between the ranges reads as zeros. */
+int nf_inflater_upload_ranges(nf_inflater **self, const unsigned long long *src_addr, const long long *dst_off,
+                              const long long *len, long long n, size_t comp_bytes);
 int nf_inflater_run(nf_inflater **self, const void *comp_host, size_t comp_bytes, const long long *in_off,
                     const long long *in_len, int nchunks, long long chunk_bytes, int elem_size, int shuffled,
                     const long long *chunk_dims, const long long *slab_dims, const long long *origin, void *out_dev,

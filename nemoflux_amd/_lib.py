@@ -132,6 +132,7 @@ _sig('nf_inflater_new', [_pp])
 _sig('nf_inflater_del', [_pp])
 _sig('nf_inflater_capacity', [c_int_p])
 _sig('nf_inflater_upload', [_pp, ctypes.c_void_p, ctypes.c_size_t])
+_sig('nf_inflater_upload_ranges', [_pp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_size_t])
 _sig('nf_inflater_run', [_pp, ctypes.c_void_p, ctypes.c_size_t, c_ll_p, c_ll_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int,
                          ctypes.c_int, c_ll_p, c_ll_p, c_ll_p, ctypes.c_void_p, ctypes.c_void_p, c_int_p])
 _sig('nf_datagen_bounds', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_long] + [ctypes.c_double] * 6 +

@@ -260,6 +260,31 @@ static const char *inflate_error_name(int rc)
     }
 }
 
+// The same without a staging copy: n byte ranges of (pageable) host memory -- the compressed chunks as they sit in the mapped
+// file -- go to their places in d_comp one hipMemcpyAsync each; the runtime pipelines its own bounce buffers with the DMA, so
+// the host-side gather and the transfer overlap instead of running one after the other.  Complete at return.
+int inflater_upload_ranges(Inflater *h, const unsigned long long *src_addr, const long long *dst_off, const long long *len,
+                           long long n, size_t comp_bytes)
+{
+    NF_REQUIRE(h && src_addr && dst_off && len && n > 0 && comp_bytes > 0, NF_ERR_ARG, "inflate upload: null argument");
+    if (h->device >= 0) NF_HIP(hipSetDevice(h->device));
+    if (!h->copy_stream) NF_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    const size_t comp_pad = comp_padded(comp_bytes);
+    h->uploaded = 0;
+    NF_TRY_RC(comp_reserve(h, comp_pad));
+    for (long long i = 0; i < n; ++i)
+        NF_REQUIRE(len[i] >= 0 && dst_off[i] >= 0 && (size_t)(dst_off[i] + len[i]) <= comp_bytes, NF_ERR_ARG,
+                   "inflate upload: a range lies outside the compressed buffer");
+    NF_HIP(hipMemsetAsync(h->d_comp, 0, comp_pad, h->copy_stream));      // gaps between the ranges and the padding read as zeros
+    for (long long i = 0; i < n; ++i)
+        if (len[i])
+            NF_HIP(hipMemcpyAsync(h->d_comp + dst_off[i], (const void *)(uintptr_t)src_addr[i], (size_t)len[i],
+                                  hipMemcpyHostToDevice, h->copy_stream));
+    NF_HIP(hipStreamSynchronize(h->copy_stream));
+    h->uploaded = comp_bytes;
+    return NF_OK;
+}
+
 int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const long long *in_off, const long long *in_len,
                  int n, long long chunk_bytes, int elem_size, int shuffled, const long long *chunk_dims,
                  const long long *slab_dims, const long long *origin, void *out_dev, hipStream_t s, int *status_host)
@@ -380,6 +405,26 @@ int nf_inflater_new(nf_inflater **self)
     }
     if (hipGetDevice(&h->device) != hipSuccess) h->device = -1;      // no GPU: every run fails loudly later
     return NF_OK;
+}
+
+int nf_inflater_upload_ranges(nf_inflater **self, const unsigned long long *src_addr, const long long *dst_off,
+                              const long long *len, long long n, size_t comp_bytes)
+{
+    if (!self || !*self) {
+        set_error("nf_inflater_upload_ranges: null handle");
+        return NF_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no usable AMD GPU (hipGetDeviceCount); nemoflux_amd has no CPU fallback");
+        return NF_ERR_NO_DEVICE;
+    }
+    try {
+        return inflater_upload_ranges(reinterpret_cast<Inflater *>(*self), src_addr, dst_off, len, n, comp_bytes);
+    } catch (...) {
+        set_error("nf_inflater_upload_ranges: out of host memory");
+        return NF_ERR_HOST;
+    }
 }
 
 int nf_inflater_upload(nf_inflater **self, const void *comp_host, size_t comp_bytes)

@@ -72,7 +72,13 @@ class ChunkDecoder(object):
         Pure host work (memcpy releases the GIL): meant for the prefetch thread."""
         return self.gather_many([(raw, plan, 0)], pinned, plan['slab_dims'][0])[0]
 
-    def gather_many(self, items, pinned, total_nz, threads=None):
+    def upload_ranges(self, plan_ranges, used):
+        """Early upload without the staging copy: `plan_ranges` = (source addresses, destination offsets, lengths) as
+        gather_many(..., copy=False) returned them; the chunks go from the mapped file to HBM one hipMemcpyAsync each."""
+        sa, do, ll = plan_ranges
+        check(lib.nf_inflater_upload_ranges(ctypes.byref(self._h), sa.ctypes.data, do.ctypes.data, ll.ctypes.data, len(ll), int(used)))
+
+    def gather_many(self, items, pinned, total_nz, threads=None, copy=True):
         """items: [(mapped file, device_plan of one slab, z offset of that slab in the group's slab)] -- e.g. uo and vo of
         several time steps, stacked along z into one (total_nz, ny, nx) slab.  The compressed chunks of all of them are
         copied into `pinned` back to back; slabs of the same chunk geometry are merged into ONE StagedChunks (= one launch,
@@ -103,7 +109,9 @@ class ChunkDecoder(object):
         threads = self._threads if threads is None else threads
         sa, da = numpy.array(src_addr, numpy.uint64), numpy.array(dst_addr, numpy.uint64)
         ll = numpy.array(lens, numpy.int64)
-        check(lib.nf_host_gather(sa.ctypes.data, da.ctypes.data, ll.ctypes.data, len(lens), max(1, int(threads))))
+        if copy:
+            check(lib.nf_host_gather(sa.ctypes.data, da.ctypes.data, ll.ctypes.data, len(lens), max(1, int(threads))))
+        self.last_ranges = (sa, (da - numpy.uint64(pinned.ptr)).astype(numpy.int64), ll, keep)   # for upload_ranges
         out = []
         for key, g in groups.items():
             plan = dict(g['plan'])

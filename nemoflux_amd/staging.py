@@ -38,6 +38,7 @@ class StepStager(object):
         self.decoder = None
         self._early_upload = os.environ.get('NF_EARLY_UPLOAD', '1') != '0'
         self._bg_threads = int(os.environ.get('NF_GATHER_THREADS_BG', 8))
+        self._direct_upload = os.environ.get('NF_DIRECT_UPLOAD', '1') != '0'
         self.comp_bytes = [None, None]            # staging size per step of a variable on the device path
         self.group = 1
         if gpu_decode and os.environ.get('NF_GPU_INFLATE', '1') != '0':
@@ -122,11 +123,17 @@ class StepStager(object):
         # early upload the caller's thread copies nothing in the steady state (NF_GATHER_THREADS_BG, default 8)
         import threading
         nthreads = None if threading.current_thread() is threading.main_thread() else self._bg_threads
-        b['staged'] = self.decoder.gather_many(items, b['comp'], 2 * (g1 - g0) * self.nz, nthreads) if items else []
+        early = bool(items) and nthreads is not None and self._early_upload
+        direct = early and self._direct_upload
+        dec = self._decoders[slot] if self.decoder is not None else None
+        b['staged'] = dec.gather_many(items, b['comp'], 2 * (g1 - g0) * self.nz, nthreads, copy=not direct) if items else []
         b['early'] = False
         t_gather = time.perf_counter()
-        if items and nthreads is not None and self._early_upload:     # background thread: the H2D copy runs under the GPU's
-            self._decoders[slot].upload(b['comp'], b['staged'][0].used)  # work on the other slot's group
+        if direct:       # background thread: the chunks go from the mapped file to HBM without the staging copy -- the runtime
+            dec.upload_ranges(dec.last_ranges[:3], b['staged'][0].used)   # pipelines its bounce buffers with the DMA
+            b['early'] = True
+        elif early:      # ... or gathered into pinned memory first, then one copy (NF_DIRECT_UPLOAD=0)
+            dec.upload(b['comp'], b['staged'][0].used)
             b['early'] = True
         self._uploaded[slot] = (-1, -1)
         self._range[slot] = (g0, g1)
