@@ -171,6 +171,38 @@ __global__ __launch_bounds__(64) void k_chain(const unsigned *init, int iters, u
                      : "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
                        "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
         idx = e + pos;
+    } else if (MODE == 33) {    // the shipped step re-ordered: every scalar instruction first, then ONE cluster of vector instructions (store + lookup)
+        unsigned long long buf = 0x0123456789abcdefull;
+        unsigned e = 0x01004105u, pos = 0;
+        asm volatile("v_lshlrev_b32 v40, 2, %3\n\t"
+                     "ds_read_b32 v60, v40 offset:0\n\tds_read_b32 v61, v40 offset:256\n\tds_read_b32 v62, v40 offset:512\n\t"
+                     "ds_read_b32 v63, v40 offset:768\n\tds_read_b32 v64, v40 offset:1024\n\tds_read_b32 v65, v40 offset:1280\n\t"
+                     "ds_read_b32 v66, v40 offset:1536\n\tds_read_b32 v67, v40 offset:1792\n\tds_read_b32 v68, v40 offset:2048\n\t"
+                     "ds_read_b32 v69, v40 offset:2304\n\tds_read_b32 v70, v40 offset:2560\n\tds_read_b32 v71, v40 offset:2816\n\t"
+                     "ds_read_b32 v72, v40 offset:3072\n\tds_read_b32 v73, v40 offset:3328\n\tds_read_b32 v74, v40 offset:3584\n\t"
+                     "ds_read_b32 v75, v40 offset:3840\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "v_lshlrev_b32 v48, 3, %3\n\tv_add_u32 v48, 8, v48\n\t"
+                     "s_mov_b64 s[40:41], %0\n\ts_mov_b64 s[58:59], exec\n\ts_mov_b64 exec, 3\n\ts_mov_b32 s63, 0\n\ts_mov_b32 s39, 0x10000000\n\t"
+                     "s_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s49, %4\n\t"
+                     "s_set_gpr_idx_on s63, 0x1\n"
+                     "2:\n\t"
+                     "s_and_b32 s47, %1, 15\n\ts_lshr_b64 s[40:41], s[40:41], s47\n\ts_sub_u32 s42, s42, s47\n\ts_cmp_le_u32 s42, 32\n\t"
+                     "s_cbranch_scc1 9f\n\t"
+                     "s_bfe_u32 s60, s40, 0x40006\n\ts_and_b32 s61, s40, 63\n\ts_set_gpr_idx_idx s60\n\t"
+                     "s_bfe_u32 s62, %1, 0x20018\n\ts_mov_b32 exec_lo, s62\n\ts_mov_b32 s38, %2\n\ts_mov_b32 s37, %1\n\t"
+                     "s_bcnt1_i32_b32 s47, s62\n\ts_add_u32 %2, %2, s47\n\t"
+                     "v_add_u32 v42, s38, %3\n\tv_and_b32 v42, 0xfff, v42\n\tv_bfe_u32 v44, s37, v48, 8\n\tds_write_b8 v42, v44 offset:4096\n\t"
+                     "v_readlane_b32 %1, v60, s61\n\ts_and_b32 %1, %1, 0x01ffffff\n\ts_or_b32 %1, %1, 0x01000005\n\t"
+                     "s_or_b32 s40, s40, 0x300\n\ts_or_b32 s41, s41, 0x300\n\t"                 // keep the chase alive: the buffer never runs dry
+                     "s_sub_u32 s49, s49, 1\n\ts_cmp_eq_u32 s49, 0\n\ts_cbranch_scc1 9f\n\t"
+                     "s_cmp_lt_u32 %1, s39\n\ts_cbranch_scc1 2b\n"
+                     "9:\n\t"
+                     "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, s[58:59]"
+                     : "+s"(buf), "+s"(e), "+s"(pos)
+                     : "v"(threadIdx.x), "s"(iters)
+                     : "s37", "s38", "s39", "s40", "s41", "s42", "s47", "s49", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v42", "v44", "v48", "v60", "v61", "v62",
+                       "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "scc", "memory");
+        idx = e + pos;
     } else if (MODE == 21) {    // the same without the exec write (both lanes always store)
         unsigned long long buf = 0x0123456789abcdefull;
         unsigned e = 0x01004105u, pos = 0;
@@ -589,6 +621,7 @@ int main()
         if (run<8>("decoder literal step", d_init, d_out, blocks, iters, 14)) return 1;
         if (run<11>("decoder literal step, lgkmcnt(1)", d_init, d_out, blocks, iters, 14)) return 1;
         if (run<20>("literal step as shipped", d_init, d_out, blocks, iters, 24)) return 1;
+        if (run<33>("  .. scalar first, one vector cluster", d_init, d_out, blocks, iters, 26)) return 1;
         if (run<21>("  .. without the exec write", d_init, d_out, blocks, iters, 23)) return 1;
         if (run<22>("  .. without the store", d_init, d_out, blocks, iters, 19)) return 1;
         if (run<23>("  .. without the lookup", d_init, d_out, blocks, iters, 20)) return 1;
