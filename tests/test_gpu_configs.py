@@ -1054,6 +1054,54 @@ def test_file_backed_field_against_the_oracle(prefetch, gpu_decode, oracle):
     assert numpy.array_equal(tot, tot2)
 
 
+def test_all_station_tables_of_the_reference_in_one_batch(oracle):
+    """Every transect file the reference ships (data/**/*.txt, 12 tables: WOCE-style station lists, two of them closed
+    loops) as ONE batch of polylines on a global 720 x 360 x 3 x 2 grid: the device weights entry by entry against the CPU
+    oracle, every transect total of every time step against the oracle's getIntegral, and the two closed loops
+    (atlantic/S3.txt, nz/SNZ.txt) against 0 -- the stations are not grid nodes, but the cell-wise bilinear stream function
+    is continuous, so a closed path telescopes to zero whatever it passes through (README.md:45,58)."""
+    with open(os.path.join(GOLDEN, 'stations.json')) as f:
+        st = json.load(f)
+    names = sorted(st)
+    assert len(names) == 12
+    polys = []
+    for n in names:
+        ll = numpy.array(st[n], dtype=numpy.float64)
+        xyz = numpy.zeros((ll.shape[0], 3))
+        xyz[:, :2] = ll
+        polys.append(xyz)
+    nx, ny, nz, nt = 720, 360, 3, 2
+    dg = device_case(nx, ny, nz, nt, PSI_ZT)
+    f = quiet_field(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, polys)
+    blon, blat = dg.bounds_lon.cpu().numpy(), dg.bounds_lat.cpu().numpy()
+    pts = oracle.assemble_points(blon, blat)
+    ows = [oracle.polyline_weights(pts, xyz) for xyz in polys]
+    cov = f.getCoverage()
+    ce, w, sg = f.getWeights()
+    off = f._tr_off
+    for p, ow in enumerate(ows):                       # entry by entry, per transect
+        sel = (sg >= off[p]) & (sg < off[p + 1])
+        got = {}
+        for a, b, c in zip(ce[sel].tolist(), w[sel].tolist(), (sg[sel] - off[p]).tolist()):
+            got[(c, a)] = got.get((c, a), 0.0) + b
+        ref = ow.as_dict()
+        assert set(got) == set(ref), names[p]
+        assert max(abs(got[k] - ref[k]) for k in ref) <= 1e-13, names[p]
+        assert numpy.allclose(cov[p], ow.coverage, rtol=0, atol=1e-12) and numpy.allclose(cov[p], 1.0, rtol=0, atol=1e-9)
+    u, v = dg.u.cpu().numpy(), dg.v.cpu().numpy()
+    th = dg.zbot - dg.ztop
+    state = oracle.EdgeFluxState(ny, nx)
+    tot, _ = f.computeAll()
+    for t in range(nt):
+        oracle.edge_flux(state, oracle.vertical_integral(u[t], th), oracle.vertical_integral(v[t], th), f.arcLengths)
+        for p, ow in enumerate(ows):
+            want = oracle.get_integral(ow, state.integratedVelocity)
+            scale = numpy.abs(ow.weight * state.integratedVelocity.reshape(-1)[ow.cell_edge]).sum()
+            assert abs(tot[t, p] - want) <= 1e-12 * max(scale, 1e-300), (names[p], t)
+            if names[p] in ('atlantic/S3.txt', 'nz/SNZ.txt'):
+                assert abs(tot[t, p]) <= 1e-11 * max(scale, 1.0), (names[p], t, tot[t, p])
+
+
 @pytest.mark.parametrize('ufile, vfile', [('cf_U.h5', 'cf_V.h5'), ('cf_U32.h5', 'cf_V.h5'), ('cf_U.h5', 'cf_V64.h5'),
                                           ('cf_U32.h5', 'cf_V64c.h5')])
 def test_cf_encoded_files_against_the_oracle(ufile, vfile, oracle):

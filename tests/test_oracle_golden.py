@@ -547,3 +547,37 @@ def test_shared_edge_rule_against_the_sampling_algorithm(oracle):
     b = sum(want[k] * data[k[1]] for k in want)
     scale = sum(abs(got[k] * data[k[1]]) for k in got)
     assert abs(a - b) <= 2e-3 * scale, (a, b)          # the sampling loses a piece of 1/nsub at every cell crossing
+
+
+def test_oracle_all_station_tables_of_the_reference(oracle):
+    """Every transect file the reference ships (data/**/*.txt: 12 WOCE-style station tables, parsed by the reference's own
+    LatLonReader into tests/golden/stations.json) on a global 720 x 360 x 3 x 2 grid: every target segment lies inside the
+    grid (coverage 1), and the two closed loops (atlantic/S3.txt, nz/SNZ.txt) integrate to zero although their stations are
+    no grid nodes -- the cell-wise bilinear stream function is continuous, so a closed path telescopes (README.md:45,58)."""
+    import json
+    with open(os.path.join(GOLDEN, 'stations.json')) as f:
+        st = json.load(f)
+    assert len(st) == 12
+    nx, ny, nz, nt = 720, 360, 3, 2
+    dg = oracle.DataGen(nx, ny, nz, nt)
+    u, v = dg.computeUV("(1+10*z)*(t+1)*(cos(2*pi*y/360) + sin(2*pi*x/360))")
+    pts = oracle.assemble_points(dg.bounds_lon, dg.bounds_lat)
+    arc = oracle.np_arc_lengths(pts)
+    state = oracle.EdgeFluxState(ny, nx)
+    th = dg.zbot - dg.ztop
+    oracle.edge_flux(state, oracle.vertical_integral(u[1], th), oracle.vertical_integral(v[1], th), arc)
+    closed = 0
+    for name in sorted(st):
+        ll = numpy.array(st[name], dtype=numpy.float64)
+        xyz = numpy.zeros((ll.shape[0], 3))
+        xyz[:, :2] = ll
+        w = oracle.polyline_weights(pts, xyz)
+        assert numpy.allclose(w.coverage, 1.0, rtol=0, atol=1e-9), name
+        tot = oracle.get_integral(w, state.integratedVelocity)
+        scale = numpy.abs(w.weight * state.integratedVelocity.reshape(-1)[w.cell_edge]).sum()
+        if numpy.allclose(ll[0], ll[-1]):
+            closed += 1
+            assert abs(tot) <= 1e-12 * scale, (name, tot)
+        else:
+            assert abs(tot) > 1e-6 * scale, (name, tot)      # an open transect of this field carries a flux
+    assert closed == 2
