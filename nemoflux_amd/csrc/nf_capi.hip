@@ -444,7 +444,9 @@ NF_API_CATCH
 int mnt_polylineintegral_getCoverage(PolylineIntegral_t **self, double *coverage)
 try {
     NF_REQUIRE(self && *self && coverage, NF_ERR_ARG, "mnt_polylineintegral_getCoverage: null argument");
-    NF_REQUIRE((*self)->d_row, NF_ERR_STATE, "mnt_polylineintegral_getCoverage: computeWeights first");
+    // also readable after a build that was refused for over-coverage (the message names one segment; this has them all)
+    NF_REQUIRE((*self)->d_row || !(*self)->ws.coverage.empty(), NF_ERR_STATE,
+               "mnt_polylineintegral_getCoverage: computeWeights first");
     const std::vector<double> &c = (*self)->ws.coverage;
     if (!c.empty()) memcpy(coverage, c.data(), sizeof(double) * c.size());
     return NF_OK;
@@ -587,7 +589,7 @@ try {
     NF_REQUIRE(vectors, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null output");
     NF_NEED_DEVICE();
     NF_TRY(launch_face_vectors(v->grid->d_xy, v->d_cell, v->d_pcoords, v->npts, data_dev, v->grid->ncell, layout,
-                               v->d_vectors, nullptr));
+                               v->periodX, v->d_vectors, nullptr));
     NF_HIP(hipMemcpy(vectors, v->d_vectors, sizeof(double) * 3 * v->npts, hipMemcpyDeviceToHost));
     return NF_OK;
 }
@@ -1168,8 +1170,26 @@ try {
         polyline_segments(f->polylines[p].data(), (int)(f->polylines[p].size() / 3), f->poly_cc[p], segs, cc);
         f->tr_off.push_back((int)cc.size());
     }
-    NF_TRY(build_weights(f->d_xy, f->ncell, segs.data(), cc.data(), (int)cc.size(), periodX, &f->ws, f->stream,
-                         f->skip_unsupported));
+    f->weights_built = false;
+    const int bw = build_weights(f->d_xy, f->ncell, segs.data(), cc.data(), (int)cc.size(), periodX, &f->ws, f->stream,
+                                 f->skip_unsupported);
+    if (bw != NF_OK) {
+        // over-covered segment (overlapping cells): name the transect and its own segment index, not the batch's
+        for (size_t q = 0; q < f->ws.coverage.size(); ++q)
+            if (f->ws.coverage[q] > 1.0 + kCoverTol) {
+                size_t p = 0;
+                while (p + 2 < f->tr_off.size() && (size_t)f->tr_off[p + 1] <= q) ++p;
+                char buf[320];
+                snprintf(buf, sizeof buf,
+                         "nf_field_build_weights: transect %zu, target segment %zu is covered %.9g times by the cells of the "
+                         "grid: cells overlap along it (a cell wrapped across the date line with periodX = 0, or duplicated "
+                         "/ folded cells that are not identical), so part of the line would be counted twice",
+                         p, q - (size_t)f->tr_off[p], f->ws.coverage[q]);
+                set_error(buf);
+                break;
+            }
+        return bw;
+    }
     // the engine reduces its own planes: fold the (cell, edge) weights onto the unique edges of (eU, eV) (field.py:219-223)
     // (only on request -- nf_tuning_set("edge_weights", 1) -- because the records measure faster: see nf_integral.hip)
     if (integral_uses_edges()) NF_TRY(fold_weights(&f->ws, f->ncell, f->nx, f->stream));
@@ -1227,7 +1247,8 @@ NF_API_CATCH
 int nf_field_get_coverage(nf_field **self, double *coverage)
 try {
     NF_REQUIRE(self && *self && coverage, NF_ERR_ARG, "nf_field_get_coverage: null argument");
-    NF_REQUIRE((*self)->weights_built, NF_ERR_STATE, "nf_field_get_coverage: build_weights first");
+    NF_REQUIRE((*self)->weights_built || !(*self)->ws.coverage.empty(), NF_ERR_STATE,
+               "nf_field_get_coverage: build_weights first");
     const std::vector<double> &c = (*self)->ws.coverage;
     if (!c.empty()) memcpy(coverage, c.data(), sizeof(double) * c.size());
     return NF_OK;

@@ -74,6 +74,24 @@ __device__ inline bool quad_is_nonconvex(const double *v)
 }
 
 
+// ---- date-line unwrap (round 4) -----------------------------------------------------------------------------------------
+// A global file stores bounds_lon wrapped into one period (say [-180,180]), so the cell that straddles the cut has corners
+// ~350 degrees apart: as a planar quad it is a clockwise sliver across the whole domain that the clip would accept and count
+// a second time.  With a periodic locator (periodX > 0) every corner is brought to within periodX/2 of corner 0 in the
+// lane's REGISTER copy of the cell -- the rule the reference's own generator applies to its rotated grids
+// (datagen.py:161-166, with 270 degrees there).  The corner table in HBM, getPoints() and the arc lengths keep the file's
+// values.  mint's own behaviour on such cells is parity unpinned.
+__device__ inline void unwrap_quad(double *v, double periodX)
+{
+    if (!(periodX > 0.0)) return;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        const double n = rint((v[2 * k] - v[0]) / periodX);
+        if (n != 0.0) v[2 * k] -= n * periodX;
+    }
+}
+constexpr double kCoverTol = 1.e-8;   // a target segment covered more than 1 + this is counted twice somewhere: an error
+
 // ---- launchers (defined in the .hip files) ----------------------------------------------------------
 // K0: geometry.  bounds (ncell,4) of T -> corner table xy (ncell,4,2), arc (ncell,4), arcE/arcN (ncell),
 // lon/lat box (4 doubles: lonmin, lonmax, latmin, latmax as order-preserving keys; see nf_geom.hip).
@@ -174,7 +192,7 @@ int launch_find_points(const double *xy, long ncell, const double *targets_dev, 
                        const long *order_dev, long npts, double periodX, double tol2, unsigned long long *best_dev,
                        long *cell_dev, double *pcoords_dev, hipStream_t s);
 int launch_face_vectors(const double *xy, const long *cell_dev, const double *pcoords_dev, long npts, const double *data,
-                        long ncell, int planes, double *vectors_dev, hipStream_t s);
+                        long ncell, int planes, double periodX, double *vectors_dev, hipStream_t s);
 
 // datagen
 int launch_datagen_bounds(double *blon, double *blat, long ny, long nx, double xmin, double xmax, double ymin,

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kBlock) void k_find_points(const double *__restrict
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = valid ? s_xy[tid * 8 + k] : 0.0;
+    unwrap_quad(v, nshift == 3 ? periodX : 0.0);   // date-line cells, as in K2 (nf_common.h)
     if (valid) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(kBlock) void k_locate_finish(const double *__restri
     double v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = xy[c * 8 + i];
+    unwrap_quad(v, nshift == 3 ? periodX : 0.0);
     double xi, eta;
     inv_bilinear_v(v, targets[3 * p] + (nshift == 3 ? k - 1 : 0) * periodX, targets[3 * p + 1], xi, eta);
     cell[p] = c;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void k_locate_finish(const double *__restri
 __global__ __launch_bounds__(kBlock) void k_face_vectors(const double *__restrict__ xy, const long *__restrict__ cell,
                                                          const double *__restrict__ pcoords, long npts,
                                                          const double *__restrict__ data, long ncell, int planes,
-                                                         double *__restrict__ vectors)
+                                                         double periodX, double *__restrict__ vectors)
 {
     const long p = (long)blockIdx.x * kBlock + threadIdx.x;
     if (p >= npts) return;
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(kBlock) void k_face_vectors(const double *__restric
         double v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = xy[c * 8 + i];
+        unwrap_quad(v, periodX);   // the tangent vectors of a date-line cell are those of the unwrapped quad
         const double xi = pcoords[2 * p], eta = pcoords[2 * p + 1];
         double d0, d1, d2, d3;
         if (planes) {
@@ -201,11 +204,11 @@ int launch_find_points(const double *xy, long ncell, const double *targets_dev, 
 }
 
 int launch_face_vectors(const double *xy, const long *cell_dev, const double *pcoords_dev, long npts, const double *data,
-                        long ncell, int planes, double *vectors_dev, hipStream_t s)
+                        long ncell, int planes, double periodX, double *vectors_dev, hipStream_t s)
 {
     if (npts == 0) return NF_OK;
     hipLaunchKernelGGL(k_face_vectors, dim3((unsigned)((npts + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, xy, cell_dev,
-                       pcoords_dev, npts, data, ncell, planes, vectors_dev);
+                       pcoords_dev, npts, data, ncell, planes, periodX, vectors_dev);
     NF_HIP(hipGetLastError());
     return NF_OK;
 }

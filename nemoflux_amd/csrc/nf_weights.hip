@@ -216,6 +216,7 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
     double cxmin = 1e300, cxmax = -1e300, cymin = 1e300, cymax = -1e300;
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = valid ? s_xy[tid * 8 + k] : 0.0;
+    unwrap_quad(v, nshift == 3 ? periodX : 0.0);   // date-line cells (nf_common.h)
     if (valid) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -721,6 +722,22 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     if (err_word != ~0ull) return refuse(err_word);   // Newton did not converge somewhere (fill pass)
     for (int q = 0; q < nseg; ++q)                     // a zero-length segment has nothing to cover
         if (segs_host[4 * q + 2] == 0.0 && segs_host[4 * q + 3] == 0.0) out->coverage[(size_t)q] = 1.0;
+    // A stretch of a target segment found in two cells that do not hold the SAME sub-segment (overlapping cells) would be
+    // counted twice: refuse, naming the segment.  The coverage stays readable (getCoverage) so the caller can see how much.
+    for (int q = 0; q < nseg; ++q)
+        if (out->coverage[(size_t)q] > 1.0 + kCoverTol) {
+            char buf[320];
+            snprintf(buf, sizeof buf,
+                     "computeWeights: target segment %d is covered %.9g times by the cells of the grid: cells overlap along it "
+                     "(a cell wrapped across the date line with a non-periodic locator, or duplicated / folded cells that "
+                     "are not identical), so part of the line would be counted twice", q, out->coverage[(size_t)q]);
+            set_error(buf);
+            std::vector<double> keep = out->coverage;
+            out->release();
+            out->nseg = nseg;
+            out->coverage.swap(keep);
+            return NF_ERR_ARG;
+        }
     return NF_OK;
 }
 

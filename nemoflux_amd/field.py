@@ -270,13 +270,15 @@ class Field(object):
         self._rowlen = n.value
         self._row = numpy.zeros(max(self._rowlen, 1), numpy.float64)
         self._row_valid = False
-        for i, cov in enumerate(self.getCoverage()):   # mint warns when part of a target line is outside the grid [recall]
-            bad = numpy.nonzero(numpy.abs(cov - 1.0) > 1.e-8)[0]
-            if bad.size:
+        # coverage > 1 (overlapping cells: a stretch of the line would be counted twice) was refused by build_weights above;
+        # coverage < 1 means part of the line lies in no cell: mint only warns there [recall], and so does this
+        for i, cov in enumerate(self.getCoverage()):
+            low = numpy.nonzero(cov < 1.0 - 1.e-8)[0]
+            if low.size:
                 import warnings
-                warnings.warn(f'transect {i}: {bad.size} of {cov.size} target segments are not fully inside the grid '
-                              f'(covered fraction {cov[bad].min():.6g} .. {cov[bad].max():.6g}); the parts outside '
-                              f'contribute no flux', RuntimeWarning, stacklevel=3)
+                warnings.warn(f'transect {i}: {low.size} of {cov.size} target segments are not fully inside the grid '
+                              f'(covered fraction {cov[low].min():.6g} .. {cov[low].max():.6g}, first: segment {low[0]}); '
+                              f'the parts outside contribute no flux', RuntimeWarning, stacklevel=3)
 
         numCells = self.ny * self.nx
         self.dx = min((self.lonmax - self.lonmin) / float(self.nx), (self.latmax - self.latmin) / float(self.ny))

@@ -146,6 +146,7 @@ void nfo_edge_flux(const double *uInt, const double *vInt, const double *arc /* 
 #define NFO_TOL_DIST_REL 1.e-12 /* on-the-edge distance tolerance, relative to max |coordinate| */
 #define NFO_TOL_T 1.e-10        /* min sub-segment length / interval matching tolerance, in t */
 #define NFO_NEWTON_MAX 16
+#define NFO_COVER_TOL 1.e-8     /* a target segment covered more than 1 + this is counted twice somewhere: an error */
 
 typedef struct {
     int seg;
@@ -255,6 +256,21 @@ static int quad_is_nonconvex(const double *v)
     return cmin < -1.e-12 * scale && cmax > 1.e-12 * scale;
 }
 
+/* Date-line unwrap (round 4).  A global file stores bounds_lon wrapped into one period (e.g. [-180,180]), so the cell that
+ * straddles the cut has corners 350 degrees apart: taken as a planar quad it is a clockwise sliver across the whole domain
+ * that the clip accepts and counts a second time.  With a periodic locator (periodX > 0) every corner is therefore brought
+ * to within periodX/2 of corner 0 before the cell is used -- the rule the reference's own generator applies to its rotated
+ * grids (datagen.py:161-166, with 270 degrees there).  Only the copy the weights / the point location work on is changed:
+ * getPoints() and the arc lengths keep the file's values.  mint's behaviour on such cells is parity unpinned. */
+static void unwrap_quad(double *v, double periodX)
+{
+    if (!(periodX > 0.0)) return;
+    for (int k = 1; k < 4; ++k) {
+        double n = rint((v[2 * k] - v[0]) / periodX);
+        if (n != 0.0) v[2 * k] -= n * periodX;
+    }
+}
+
 static int point_in_quad_evenodd(const double *v, double px, double py)
 {
     int in = 0;
@@ -313,6 +329,7 @@ static int rec_cmp(const void *a, const void *b)
  * Output (sorted by segment, ta, cell): cell_edge[k] = cell*4 + edge, weight[k], seg[k] (0-based target
  * segment).  Returns the number of entries (4 per crossed cell), or -(needed) if cap is too small.
  * status[0]: 0 = fine; 1 = a target segment overlaps a non-convex cell; 2 = the inverse bilinear map did not converge;
+ * 3 = a target segment is covered more than once (overlapping cells; status[1] = -1, coverage[] is filled in);
  * status[1] = the smallest offending cell id, status[2] = its first segment.  On an error no weights are returned (0).
  */
 long nfo_polyline_weights(const double *points, long ncell, const double *xyz, int npts, double periodX,
@@ -339,6 +356,9 @@ long nfo_polyline_weights(const double *points, long ncell, const double *xyz, i
                 for (int i = 0; i < 4; ++i) {
                     v[2 * i] = points[(c * 4 + i) * 3];
                     v[2 * i + 1] = points[(c * 4 + i) * 3 + 1];
+                }
+                unwrap_quad(v, periodX);
+                for (int i = 0; i < 4; ++i) {
                     if (v[2 * i] < cxmin) cxmin = v[2 * i];
                     if (v[2 * i] > cxmax) cxmax = v[2 * i];
                     if (v[2 * i + 1] < cymin) cymin = v[2 * i + 1];
@@ -393,11 +413,20 @@ long nfo_polyline_weights(const double *points, long ncell, const double *xyz, i
             if (fabs(recs[j].tb - recs[i].tb) <= NFO_TOL_T) ++n;
         recs[i].coef = 1.0 / (double)n;
     }
-    if (coverage) {
-        for (int q = 0; q + 1 < npts; ++q) coverage[q] = 0.0;
-        for (long i = 0; i < nrec; ++i) coverage[recs[i].seg] += recs[i].coef * (recs[i].tb - recs[i].ta);
+    {   /* coverage of every target segment; more than 1 = some stretch of it was found in two cells that are not the
+         * same sub-segment (overlapping cells): that would be counted twice, so it is an error (status 3), never a number */
+        double *cov = (double *)calloc(npts > 1 ? npts - 1 : 1, sizeof(double));
+        for (long i = 0; i < nrec; ++i) cov[recs[i].seg] += recs[i].coef * (recs[i].tb - recs[i].ta);
         for (int q = 0; q + 1 < npts; ++q)   /* a zero-length segment has nothing to cover */
-            if (xyz[3 * (q + 1)] == xyz[3 * q] && xyz[3 * (q + 1) + 1] == xyz[3 * q + 1]) coverage[q] = 1.0;
+            if (xyz[3 * (q + 1)] == xyz[3 * q] && xyz[3 * (q + 1) + 1] == xyz[3 * q + 1]) cov[q] = 1.0;
+        if (coverage) for (int q = 0; q + 1 < npts; ++q) coverage[q] = cov[q];
+        for (int q = 0; q + 1 < npts; ++q)
+            if (cov[q] > 1.0 + NFO_COVER_TOL) {
+                if (status) { status[0] = 3; status[1] = -1; status[2] = q; }
+                free(cov); free(recs);
+                return 0;
+            }
+        free(cov);
     }
     long need = nrec * 4;
     if (need > cap) { free(recs); return -need; }
@@ -467,6 +496,9 @@ void nfo_vector_interp(const double *points, long ncell, const double *targets, 
             for (int i = 0; i < 4; ++i) {
                 v[2 * i] = points[(c * 4 + i) * 3];
                 v[2 * i + 1] = points[(c * 4 + i) * 3 + 1];
+            }
+            unwrap_quad(v, periodX);   /* date-line cells: as in A6 */
+            for (int i = 0; i < 4; ++i) {
                 if (v[2 * i] < xmin) xmin = v[2 * i];
                 if (v[2 * i] > xmax) xmax = v[2 * i];
                 if (v[2 * i + 1] < ymin) ymin = v[2 * i + 1];

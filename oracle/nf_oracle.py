@@ -144,6 +144,14 @@ class UnsupportedCell(ValueError):
         super().__init__(f'target segment {seg} {what} {cell}')
 
 
+class OverCovered(ValueError):
+    """A target segment was found in overlapping cells over part of its length (coverage > 1): it would be counted twice."""
+
+    def __init__(self, seg, coverage):
+        self.seg, self.coverage = int(seg), coverage
+        super().__init__(f'target segment {seg} is covered {coverage[seg]:.9g} times by the cells of the grid (overlapping cells)')
+
+
 def polyline_weights(points, xyz, periodX=360., counterclock=False, skip_unsupported=False):
     """A6 mint.PolylineIntegral.computeWeights (field.py:45-48).  Raises UnsupportedCell instead of returning numbers
     for a line that crosses a non-convex cell; skip_unsupported=True drops such cells instead (coverage < 1)."""
@@ -161,6 +169,8 @@ def polyline_weights(points, xyz, periodX=360., counterclock=False, skip_unsuppo
                                        cap, ce.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _dp(w),
                                        sg.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), status, _dp(cov),
                                        1 if skip_unsupported else 0)
+        if status[0] == 3:
+            raise OverCovered(status[2], cov[:xyz.shape[0] - 1].copy())
         if status[0]:
             raise UnsupportedCell(status[0], status[1], status[2])
         if n >= 0:

@@ -148,3 +148,73 @@ def deflated_dataset(a, name, chunk, level=4, shuffle=True, attrs=None, threads=
                          ('chunked', None, (1, cz, cy, cx, es), None), filters, dict(attrs or {}))
     ds._chunks = chunks
     return hdf5min.LazyVariable(ds), off
+
+
+# ---- date-line-wrapped cell bounds (round 4) ----------------------------------------------------------------------------
+def wrap180(lon):
+    """Longitudes the way a global NEMO T-file stores them: every corner on its own wrapped into [-180, 180)."""
+    return (numpy.asarray(lon, numpy.float64) + 180.) % 360. - 180.
+
+
+def wrapped_grid_case(oracle, kind, seed):
+    """One geometry with its bounds_lon (a) as one continuous branch and (b) wrapped per corner into [-180, 180), so that the
+    cells straddling the cut have corners ~355 degrees apart (what horizgrid.py:17-24 hands to mint for a real global file).
+    kind: 'g0' = global 72 x 36 on [0, 360]; 'g73' = global on [73, 433] (ORCA's start longitude); 'sa150' = the real
+    ORCA025 subset of data/sa/T.nc moved 150 degrees east (it then straddles the date line).
+    Returns (points_plain, points_wrapped, data, transects, exact): data = cell-by-cell edge differences of a random node
+    stream function (x-periodic on the global grids), transects = 20 seeded node-to-node polylines with free interior
+    vertices, some crossing 180 E, exact[k] = psi(end) - psi(start) or None where the geometry has no shared nodes."""
+    rng = numpy.random.default_rng(seed)
+    if kind == 'sa150':
+        b = load_golden('sa_T_bounds')
+        blon = b['bounds_lon'].astype(numpy.float64) + 150.
+        blat = b['bounds_lat'].astype(numpy.float64)
+        ny, nx = blon.shape[:2]
+        pts = oracle.assemble_points(blon, blat)
+        f = [pts[:, :, 0], pts[:, :, 1]]     # planar lon / lat are bilinear per cell: their "flux" is the end-point difference
+        data = [numpy.stack([g[:, 1] - g[:, 0], g[:, 2] - g[:, 1], g[:, 2] - g[:, 3], g[:, 3] - g[:, 0]], axis=1) for g in f]
+        transects, exact = [], []
+        for k in range(20):
+            n = int(rng.integers(2, 7))
+            x, y = rng.uniform(165., 185., n), rng.uniform(-39., -23., n)
+            if k % 4 == 0:
+                x[0], x[-1] = 171.3, 184.2        # certainly across 180 E
+            if k % 4 == 1:
+                x = wrap180(x)                       # the caller's own longitudes wrapped: pieces go the long way round
+            xyz = numpy.zeros((n, 3))
+            xyz[:, 0], xyz[:, 1] = x, y
+            transects.append(xyz)
+            exact.append(None)
+        wr = pts.copy()
+        wr[:, :, 0] = wrap180(pts[:, :, 0])
+        return pts, wr, data, transects, exact
+    x0 = {'g0': 0., 'g73': 73.}[kind]
+    nx, ny = 72, 36
+    o = oracle.DataGen(nx, ny, 1, 1, xmin=x0, xmax=x0 + 360.)
+    pts = oracle.assemble_points(o.bounds_lon, o.bounds_lat)
+    psi = rng.standard_normal((ny + 1, nx + 1))
+    psi[:, -1] = psi[:, 0]
+    p0, p1, p2, p3 = psi[:-1, :-1], psi[:-1, 1:], psi[1:, 1:], psi[1:, :-1]
+    data = [numpy.stack([p1 - p0, p2 - p1, p2 - p3, p3 - p0], axis=-1).reshape(-1, 4)]
+    xn, yn = o.xx[0], o.yy[:, 0]
+    transects, exact = [], []
+    for k in range(20):
+        ia, ja, ib, jb = rng.integers(0, nx + 1), rng.integers(1, ny), rng.integers(0, nx + 1), rng.integers(1, ny)
+        n = int(rng.integers(0, 5))
+        x = numpy.concatenate([[xn[ia]], rng.uniform(x0, x0 + 360., n), [xn[ib]]])
+        y = numpy.concatenate([[yn[ja]], rng.uniform(-80., 80., n), [yn[jb]]])
+        if k % 4 == 0:      # straight across 180 E, end points on nodes either side of it
+            ia, ib = int(numpy.argmin(abs(xn - 150.))), int(numpy.argmin(abs(xn - 215.)))
+            x = numpy.array([xn[ia], xn[ib]])
+            y = numpy.array([yn[ja], yn[jb]])
+        if k % 4 == 1:      # the caller's longitudes in [-180, 180): the same nodes, pieces may go the long way round
+            x = wrap180(x)
+        if k % 4 == 2:      # the whole line moved by a period
+            x = x - 360.
+        xyz = numpy.zeros((x.size, 3))
+        xyz[:, 0], xyz[:, 1] = x, y
+        transects.append(xyz)
+        exact.append(psi[jb, ib] - psi[ja, ia])
+    wr = pts.copy()
+    wr[:, :, 0] = wrap180(pts[:, :, 0])
+    return pts, wr, data, transects, exact

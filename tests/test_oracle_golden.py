@@ -8,7 +8,7 @@ import os
 import numpy
 import pytest
 
-from conftest import FULL_CASES, GOLDEN, case_box, load_golden, transect_xyz
+from conftest import FULL_CASES, GOLDEN, case_box, load_golden, transect_xyz, wrapped_grid_case
 
 EPS = numpy.finfo(numpy.float64).eps
 
@@ -581,3 +581,62 @@ def test_oracle_all_station_tables_of_the_reference(oracle):
         else:
             assert abs(tot) > 1e-6 * scale, (name, tot)      # an open transect of this field carries a flux
     assert closed == 2
+
+
+@pytest.mark.parametrize('kind', ['g0', 'g73', 'sa150'])
+def test_oracle_dateline_wrapped_bounds(kind, oracle):
+    """Round-3 verdict W1.  bounds_lon of a global file is wrapped into one period, so the cells on the cut have corners
+    ~355 degrees apart; horizgrid.py:17-24 hands them to mint as they are (mint's behaviour: parity unpinned).  As planar
+    quads they are clockwise slivers across the whole domain: before round 4 the restatement clipped them like any cell
+    and counted part of the line twice (coverage 2, flux 0.88 for 0.74).  With a periodic locator the corners are now
+    brought to within periodX/2 of corner 0 (the rule of datagen.py:161-166): the weights of the wrapped grid equal the
+    weights of the same grid on one continuous branch entry by entry, the totals are the stream-function differences, and
+    every point of the line is counted once."""
+    pts, wr, data, transects, exact = wrapped_grid_case(oracle, kind, {'g0': 40, 'g73': 41, 'sa150': 42}[kind])
+    span = wr[:, :, 0].max(axis=1) - wr[:, :, 0].min(axis=1)
+    assert (span > 300.).sum() >= (36 if kind != 'sa150' else 50)      # the input really holds date-line cells
+    tol = 1e-12 if kind != 'sa150' else 1e-10    # sa150: (x + 150 - 360) + 360 rounds, on cells a quarter of a degree wide
+    for k, xyz in enumerate(transects):
+        a = oracle.polyline_weights(pts, xyz)
+        b = oracle.polyline_weights(wr, xyz)
+        da, db = a.as_dict(), b.as_dict()
+        assert set(da) == set(db), (kind, k)
+        assert max(abs(da[key] - db[key]) for key in da) <= tol, (kind, k)
+        assert numpy.allclose(b.coverage, a.coverage, rtol=0, atol=1e-9), (kind, k)
+        inside = kind != 'sa150' or k % 4 != 1     # regional grid: wrapped caller longitudes leave it the long way round
+        assert not inside or numpy.allclose(b.coverage, 1.0, rtol=0, atol=1e-9), (kind, k)
+        if exact[k] is not None:
+            assert abs(oracle.get_integral(b, data[0]) - exact[k]) <= 1e-12 * max(1., abs(exact[k])), (kind, k)
+        elif inside:
+            for c in (0, 1):      # lon and lat as "edge data" integrate to the end-point differences of every segment
+                tot, segs = oracle.get_integral(b, data[c], True)
+                assert numpy.allclose(segs, numpy.diff(xyz[:, c]), rtol=0, atol=1e-9), (kind, k, c)
+    # the point location / face vectors see the same unwrapped cells
+    tg = numpy.array([[178.7, -30.2, 0.], [181.9, -30.2, 0.], [-178.1, -30.2, 0.]])
+    va, ia = oracle.vector_interp(pts, tg, data[0])
+    vb, ib = oracle.vector_interp(wr, tg, data[0])
+    assert numpy.array_equal(ia, ib) and numpy.all(ia >= 0) and ia[1] == ia[2]
+    assert numpy.allclose(va, vb, rtol=0, atol=1e-9 * max(1., numpy.abs(va).max()))
+
+
+def test_oracle_refuses_double_counting(oracle):
+    """Coverage > 1: some stretch of a target segment lies in two cells that do not hold the same sub-segment.  That is a
+    doubled flux, so it is an error that names the segment -- never a number (round-3 verdict W1).  A wrapped global grid
+    used with a NON-periodic locator is such a case (nothing says the cells may be unwrapped)."""
+    # two unit-height cells [0,2] and [1,3] overlapping on [1,2]
+    quad = lambda x0, x1: [[x0, 0., 0.], [x1, 0., 0.], [x1, 1., 0.], [x0, 1., 0.]]
+    pts = numpy.array([quad(0., 2.), quad(1., 3.)])
+    line = numpy.array([[0.2, -1., 0.], [0.5, 0.5, 0.], [2.5, 0.5, 0.]])
+    with pytest.raises(oracle.OverCovered) as e:
+        oracle.polyline_weights(pts, line, periodX=0.)
+    assert e.value.seg == 1 and abs(e.value.coverage[1] - 1.5) <= 1e-12 and e.value.coverage[0] < 1.
+    # identical duplicates (the halo columns / the north-fold row of an ORCA file) are NOT an error: each counts one half
+    dup = numpy.array([quad(0., 2.), quad(0., 2.), quad(2., 3.)])
+    w = oracle.polyline_weights(dup, line[1:], periodX=0.)
+    assert abs(w.coverage[0] - 1.0) <= 1e-12 and sorted(set(w.cell_edge // 4)) == [0, 1, 2]
+    # wrapped bounds + periodX = 0: refused, with periodX = 360 (field.py:47) fine
+    _, wr, data, transects, exact = wrapped_grid_case(oracle, 'g0', 40)
+    with pytest.raises(oracle.OverCovered):
+        oracle.polyline_weights(wr, transect_xyz("(20,-40),(100,30)"), periodX=0.)
+    w = oracle.polyline_weights(wr, transect_xyz("(20,-40),(100,30)"), periodX=360.)
+    assert numpy.allclose(w.coverage, 1.0, rtol=0, atol=1e-12)
