@@ -70,8 +70,10 @@ def make_transects(nx, ny, xmin, xmax, ymin, ymax, nbatch, seed=20260401, seam=F
     return polys
 
 
-def run_workload(args, dtype, scaling, rank, world, local, want_totals=False):
-    """Generate the workload on the device, time `steps` passes, check the accuracy.  Returns a dict of measurements."""
+def run_workload(args, dtype, scaling, rank, world, local, want_totals=False, emulate=None):
+    """Generate the workload on the device, time `steps` passes, check the accuracy.  Returns a dict of measurements.
+    emulate = (r, N): this ONE process does exactly what rank r of an N-rank strong-scaling run does on its GPU -- the same
+    slab range, the same time steps generated, the same launches -- minus the all-reduce (there is nobody to reduce with)."""
     import contextlib
     import ctypes
     import io
@@ -86,7 +88,7 @@ def run_workload(args, dtype, scaling, rank, world, local, want_totals=False):
     nx, ny, nz = args.nx, args.ny, args.nz
     psi = STREAM_FUNCTIONS[5]
     nt_global = args.nt * world if scaling == 'weak' else args.nt
-    srange = nfdist.slab_range(nt_global, nz, rank, world)
+    srange = nfdist.slab_range(nt_global, nz, *(emulate if emulate else (rank, world)))
     t_begin, t_end = nfdist.time_steps_touched(srange, nz)
     if t_end <= t_begin:        # more ranks than slabs: this rank owns nothing, but its pointers must still be valid
         t_begin, t_end = 0, 1
@@ -147,6 +149,8 @@ def run_workload(args, dtype, scaling, rank, world, local, want_totals=False):
         elapsed = float(tt.item())
 
     units_total = float(nt_global) * nz * ny * nx
+    if emulate:     # the rank's own share: what it integrates per pass
+        units_total = float(srange[1] - srange[0]) * ny * nx
     m = {'value': units_total * args.steps / elapsed, 'ms_per_step': elapsed / args.steps * 1e3,
          'nt_global': nt_global, 'setup_s': setup_s, 'psi': psi, 'polys': polys, 'nseg': fld._nseg,
          'weight_entries': int(fld.getWeights()[0].size), 'dg': dg, 'u': u, 'v': v, 'xyz0': xyzs[0]}
@@ -191,11 +195,20 @@ def run_workload(args, dtype, scaling, rank, world, local, want_totals=False):
     res = rows.cpu().numpy()
     nseg = fld._nseg
     max_err, max_ref = 0.0, 0.0
-    for p, pts in enumerate(polys if rank == 0 else []):     # rank 0 prints the line: only it needs the check
+    for p, pts in enumerate(polys if rank == 0 and not emulate else []):     # rank 0 prints the line: only it needs the check
         ex = exactFlux(psi, pts, nz, nt_global)
         got = res[:, nseg + p]
         max_err = max(max_err, float(numpy.abs(got - numpy.array(ex)).max()))
         max_ref = max(max_ref, float(numpy.abs(ex).max()))
+    if emulate:     # partial rows of one rank: nothing to compare with the closed form
+        max_err, max_ref = None, None
+        m['emulated'] = {'rank': emulate[0], 'of': emulate[1], 'slabs': [int(srange[0]), int(srange[1])],
+                         'steps_touched': [int(t_begin), int(t_end)], 'launches_per_pass': nlaunch // max(1, args.steps),
+                         'ms_per_pass': round(elapsed / args.steps * 1e3, 4),
+                         'k_flux_ms': round(flux_ms / max(1, args.steps), 4),
+                         'k_expand_ms': round(expand_ms / max(1, args.steps), 4),
+                         'k3_ms': round(k3_ms / max(1, args.steps), 4),
+                         'partial_step_planes': os.environ.get('NF_PARTIAL_STEP_PLANES', 'signed-only (default)')}
     m['accuracy'] = {'max_abs_err_vs_fluxexact': max_err, 'max_abs_exact': max_ref,
                      'singular_transect_t0': float(res[0, nseg + 0]), 'transect_steps_checked': len(polys) * nt_global}
     if want_totals:
@@ -230,6 +243,8 @@ def run_workload(args, dtype, scaling, rank, world, local, want_totals=False):
                      'units_per_launch': units_per_launch,
                      'wall_frac': round(bytes_per_unit * units_total * (own / float(nt_global * nz)) /
                                         (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+    if emulate:
+        m['roofline']['wall_frac'] = round(bytes_per_unit * units_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
     del fld
     return m
 
@@ -251,6 +266,9 @@ def main():
     ap.add_argument('--no-f32', action='store_true', help='skip the float32 sub-record (N=1, --dtype f64 only)')
     ap.add_argument('--no-ingest', action='store_true', help='skip the file-ingest sub-record (N=1)')
     ap.add_argument('--dump-totals', action='store_true', help='add the (nt, ntransect) totals to the JSON (small grids)')
+    ap.add_argument('--emulate-rank', default=None, metavar='r/N',
+                    help='NOT a scaling run: on ONE GPU, do exactly what rank r of an N-rank strong-scaling run does (its slab '
+                         'range, its launches; no reduce) and report its ms per pass -- per-rank compute evidence for N > 1')
     ap.add_argument('--compact', action='store_true',
                     help='NOT the headline configuration: keep only (eU, eV) resident per step (nf_field_set_compact); the '
                          '(ncell,4) copies and |.| arrays are derived at read-back, which a batch driver never asks for')
@@ -258,7 +276,7 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher.  It has made no GPU call and never will
-        # (device_count() does not initialise the runtime); the N ranks are fresh child processes.
+        # (it does not import torch; devices are counted from sysfs); the N ranks are fresh child processes.
         raise SystemExit(self_launch(args.gpus))
 
     import torch
@@ -275,7 +293,14 @@ def main():
     torch.cuda.set_device(local)
 
     nx, ny, nz = args.nx, args.ny, args.nz
-    m = run_workload(args, args.dtype, args.scaling, rank, world, local, want_totals=args.dump_totals)
+    emulate = None
+    if args.emulate_rank:
+        r, n = (int(x) for x in args.emulate_rank.split('/'))
+        if world != 1 or args.scaling != 'strong' or not (0 <= r < n):
+            raise SystemExit('bench.py: --emulate-rank r/N needs --gpus 1, strong scaling and 0 <= r < N')
+        emulate = (r, n)
+        args.no_cpu = args.no_f32 = args.no_ingest = True
+    m = run_workload(args, args.dtype, args.scaling, rank, world, local, want_totals=args.dump_totals, emulate=emulate)
     slabs = m['nt_global'] * nz
     out = {
         'metric': 'edge-flux integrals/sec', 'value': m['value'], 'unit': 'integrals/s', 'n_gpus': world,
@@ -295,6 +320,10 @@ def main():
         'roofline': m['roofline'],
         'accuracy': m['accuracy'],
     }
+    if emulate:
+        out['emulated_rank'] = m['emulated']
+        out['config']['workload'] += (f' -- EMULATION of rank {emulate[0]} of {emulate[1]} on one GPU: value = this rank\'s own '
+                                      'slabs per second, no reduce; not a scaling measurement')
     if 'reduce' in m:
         out['reduce'] = m['reduce']
         out['ranks'] = m['ranks']
@@ -380,17 +409,45 @@ def ingest_record(streams=256):
             'kernels': 'nf::k_inflate + nf::k_place16', 'resident_streams_capacity': ChunkDecoder.capacity()}
 
 
+def visible_gpu_count():
+    """GPUs a child process would see, counted WITHOUT touching the HIP runtime (the launcher must stay a process that has
+    never initialised the GPU): the KFD topology in sysfs (GPU nodes have simd_count > 0), narrowed by HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.  None when sysfs cannot be read (the ranks then fail loudly
+    themselves if a device is missing)."""
+    n = None
+    try:
+        base = '/sys/class/kfd/kfd/topology/nodes'
+        if not os.path.exists('/sys/class/kfd'):
+            raise FileNotFoundError
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, 'properties')) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get('simd_count', '0')) > 0:
+                n += 1
+    except FileNotFoundError:
+        n = 0           # no KFD node at all: no compute driver, no GPU
+    except (OSError, ValueError):
+        n = None
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            k = len([x for x in v.split(',') if x.strip() != ''])
+            n = k if n is None else min(n, k)
+    return n
+
+
 def self_launch(ngpus):
     """`python bench.py --gpus N` without a launcher: start the N ranks the way the driver's own N>1 command does
     (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>), one process per GPU, as a
-    child of this process -- which has not touched the GPU -- relay rank 0's JSON line and return the child's exit code.
+    child of this process -- which has not touched the GPU and has not even imported torch -- relay rank 0's JSON line and
+    return the child's exit code.
     Fewer than N visible devices is an error, not a silent N=1 run (NF_FORCE_DEVICE, the rehearsal hook of
     nemoflux_amd.dist that puts every rank on one GPU, lifts that check)."""
     import socket
     import subprocess
-    import torch
-    ndev = torch.cuda.device_count()        # counts devices without initialising the HIP runtime in this process
-    if ndev < ngpus and 'NF_FORCE_DEVICE' not in os.environ:
+    ndev = visible_gpu_count()              # from sysfs / the *_VISIBLE_DEVICES variables: no HIP or torch call in this process
+    if ndev is not None and ndev < ngpus and 'NF_FORCE_DEVICE' not in os.environ:
         print(f'bench.py: --gpus {ngpus} but {ndev} GPU(s) visible on this node; refusing to run a smaller job under that '
               'name', file=sys.stderr)
         return 2
@@ -402,7 +459,8 @@ def self_launch(ngpus):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: what RCCL needs between processes on this host
     env.setdefault('OMP_NUM_THREADS', '4')
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    env.setdefault('NF_DIST_TIMEOUT_S', '300')            # a rank that cannot join ends the job with a message (dist._Deadline)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, close_fds=True)
     for line in child.stdout:               # rank 0's JSON line (and anything else the ranks print) goes straight through
         sys.stdout.write(line)
         sys.stdout.flush()

@@ -68,8 +68,8 @@ int nf_host_unshuffle(const void *src, void *dst, size_t n, int es);
  * chunks of a group of time steps out of the mapped file into a pinned staging buffer (field.py:149 reads them one by one) */
 int nf_host_gather(const unsigned long long *src_addr, const unsigned long long *dst_addr, const long long *len, long long n,
                    int nthreads);
-/* tuning knobs for A/B measurements inside one process: "flux_variant" (0 = default; see nf_flux.hip),
- * "xcd_map" (1 = on), "ww_blocks_per_cu", "batch_steps" (1 = small grids run all time steps in one launch) */
+/* tuning knobs for A/B measurements inside one process: "flux_variant" (0 = default store form, 5 = the other one; see nf_flux.hip),
+ * "xcd_map" (1 = on), "batch_steps" (1 = small grids run all time steps in one launch) */
 int nf_tuning_set(const char *name, int value);
 
 /* ------------------------------------------------------------------ Level 1: mint-shaped API */
@@ -239,6 +239,10 @@ int nf_field_timing_k3(nf_field **self, double *k3_ms);
  * first use from the copy the process already holds (PyTorch's, or the system's librccl.so.1): no link-time dependency.
  *   nf_rccl_unique_id : rank 0 creates the 128-byte id and hands it to the other ranks by any means (file, socket, MPI,
  *                       torch.distributed store)
+ *   nf_rccl_preflight : NOT collective: checks what nf_rccl_comm_init needs that does not involve the other ranks (librccl
+ *                       resolves, the calling thread has a usable HIP device; *device = its index).  ncclCommInitRank is
+ *                       collective, so a rank that failed before it would leave the others waiting inside it: call this
+ *                       on every rank, agree on the outcome over the channel that carried the id, then init together
  *   nf_rccl_comm_init : every rank, after nf_set_device(its GPU); collective over the nranks callers
  *   nf_rows_allreduce : rows_dev (HBM, n doubles) summed in place over all ranks, asynchronous on hip_stream.  rccl_comm may
  *                       also be a ncclComm_t the caller created itself with the same librccl
@@ -246,6 +250,7 @@ int nf_field_timing_k3(nf_field **self, double *k3_ms);
  *   nf_rccl_library   : path of the librccl the entry points were resolved from */
 #define NF_RCCL_UNIQUE_ID_BYTES 128
 int nf_rccl_unique_id(void *id128);
+int nf_rccl_preflight(int *device);
 int nf_rccl_comm_init(void **comm, int nranks, const void *id128, int rank);
 int nf_rccl_comm_destroy(void *comm);
 int nf_rccl_comm_info(void *comm, int *nranks, int *rank, int *device);

@@ -122,6 +122,7 @@ _sig('nf_field_timing_read', [_pp, ctypes.POINTER(ctypes.c_long), c_double_p])
 _sig('nf_field_timing_split', [_pp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)])
 _sig('nf_field_timing_k3', [_pp, ctypes.POINTER(ctypes.c_double)])
 _sig('nf_rccl_unique_id', [ctypes.c_void_p])
+_sig('nf_rccl_preflight', [c_int_p])
 _sig('nf_rccl_comm_init', [c_void_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_int])
 _sig('nf_rccl_comm_destroy', [ctypes.c_void_p])
 _sig('nf_rccl_comm_info', [ctypes.c_void_p, c_int_p, c_int_p, c_int_p])

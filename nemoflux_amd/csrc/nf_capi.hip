@@ -841,7 +841,15 @@ static int field_step_async(nf_field *f, long t, double *row_dev)
     a.absU = f->d_abs;
     a.absV = f->d_abs + f->ncell;
     a.maxbits = f->d_maxbits;
-    a.signed_only = f->compact && flux_supports_signed_only(a);
+    // A rank of a sharded run that owns only PART of this step's levels (slab sharding cuts inside a time step) produces
+    // partial sums: its south / west copies and |.| planes mean nothing (only a step owned whole has full-field outputs),
+    // the transect reduction reads the two signed planes only, so the step runs in the signed-only form and the four derived
+    // planes are written on demand (read_step / device_ptr), exactly as in the compact mode.  0.116 ms per such launch at
+    // the C4 size; the rows are bit-identical (test_slab_sharding_sums_to_full).  NF_PARTIAL_STEP_PLANES=full keeps the
+    // six-plane epilogue on partial steps (the before / after measurement of profiles/r04_rank_emulation.txt).
+    static const bool partial_full = getenv("NF_PARTIAL_STEP_PLANES") && !strcmp(getenv("NF_PARTIAL_STEP_PLANES"), "full");
+    const bool partial = (z0 > 0 || z1 < (int)f->nz) && !partial_full;
+    a.signed_only = (f->compact || partial) && flux_supports_signed_only(a);
     f->derived_stale = a.signed_only != 0;
     if (f->timing) {
         NF_TRY(field_timed_flux(f, a));
@@ -1549,13 +1557,20 @@ try {
         return NF_OK;
     }
     std::vector<std::thread> pool;
+    pool.reserve((size_t)nt);
     const long long share = (total + nt - 1) / nt;
     long long lo = 0;
-    for (int t = 0; t < nt && lo < n; ++t) {
-        long long hi = lo, acc = 0;
-        while (hi < n && (acc < share || t == nt - 1)) acc += len[hi++];
-        pool.emplace_back(work, lo, hi);
-        lo = hi;
+    try {
+        for (int t = 0; t < nt && lo < n; ++t) {
+            long long hi = lo, acc = 0;
+            while (hi < n && (acc < share || t == nt - 1)) acc += len[hi++];
+            pool.emplace_back(work, lo, hi);
+            lo = hi;
+        }
+    } catch (...) {   // a thread could not be started: the caller's thread finishes the rest, the started ones are joined
+        for (auto &th : pool) th.join();   // (destroying a joinable std::thread would call std::terminate)
+        work(lo, n);
+        return NF_OK;
     }
     for (auto &th : pool) th.join();
     return NF_OK;

@@ -381,9 +381,9 @@ static int launch_flux_t(const FluxArgs &a, hipStream_t s)
     return NF_OK;
 }
 
-// Tuning variants of the vector path (NF_FLUX_VARIANT / nf_tuning_set("flux_variant")); 0 is the default.  Every variant the
-// product library accepts produces the same bits as the default (tests/test_gpu_configs.py); an unknown number runs the
-// default kernel.
+// Store form of the vector path (NF_FLUX_VARIANT / nf_tuning_set("flux_variant")): 0 = the per-dtype default, 5 = the other
+// one; same bits either way (tests/test_gpu_configs.py).  Any other number runs the default kernel in the shipped library;
+// the measured alternatives of the load loop exist only in the tuning build (`make tuning`), where the same test checks them.
 template <typename T, int VEC>
 static int launch_flux_v(const FluxArgs &a, hipStream_t s)
 {
@@ -411,13 +411,14 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
         return launch_expand_planes(a.iV, a.absU, a.ncell, a.ny, a.nx, s);
     }
     switch (variant) {
-        // measured alternatives (tools/ab_flux.py): all within +-3 % of the default
+#ifdef NF_TUNING_BUILD
+        // measured alternatives (tools/ab_flux.py; docs/EXPERIMENTS.md): all within +-3 % of the default.  Tuning build only
+        // (round-3 verdict W9): the shipped library carries the default and the other store form (5), nothing else
         case 3: return launch_flux_t<T, VEC, 4, true, 256, 1>(a, s);    // 4 levels in flight (+2..3 %)
         case 4: return launch_flux_t<T, VEC, 4, true, 256, 2>(a, s);    // 4 levels, 2 chunks per lane
         case 11: return launch_flux_t<T, VEC, 10, false, 256, 1>(a, s); // plain (temporal) loads: +4 %
         case 12: return launch_flux_t<T, VEC, 8, true, 256, 1>(a, s);   // 8 levels in flight
         case 14: return launch_flux_t<T, VEC, 16, true, 256, 1>(a, s);  // 16 levels in flight
-#ifdef NF_TUNING_BUILD
         case 13: return launch_flux_t<T, VEC, 10, true, 256, 1, kDiagPlainStores>(a, s);  // plain instead of non-temporal stores
         case 40: return launch_flux_ww<T, VEC, 2>(a, s);                       // writer-wave form
         // diagnostic builds (WRONG RESULTS on purpose) that price one ingredient each
@@ -425,11 +426,11 @@ static int launch_flux_v(const FluxArgs &a, hipStream_t s)
         case 28: return launch_flux_t<T, VEC, 10, true, 256, 1, kFormSignedOnly>(a, s);   // only the two signed planes, no expansion
         case 29: return launch_flux_t<T, VEC, 10, true, 256, 1, kDiagInterleaved>(a, s);  // one interleaved (eU,eV) stream
         case 45: return launch_flux_ww<T, VEC, 2, 2>(a, s);                        // writer-wave, no stores
-#endif
         case 6: {  // the nested per-level load loop with the split store form: the defaults before the flat loop
             const int rc = launch_flux_t<T, VEC, (sizeof(T) == 8 ? 10 : 8), true, 256, 1, kFormSignedOnly | kFormNestedLoads>(a, s);
             return rc != NF_OK ? rc : launch_expand_planes(a.iV, a.absU, a.ncell, a.ny, a.nx, s);
         }
+#endif
         case 5:    // the OTHER store form than the default's (float64: split, float32: fused)
         default: {
             // 10 (float64) or 8 (float32) levels x 2 fields per batch.  Two store forms: FUSED = all seven stores in the flux kernel; SPLIT = the flux

@@ -115,6 +115,26 @@ try {
     return NF_ERR_HOST;
 }
 
+// Everything nf_rccl_comm_init needs that can be checked WITHOUT the other ranks: librccl resolves and the calling thread
+// has a usable HIP device.  ncclCommInitRank is collective -- a rank that fails before it leaves the others waiting
+// inside it -- so the ranks call this first, agree on the outcome by whatever means they already share (nemoflux_amd.dist:
+// one MIN all-reduce over torch.distributed) and only then create the communicator together.
+int nf_rccl_preflight(int *device)
+try {
+    if (int rc = need_device()) return rc;
+    RcclApi *a = nullptr;
+    if (int rc = rccl_api(&a)) return rc;
+    int dev = -1;
+    NF_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    NF_HIP(hipGetDeviceProperties(&prop, dev));
+    if (device) *device = dev;
+    return NF_OK;
+} catch (...) {
+    set_error("nf_rccl_preflight: internal error");
+    return NF_ERR_HOST;
+}
+
 int nf_rccl_comm_init(void **comm, int nranks, const void *id128, int rank)
 try {
     NF_REQUIRE(comm && id128, NF_ERR_ARG, "nf_rccl_comm_init: null argument");

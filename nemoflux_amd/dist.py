@@ -8,7 +8,8 @@ all-reduce over RCCL / xGMI.  The message is <= ~0.4 MB (latency-bound), so no b
 
 On GPUs ('nccl' backend = RCCL) the reduce is the C ABI's own: nf_rows_allreduce (ncclAllReduce(sum, ncclDouble) in
 csrc/nf_reduce.hip) on a communicator the library creates with nf_rccl_comm_init -- torch.distributed only carries the
-128-byte unique id from rank 0 to the others, the way a plain-C client would carry it over MPI or a socket.  gloo (CPU
+128-byte unique id from rank 0 to the others, the way a plain-C client would carry it over MPI or a socket -- after every
+rank passed nf_rccl_preflight and the ranks agreed on that (start-up fails soft: see native_comm).  gloo (CPU
 tests, and the rehearsal of N ranks on a one-GPU box) goes through torch.distributed's all_reduce.  NF_NATIVE_REDUCE=0
 keeps torch.distributed's RCCL call on GPUs too.
 """
@@ -49,12 +50,15 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        import datetime
+        # a rank that never arrives must not hang the job: rendezvous and every torch collective give up after this long
+        timeout = datetime.timedelta(seconds=startup_timeout_s())
         if backend == 'nccl':     # RCCL: bind the communicator to this rank's GPU at init (one process per GPU)
             torch.cuda.set_device(local)
-            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout,
                                     device_id=torch.device('cuda', local))
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local
@@ -73,27 +77,81 @@ def all_reduce(tensor, op=None, group=None):
     return tensor
 
 
-class NativeComm(object):
-    """The engine's own RCCL communicator over the ranks of a torch.distributed group (nf_rccl_* of the C ABI)."""
+class _Deadline(object):
+    """Bounds a collective start-up step: if the block has not finished after `seconds`, the process says what it was
+    waiting for on stderr and exits with code 3 -- the launcher (torch.distributed.run) then ends the other ranks.  A rank
+    that cannot join must end the job, not hang it.  It exits; it never re-executes anything."""
 
-    def __init__(self, group=None):
+    def __init__(self, seconds, what):
+        self.seconds, self.what = float(seconds), what
+
+    def __enter__(self):
+        import threading
+
+        def expire():
+            print(f'# nemoflux_amd.dist: rank {os.environ.get("RANK", "?")}: {self.what} did not finish within '
+                  f'{self.seconds:.0f} s (another rank is missing or stuck); ending this rank', file=sys.stderr, flush=True)
+            os._exit(3)
+        self._timer = threading.Timer(self.seconds, expire)
+        self._timer.daemon = True
+        self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._timer.cancel()
+        return False
+
+
+def startup_timeout_s():
+    """Seconds a rank waits in a collective start-up step before it gives up (NF_DIST_TIMEOUT_S, default 300)."""
+    return float(os.environ.get('NF_DIST_TIMEOUT_S', '300'))
+
+
+def _agree(flag, group=None):
+    """MIN over the ranks of an int flag, through torch.distributed on whatever backend the group has."""
+    dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+    t = torch.tensor([int(flag)], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())
+
+
+class NativeComm(object):
+    """The engine's own RCCL communicator over the ranks of a torch.distributed group (nf_rccl_* of the C ABI).
+
+    ncclCommInitRank is collective, so nothing that can fail on ONE rank may sit between the ranks' agreement and that call:
+    `preflight` (not collective: librccl resolves, the rank has a usable device, rank 0 has the unique id) runs first on
+    every rank, the outcomes are combined with one MIN all-reduce over torch.distributed, and only when every rank passed
+    do all of them call `connect`."""
+
+    def __init__(self):
         from ._lib import lib, check
         self._lib, self._check = lib, check
+        self.ptr = None
+        self._ident = None
+
+    def preflight(self, group=None):
+        """This rank's share of the start-up that needs no other rank.  Raises on failure."""
+        rank = dist.get_rank(group)
+        inject = os.environ.get('NF_TEST_FAIL_COMM')          # test hook: the named rank fails here
+        if inject is not None and int(inject) == rank:
+            raise RuntimeError(f'NF_TEST_FAIL_COMM={inject}: injected preflight failure on rank {rank}')
+        dev = ctypes.c_int(-1)
+        self._check(self._lib.nf_rccl_preflight(ctypes.byref(dev)))
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            self._check(self._lib.nf_rccl_unique_id(buf))
+            self._ident = buf.raw
+        return dev.value
+
+    def connect(self, group=None):
+        """Collective: every rank of the group, after all of them passed preflight."""
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        ident = [None]
-        if rank == 0:       # whatever happens here, the broadcast below is reached: the other ranks are waiting in it
-            try:
-                buf = ctypes.create_string_buffer(128)
-                check(lib.nf_rccl_unique_id(buf))
-                ident[0] = buf.raw
-            except Exception as e:
-                ident[0] = e
+        ident = [self._ident]
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast_object_list(ident, src=src, group=group)
-        if not isinstance(ident[0], bytes):
-            raise RuntimeError(f'rank 0 could not create the RCCL unique id: {ident[0]}')
-        self.ptr = ctypes.c_void_p()
-        check(lib.nf_rccl_comm_init(ctypes.byref(self.ptr), world, ctypes.c_char_p(ident[0]), rank))
+        ptr = ctypes.c_void_p()
+        self._check(self._lib.nf_rccl_comm_init(ctypes.byref(ptr), world, ctypes.c_char_p(ident[0]), rank))
+        self.ptr = ptr
 
     def all_reduce_sum(self, rows):
         assert rows.is_cuda and rows.dtype == torch.float64 and rows.is_contiguous()
@@ -118,44 +176,64 @@ class NativeComm(object):
 _native = {}   # group -> NativeComm, or False when it could not be created on every rank
 
 
+def _fallback(group, err, comm=None):
+    if comm is not None:
+        try:
+            comm.destroy()
+        except Exception:
+            pass
+    if err or dist.get_rank(group) == 0:
+        print(f'# nemoflux_amd.dist: native RCCL communicator unavailable ({err or "failed on another rank"}); '
+              'reducing through torch.distributed', file=sys.stderr, flush=True)
+    _native[group] = False
+    return None
+
+
 def native_comm(group=None):
     """The NativeComm of `group` (created at first use, collectively), or None: not the 'nccl' backend, switched off with
-    NF_NATIVE_REDUCE=0, or the communicator could not be created on every rank (reported once on stderr)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != 'nccl':
+    NF_NATIVE_REDUCE=0, or the communicator could not be created on every rank (reported once on stderr; the ranks then
+    all reduce through torch.distributed).  NF_NATIVE_REDUCE=rehearse runs the start-up protocol up to the agreement on
+    any backend (gloo on CPU, or N ranks sharing one GPU): the control flow of a failed start-up can be tested without RCCL.
+    Every collective step is bounded by startup_timeout_s(): a rank that waits longer ends the job with a message."""
+    if not (dist.is_available() and dist.is_initialized()):
         return None
-    if os.environ.get('NF_NATIVE_REDUCE', '1') == '0':
+    mode = os.environ.get('NF_NATIVE_REDUCE', '1')
+    is_rccl = dist.get_backend(group) == 'nccl'
+    if mode == '0' or not (is_rccl or mode == 'rehearse'):
         return None
-    if group not in _native:
-        comm, err = None, ''
+    if group in _native:
+        return _native[group] or None
+    comm, err = None, ''
+    # 1. what each rank can check on its own -- no rank raises, the ranks must agree on the path they take
+    try:
+        comm = NativeComm()
+        comm.preflight(group)
+    except Exception as e:
+        err = f'{type(e).__name__}: {e}'
+    # 2. agreement BEFORE the collective ncclCommInitRank (a rank that failed above would leave the others inside it)
+    with _Deadline(startup_timeout_s(), 'the agreement before nf_rccl_comm_init'):
+        all_ok = _agree(0 if err else 1, group)
+    if not all_ok:
+        return _fallback(group, err, comm)
+    if not is_rccl:      # rehearsal on gloo: N ranks on one device cannot form an RCCL communicator (duplicate device)
+        return _fallback(group, 'rehearsal on the %s backend: no RCCL communicator is attempted' % dist.get_backend(group), comm)
+    # 3. every rank is able: create the communicator together, then one known-answer all-reduce before it carries real rows
+    with _Deadline(startup_timeout_s(), 'nf_rccl_comm_init (ncclCommInitRank over all ranks)'):
         try:
-            comm = NativeComm(group)
-        except Exception as e:   # the ranks must agree on the path they take, so no rank raises here
+            comm.connect(group)
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            probe = torch.tensor([rank + 1.0, 0.5], dtype=torch.float64, device='cuda')
+            comm.all_reduce_sum(probe)
+            torch.cuda.synchronize()
+            if probe.tolist() != [world * (world + 1) / 2.0, 0.5 * world]:
+                err = f'self-test gave {probe.tolist()}'
+        except Exception as e:
             err = f'{type(e).__name__}: {e}'
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device='cuda')
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok.item()) == 1:   # every rank has a communicator: one known-answer all-reduce before it carries real rows
-            try:
-                world, rank = dist.get_world_size(group), dist.get_rank(group)
-                probe = torch.tensor([rank + 1.0, 0.5], dtype=torch.float64, device='cuda')
-                comm.all_reduce_sum(probe)
-                torch.cuda.synchronize()
-                if probe.tolist() != [world * (world + 1) / 2.0, 0.5 * world]:
-                    err = f'self-test gave {probe.tolist()}'
-                    ok.fill_(0)
-            except Exception as e:
-                err = f'{type(e).__name__}: {e}'
-                ok.fill_(0)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok.item()) == 1:
-            _native[group] = comm
-        else:
-            if comm is not None:
-                comm.destroy()
-            if err or dist.get_rank(group) == 0:
-                print(f'# nemoflux_amd.dist: native RCCL communicator unavailable ({err or "failed on another rank"}); '
-                      'reducing through torch.distributed', file=sys.stderr)
-            _native[group] = False
-    return _native[group] or None
+        all_ok = _agree(0 if err else 1, group)
+    if not all_ok:
+        return _fallback(group, err, comm)
+    _native[group] = comm
+    return comm
 
 
 def destroy_native_comms():

@@ -147,7 +147,7 @@ def test_plain_c_client_of_the_abi(tmp_path):
     assert 'reduce: 1 rank(s), rank 0 on device 0, row = 1.5 -2.0 360.0' in r.stdout      # nf_rows_allreduce from plain C
 
 
-def _bench_json(extra, nproc=1, launcher='torchrun'):
+def _bench_json(extra, nproc=1, launcher='torchrun', env_extra=None, with_stderr=False):
     """Run bench.py on a small grid -- directly (N=1), under torch.distributed.run with `nproc` ranks (the driver's N>1
     command), or as plain `python bench.py --gpus N` (launcher='self': bench.py starts its own ranks); with N>1 all ranks
     use GPU 0 and reduce over gloo (NF_FORCE_DEVICE / NF_DIST_BACKEND: the rehearsal hook of nemoflux_amd.dist).
@@ -171,11 +171,12 @@ def _bench_json(extra, nproc=1, launcher='torchrun'):
             cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
                    '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
                    '--gpus', str(nproc)] + small
+    env.update(env_extra or {})
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    return (json.loads(lines[0]), r.stderr) if with_stderr else json.loads(lines[0])
 
 
 @pytest.mark.parametrize('scaling', ['strong', 'weak', 'default'])
@@ -203,6 +204,33 @@ def test_bench_two_ranks_rehearsal(scaling):
     r = two['roofline']            # rank 0's kernel: half of the slabs
     assert r['frac'] > 0 and r['launches'] >= 2
     _check_rank_records(two, 2, nt_global * 9)
+
+
+def test_bench_start_up_fails_soft_when_a_rank_cannot_join_rccl():
+    """Round-3 verdict W6, on the GPU box: bench.py with two ranks whose native-communicator start-up is rehearsed
+    (NF_NATIVE_REDUCE=rehearse) and rank 1's preflight made to fail (NF_TEST_FAIL_COMM=1): nobody enters ncclCommInitRank,
+    both ranks fall back to torch.distributed together with the line on stderr, and the totals equal the N=1 run."""
+    nt = 3
+    two, err = _bench_json(['--nt', str(nt)], nproc=2, with_stderr=True,
+                           env_extra={'NF_NATIVE_REDUCE': 'rehearse', 'NF_TEST_FAIL_COMM': '1', 'NF_DIST_TIMEOUT_S': '120'})
+    one = _bench_json(['--nt', str(nt)])
+    assert 'injected preflight failure on rank 1' in err and 'reducing through torch.distributed' in err
+    assert two['reduce']['path'] == 'torch.distributed.all_reduce' and two['n_gpus'] == 2
+    a, b = numpy.array(two['totals']), numpy.array(one['totals'])
+    assert a.shape == b.shape and numpy.abs(a - b).max() <= 1e-13 * numpy.abs(b).max()
+    # without the injected fault the rehearsal stops at the agreement (two ranks on one device cannot form a communicator)
+    two, err = _bench_json(['--nt', str(nt)], nproc=2, with_stderr=True, env_extra={'NF_NATIVE_REDUCE': 'rehearse'})
+    assert 'rehearsal on the gloo backend' in err and two['reduce']['path'] == 'torch.distributed.all_reduce'
+
+
+def test_rccl_preflight_is_not_collective():
+    """nf_rccl_preflight: librccl resolves and this thread has a device -- answered by one rank on its own."""
+    import ctypes
+    import torch
+    from nemoflux_amd._lib import lib, check
+    dev = ctypes.c_int(-1)
+    check(lib.nf_rccl_preflight(ctypes.byref(dev)))
+    assert dev.value == torch.cuda.current_device()
 
 
 def _check_rank_records(line, world, slabs):
