@@ -27,10 +27,10 @@ def check_variants(variants, real='float64'):
     dg.computeUVFromPotential()
     tri = numpy.array([(-100., -50., 0.), (100., -50., 0.), (0., 50., 0.), (-100., -50., 0.)])
     args = (dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, [tri])
-    with contextlib.redirect_stdout(io.StringIO()):
-        ref = Field.fromArrays(*args)
     for variant in variants:
         try:
+            with contextlib.redirect_stdout(io.StringIO()):      # a fresh pair: maxAbsFlux is monotone over a field's life
+                ref = Field.fromArrays(*args)
             check(lib.nf_tuning_set(b'flux_variant', variant))
             with contextlib.redirect_stdout(io.StringIO()):
                 alt = Field.fromArrays(*args)
