@@ -195,6 +195,10 @@ try {
         integral_use_edges(value);
         return NF_OK;
     }
+    if (!strcmp(name, "datagen_rows")) {   // generator: 1 = the row kernel (default), 0 = one cell per lane with plain division
+        datagen_use_rows(value);
+        return NF_OK;
+    }
     int rc = tuning_set(name, value);
     NF_REQUIRE(rc == NF_OK, NF_ERR_ARG, std::string("nf_tuning_set: unknown knob ") + name);
     return NF_OK;

@@ -197,6 +197,7 @@ int launch_face_vectors(const double *xy, const long *cell_dev, const double *pc
 // datagen
 int launch_datagen_bounds(double *blon, double *blat, long ny, long nx, double xmin, double xmax, double ymin,
                           double ymax, double dlon, double dlat, int lat_uses_dx, hipStream_t s);
+void datagen_use_rows(int on);   // 0: always the one-cell-per-lane generator kernel (plain division): the row kernel's reference
 int launch_datagen_uv(void *u, void *v, int dtype, long t0, long t1, long nt, long nz, long ny, long nx,
                       double xmin, double xmax, double ymin, double ymax, double zmin, double zmax,
                       int lat_uses_dx, int psi, hipStream_t s);

@@ -8,6 +8,8 @@
 // the reference's rotatePole is a Python triple loop), so the generator lives on the GPU.  There is no
 // eval() on the device: psi comes from the fixed menu of include/nemoflux_amd.h, each entry evaluated in the
 // SAME operation order as the Python expression it names (no fma contraction), psi = post(g(z,t) * h(x,y)).
+#include <vector>
+
 #include "nf_common.h"
 
 namespace nf {
@@ -156,19 +158,68 @@ __global__ __launch_bounds__(kBlock) void k_ds(double *__restrict__ ds21, double
     ds23[c] = d23;
 }
 
+// ---- u, v of all slabs: the write stream of the generator (93 GB for the bench workload) -----------------------------
+// Division is the arithmetic of this kernel (u = dpsi/ds21, v = -dpsi/ds23, psi = g h / (2 pi)), and its divisors do not
+// depend on the slab: ds21, ds23 belong to the cell, 2 pi is a constant.  The compiler's own float64 division on gfx950 is
+//      r = rcp(d); e = fma(-d, r, 1); r = fma(r, e, r); e = fma(-d, r, 1); r = fma(r, e, r);      <- divisor only
+//      q = n * r;  rem = fma(-d, q, n);  n / d = fma(rem, r, q)                                   <- per quotient
+// (wrapped in v_div_scale / v_div_fmas / v_div_fixup, which change nothing unless an operand sits near the ends of the
+// exponent range or the numerator is zero).  So the divisor half is done ONCE per cell and kept in registers and every slab
+// pays three operations per quotient instead of eleven plus a quarter-rate reciprocal -- the same operations on the same
+// operands, hence the same bits (test_device_datagen_vs_reference, test_datagen_fast_path_equals_plain_division).
+// Operands outside [2^-400, 2^400] (never the case for the menu's stream functions) take the plain division.
+struct Divisor {
+    double d, r;
+    bool plain;   // divisor outside the range in which the hardware sequence runs unscaled
+};
+__device__ inline Divisor make_divisor(double d)
+{
+    Divisor x;
+    x.d = d;
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    x.r = r;
+    x.plain = !(d >= 0x1p-400 && d <= 0x1p400);
+    return x;
+}
+__device__ inline double divide(double n, const Divisor &x)
+{
+    const double q = n * x.r;
+    const double rem = fma(-x.d, q, n);
+    double res = fma(rem, x.r, q);
+    const double an = fabs(n);
+    if (x.plain || !(an >= 0x1p-400 && an <= 0x1p400)) {   // zero, tiny, huge, NaN: rare
+        double nn = n;
+        asm volatile("" : "+v"(nn));   // keeps this a real branch (skipped by the whole wave): without it the compiler
+        res = nn / x.d;                // computes BOTH forms for every quotient and selects
+    }
+    return res;
+}
+// POT: how psi follows from g(z,t) and h(x,y) -- 0: h, 1: g*h, 2: g*h/(2 pi)  (psi_pot, as a compile-time choice)
+__host__ __device__ inline int psi_pot_kind(int psi) { return psi == 5 ? 2 : (psi == 3 || psi == 4) ? 1 : 0; }
+template <int POT>
+__device__ inline double psi_pot_div(double g, double h, const Divisor &twopi)
+{
+    if (POT == 2) return divide(g * h, twopi);   // g * h / (2.0 * kPi)
+    if (POT == 1) return g * h;
+    return h;
+}
+
+// one cell per lane: any shape, any alignment (and the reference for the row kernel below)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_uv(T *__restrict__ u, T *__restrict__ v,
                                                const double *__restrict__ h, const double *__restrict__ ds21,
-                                               const double *__restrict__ ds23, unsigned ny, unsigned nx,
-                                               long nz, long t0, long nt, double zmin, double dz, int psi)
+                                               const double *__restrict__ ds23, const double *__restrict__ gtab,
+                                               unsigned ny, unsigned nx, int psi)
 {
     const long c = (long)blockIdx.x * kBlock + threadIdx.x;
     const long ncell = (long)ny * nx;
     if (c >= ncell) return;
     const long slab = blockIdx.y;  // (t - t0) * nz + k
-    const long t = t0 + slab / nz, k = slab % nz;
-    const double z = zmin + ((double)k + 0.5) * dz;  // datagen.py:38
-    const double g = psi_g(psi, z, t, nt);
+    const double g = gtab[slab];
     const unsigned j = (unsigned)(c / nx), i = (unsigned)(c - (long)j * nx);
     const long nx1 = (long)nx + 1;
     const double p1 = psi_pot(psi, g, h[(long)j * nx1 + i + 1]);        // corner 1
@@ -177,6 +228,59 @@ __global__ __launch_bounds__(kBlock) void k_uv(T *__restrict__ u, T *__restrict_
     u[slab * ncell + c] = (T)((p2 - p1) / ds21[c]);   // datagen.py:107,110
     v[slab * ncell + c] = (T)(-(p2 - p3) / ds23[c]);  // datagen.py:108,113
 }
+
+// A lane owns VEC consecutive cells of ONE grid row (16 bytes of output: 2 x float64 or 4 x float32; nx % VEC == 0) and
+// walks `chunk` slabs: node values h and the divisors' reciprocals are loaded / refined once and stay in registers; per
+// slab the wavefront stores 1 KiB contiguous to u and to v with non-temporal 16-byte stores (a write-once stream).
+template <typename T, int VEC, int POT>
+__global__ __launch_bounds__(kBlock) void k_uv_rows(T *__restrict__ u, T *__restrict__ v,
+                                                    const double *__restrict__ h, const double *__restrict__ ds21,
+                                                    const double *__restrict__ ds23, const double *__restrict__ gtab,
+                                                    unsigned ny, unsigned nx, long nslab, int chunk)
+{
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+    const long ncell = (long)ny * nx;
+    const long c0 = ((long)blockIdx.x * kBlock + threadIdx.x) * VEC;
+    if (c0 >= ncell) return;
+    const unsigned j = (unsigned)(c0 / nx), i = (unsigned)(c0 - (long)j * nx);
+    const long nx1 = (long)nx + 1;
+    double hlo[VEC], hhi[VEC + 1];          // nodes (j, i+1 .. i+VEC) and (j+1, i .. i+VEC)
+    Divisor d21[VEC], d23[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        hlo[k] = h[(long)j * nx1 + i + 1 + k];
+        d21[k] = make_divisor(ds21[c0 + k]);
+        d23[k] = make_divisor(ds23[c0 + k]);
+    }
+#pragma unroll
+    for (int k = 0; k <= VEC; ++k) hhi[k] = h[(long)(j + 1) * nx1 + i + k];
+    const Divisor twopi = make_divisor(2.0 * kPi);
+    const long s0 = (long)blockIdx.y * chunk;
+    const long s1 = s0 + chunk < nslab ? s0 + chunk : nslab;
+    T *pu = u + s0 * ncell + c0, *pv = v + s0 * ncell + c0;
+    for (long s = s0; s < s1; ++s) {
+        const double g = gtab[s];           // wave-uniform: a scalar load
+        double plo[VEC], phi[VEC + 1];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) plo[k] = psi_pot_div<POT>(g, hlo[k], twopi);
+#pragma unroll
+        for (int k = 0; k <= VEC; ++k) phi[k] = psi_pot_div<POT>(g, hhi[k], twopi);
+        vecT ou, ov;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            ou[k] = (T)divide(phi[k + 1] - plo[k], d21[k]);       // (p2 - p1) / ds21      datagen.py:107,110
+            ov[k] = (T)divide(-(phi[k + 1] - phi[k]), d23[k]);    // -(p2 - p3) / ds23     datagen.py:108,113
+        }
+        __builtin_nontemporal_store(ou, reinterpret_cast<vecT *>(pu));
+        __builtin_nontemporal_store(ov, reinterpret_cast<vecT *>(pv));
+        pu += ncell;
+        pv += ncell;
+    }
+}
+
+// 1 = the row kernel where shape and alignment allow (default); 0 = always one cell per lane (the test's reference path)
+static int g_uv_rows = 1;
+void datagen_use_rows(int on) { g_uv_rows = on; }
 
 int launch_datagen_uv(void *u, void *v, int dtype, long t0, long t1, long nt, long nz, long ny, long nx,
                       double xmin, double xmax, double ymin, double ymax, double zmin, double zmax,
@@ -198,20 +302,52 @@ int launch_datagen_uv(void *u, void *v, int dtype, long t0, long t1, long nt, lo
     const unsigned nb = (unsigned)((ncell + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_ds, dim3(nb), dim3(kBlock), 0, s, ds21, ds23, (unsigned)ny, (unsigned)nx, xmin, ymin, dx,
                        dyy);
-    if (t1 > t0) {
-        dim3 grid(nb, (unsigned)((t1 - t0) * nz));
-        if (dtype == NF_F64)
-            hipLaunchKernelGGL(k_uv<double>, grid, dim3(kBlock), 0, s, (double *)u, (double *)v, h, ds21, ds23,
-                               (unsigned)ny, (unsigned)nx, nz, t0, nt, zmin, dz, psi);
-        else
-            hipLaunchKernelGGL(k_uv<float>, grid, dim3(kBlock), 0, s, (float *)u, (float *)v, h, ds21, ds23,
-                               (unsigned)ny, (unsigned)nx, nz, t0, nt, zmin, dz, psi);
+    // g(z, t) of every slab: a table (the lanes of a slab share it, and psi 4's cosine is then evaluated once per slab)
+    const long nslab = (t1 - t0) * nz;
+    std::vector<double> gh((size_t)(nslab ? nslab : 1));
+    for (long sl = 0; sl < nslab; ++sl) {
+        const long t = t0 + sl / nz, k = sl % nz;
+        gh[(size_t)sl] = psi_g(psi, zmin + ((double)k + 0.5) * dz, t, nt);   // z: datagen.py:38
+    }
+    double *gtab = nullptr;
+    NF_HIP(hipMalloc((void **)&gtab, sizeof(double) * gh.size()));
+    NF_HIP(hipMemcpyAsync(gtab, gh.data(), sizeof(double) * gh.size(), hipMemcpyHostToDevice, s));
+    if (nslab > 0) {
+        const int vec = dtype == NF_F64 ? 2 : 4;
+        const bool rows = g_uv_rows && nx % vec == 0 && (uintptr_t)u % 16 == 0 && (uintptr_t)v % 16 == 0;
+        if (rows) {
+            const int chunk = 25;   // slabs per workgroup: the per-cell prologue (7 loads, 2 reciprocals) is paid once per chunk
+            dim3 grid((unsigned)((ncell / vec + kBlock - 1) / kBlock), (unsigned)((nslab + chunk - 1) / chunk));
+            const int pot = psi_pot_kind(psi);
+#define NF_UV_ROWS(T, VEC, POT)                                                                                          \
+    hipLaunchKernelGGL((k_uv_rows<T, VEC, POT>), grid, dim3(kBlock), 0, s, (T *)u, (T *)v, h, ds21, ds23, gtab, (unsigned)ny, \
+                       (unsigned)nx, nslab, chunk)
+            if (dtype == NF_F64) {
+                if (pot == 2) NF_UV_ROWS(double, 2, 2);
+                else if (pot == 1) NF_UV_ROWS(double, 2, 1);
+                else NF_UV_ROWS(double, 2, 0);
+            } else {
+                if (pot == 2) NF_UV_ROWS(float, 4, 2);
+                else if (pot == 1) NF_UV_ROWS(float, 4, 1);
+                else NF_UV_ROWS(float, 4, 0);
+            }
+#undef NF_UV_ROWS
+        } else {
+            dim3 grid(nb, (unsigned)nslab);
+            if (dtype == NF_F64)
+                hipLaunchKernelGGL(k_uv<double>, grid, dim3(kBlock), 0, s, (double *)u, (double *)v, h, ds21, ds23, gtab,
+                                   (unsigned)ny, (unsigned)nx, psi);
+            else
+                hipLaunchKernelGGL(k_uv<float>, grid, dim3(kBlock), 0, s, (float *)u, (float *)v, h, ds21, ds23, gtab,
+                                   (unsigned)ny, (unsigned)nx, psi);
+        }
     }
     hipError_t e = hipGetLastError();
     hipError_t e2 = hipStreamSynchronize(s);
     (void)hipFree(h);
     (void)hipFree(ds21);
     (void)hipFree(ds23);
+    (void)hipFree(gtab);
     NF_HIP(e);
     NF_HIP(e2);
     return NF_OK;

@@ -88,6 +88,32 @@ def test_datagen_f32_and_time_window():
     assert numpy.array_equal(u12.cpu().numpy(), u64[1:3])
 
 
+@pytest.mark.parametrize('real', ['float64', 'float32'])
+def test_datagen_row_kernel_equals_plain_division(real):
+    """Round-3 verdict W5.  The generator's write kernel keeps the divisor half of every float64 division (ds21, ds23, 2 pi:
+    none depends on the slab) in registers and does only the per-quotient half per slab -- the same operations the compiler
+    emits for `/`, hence the same BITS (signs of zeros included) as the one-cell-per-lane kernel with plain division, for
+    every stream function of the menu, with and without the pole rows' 1e-12 divisor, float64 and float32 output; shapes
+    whose rows do not split into 16-byte pieces take the plain kernel by themselves."""
+    from nemoflux_amd._lib import lib, check
+    from nemoflux_amd.datagen import STREAM_FUNCTIONS
+    bits = numpy.uint64 if real == 'float64' else numpy.uint32
+    for psi in STREAM_FUNCTIONS:
+        for nx, ny, nz, nt, box in ((72, 36, 27, 3, (-180., 180., -90., 90., 0., 1.)),
+                                    (40, 24, 5, 2, (-20., 40., 30., 66., 0., 100.))):
+            out = []
+            for rows in (1, 0):
+                try:
+                    check(lib.nf_tuning_set(b'datagen_rows', rows))
+                    dg = device_case(nx, ny, nz, nt, psi, real=real, box=box)
+                    out.append((dg.u.cpu().numpy().view(bits), dg.v.cpu().numpy().view(bits)))
+                finally:
+                    check(lib.nf_tuning_set(b'datagen_rows', 1))
+            assert numpy.array_equal(out[0][0], out[1][0]) and numpy.array_equal(out[0][1], out[1][1]), (psi, nx)
+    dg = device_case(35, 18, 4, 2, PSI_ZT, real=real)          # nx not a multiple of the lane's cells: the plain kernel
+    assert numpy.isfinite(dg.u.cpu().numpy()).all()
+
+
 # ------------------------------------------------------------------------------------------ BASELINE configs
 def test_config_c2_rotated_closed_loop_and_twin(oracle):
     """C2: 360x180x10x20, deltaDeg=(20,30), closed loop -> 0 (reference: 2.34e-11 at unit amplitude; here the
