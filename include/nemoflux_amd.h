@@ -277,6 +277,10 @@ int nf_rows_allreduce(void *rccl_comm, double *rows_dev, size_t n, void *hip_str
 typedef struct nf_inflater nf_inflater;
 int nf_inflater_new(nf_inflater **self);
 int nf_inflater_del(nf_inflater **self);
+/* `self` uses owner's decode scratch (the decoded group, job and status arrays) from now on instead of its own: for two
+ * inflaters whose nf_inflater_run calls never overlap in time (a run is synchronous) but which each need their own
+ * compressed buffer -- the two staging slots of a file-backed field.  owner must outlive self. */
+int nf_inflater_share_scratch(nf_inflater **self, nf_inflater **owner);
 /* how many chunks the device decodes at once (resident decoder wavefronts): callers batch that many per nf_inflater_run */
 int nf_inflater_capacity(int *streams);
 /* Early upload: copy comp_bytes of compressed chunks to HBM on the inflater's own stream, complete at return.  Meant for a

@@ -131,6 +131,7 @@ _sig('nf_rows_allreduce', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ct
 c_ll_p = ctypes.POINTER(ctypes.c_longlong)
 _sig('nf_inflater_new', [_pp])
 _sig('nf_inflater_del', [_pp])
+_sig('nf_inflater_share_scratch', [_pp, _pp])
 _sig('nf_inflater_capacity', [c_int_p])
 _sig('nf_inflater_upload', [_pp, ctypes.c_void_p, ctypes.c_size_t])
 _sig('nf_inflater_upload_ranges', [_pp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_size_t])

@@ -198,6 +198,11 @@ struct Inflater {
     hipStream_t copy_stream = nullptr;
     size_t uploaded = 0;          // bytes of compressed data sitting in d_comp, 0 = none
     int device = -1;
+    // nf_inflater_share_scratch: the decode scratch (d_tmp = the whole decoded group, d_jobs, d_status) of ANOTHER inflater is
+    // used instead of an own one.  Only the compressed buffer needs one copy per staging slot (it is filled by the staging
+    // thread while the other slot decodes); a run is synchronous on its caller's thread, so two inflaters whose runs never
+    // overlap in time can share the rest (a file-backed Field then holds one decoded-group scratch, not two).
+    Inflater *scratch_owner = nullptr;
     void release()
     {
         for (void *p : {(void *)d_comp, (void *)d_tmp, (void *)d_jobs, (void *)d_status})
@@ -320,22 +325,23 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
     const size_t comp_pad = comp_padded(comp_bytes);
     const size_t tmp_bytes = (size_t)chunk_bytes * (size_t)n;
     if (comp_host) NF_TRY_RC(comp_reserve(h, comp_pad));
-    if (h->tmp_cap < tmp_bytes) {
-        if (h->d_tmp) (void)hipFree(h->d_tmp);
-        h->d_tmp = nullptr;
-        h->tmp_cap = 0;
-        NF_HIP(hipMalloc((void **)&h->d_tmp, tmp_bytes));
-        h->tmp_cap = tmp_bytes;
+    Inflater *so = h->scratch_owner ? h->scratch_owner : h;    // whose decode scratch this run uses
+    if (so->tmp_cap < tmp_bytes) {
+        if (so->d_tmp) (void)hipFree(so->d_tmp);
+        so->d_tmp = nullptr;
+        so->tmp_cap = 0;
+        NF_HIP(hipMalloc((void **)&so->d_tmp, tmp_bytes));
+        so->tmp_cap = tmp_bytes;
     }
-    if (h->jobs_cap < (size_t)n) {
-        if (h->d_jobs) (void)hipFree(h->d_jobs);
-        if (h->d_status) (void)hipFree(h->d_status);
-        h->d_jobs = nullptr;
-        h->d_status = nullptr;
-        h->jobs_cap = 0;
-        NF_HIP(hipMalloc((void **)&h->d_jobs, sizeof(InflateJob) * (size_t)n));
-        NF_HIP(hipMalloc((void **)&h->d_status, sizeof(int) * (size_t)n));
-        h->jobs_cap = (size_t)n;
+    if (so->jobs_cap < (size_t)n) {
+        if (so->d_jobs) (void)hipFree(so->d_jobs);
+        if (so->d_status) (void)hipFree(so->d_status);
+        so->d_jobs = nullptr;
+        so->d_status = nullptr;
+        so->jobs_cap = 0;
+        NF_HIP(hipMalloc((void **)&so->d_jobs, sizeof(InflateJob) * (size_t)n));
+        NF_HIP(hipMalloc((void **)&so->d_status, sizeof(int) * (size_t)n));
+        so->jobs_cap = (size_t)n;
     }
     if (comp_host) {
         const size_t tail = comp_bytes & ~(size_t)3;                    // zero the last partial word and the padding behind the data
@@ -343,9 +349,9 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
         NF_HIP(hipMemsetAsync(h->d_comp + tail, 0, comp_pad - tail, s));
         NF_HIP(hipMemcpyAsync(h->d_comp, comp_host, comp_bytes, hipMemcpyHostToDevice, s));
     }
-    NF_HIP(hipMemcpyAsync(h->d_jobs, jobs.data(), sizeof(InflateJob) * (size_t)n, hipMemcpyHostToDevice, s));
+    NF_HIP(hipMemcpyAsync(so->d_jobs, jobs.data(), sizeof(InflateJob) * (size_t)n, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_inflate, dim3((unsigned)n), dim3(64), 0, s, h->d_comp, (unsigned long long)comp_pad,
-                       h->d_jobs, n, h->d_tmp, (unsigned)chunk_bytes, h->d_status);
+                       so->d_jobs, n, so->d_tmp, (unsigned)chunk_bytes, so->d_status);
     const SlabGeom g{(unsigned)chunk_dims[0], (unsigned)chunk_dims[1], (unsigned)chunk_dims[2], (unsigned)slab_dims[0],
                      (unsigned)slab_dims[1], (unsigned)slab_dims[2]};
     const bool four = shuffled && chunk_dims[2] % 4 == 0;             // four elements per lane (k_place4)
@@ -357,19 +363,19 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
     if (gx == 0) gx = 1;
     const dim3 grid(gx, (unsigned)std::min(n, 65535)), block(kBlock);  // gridDim.y is capped: the kernels walk the chunks
     uint8_t *dst = (uint8_t *)out_dev;
-    if (elem_size == 1) hipLaunchKernelGGL((k_place<1, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
-    else if (sixteen) hipLaunchKernelGGL(k_place16, grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
-    else if (elem_size == 4 && four && planes) hipLaunchKernelGGL((k_place4<4, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
-    else if (elem_size == 8 && four && planes) hipLaunchKernelGGL((k_place4<8, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
-    else if (elem_size == 4 && four) hipLaunchKernelGGL((k_place4<4, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
-    else if (elem_size == 8 && four) hipLaunchKernelGGL((k_place4<8, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
-    else if (elem_size == 4 && shuffled) hipLaunchKernelGGL((k_place<4, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
-    else if (elem_size == 4) hipLaunchKernelGGL((k_place<4, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
-    else if (shuffled) hipLaunchKernelGGL((k_place<8, true>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
-    else hipLaunchKernelGGL((k_place<8, false>), grid, block, 0, s, h->d_tmp, (unsigned)chunk_bytes, h->d_jobs, n, g, dst);
+    if (elem_size == 1) hipLaunchKernelGGL((k_place<1, false>), grid, block, 0, s, so->d_tmp, (unsigned)chunk_bytes, so->d_jobs, n, g, dst);
+    else if (sixteen) hipLaunchKernelGGL(k_place16, grid, block, 0, s, so->d_tmp, (unsigned)chunk_bytes, so->d_jobs, n, g, dst);
+    else if (elem_size == 4 && four && planes) hipLaunchKernelGGL((k_place4<4, true>), grid, block, 0, s, so->d_tmp, (unsigned)chunk_bytes, so->d_jobs, n, g, dst);
+    else if (elem_size == 8 && four && planes) hipLaunchKernelGGL((k_place4<8, true>), grid, block, 0, s, so->d_tmp, (unsigned)chunk_bytes, so->d_jobs, n, g, dst);
+    else if (elem_size == 4 && four) hipLaunchKernelGGL((k_place4<4, false>), grid, block, 0, s, so->d_tmp, (unsigned)chunk_bytes, so->d_jobs, n, g, dst);
+    else if (elem_size == 8 && four) hipLaunchKernelGGL((k_place4<8, false>), grid, block, 0, s, so->d_tmp, (unsigned)chunk_bytes, so->d_jobs, n, g, dst);
+    else if (elem_size == 4 && shuffled) hipLaunchKernelGGL((k_place<4, true>), grid, block, 0, s, so->d_tmp, (unsigned)chunk_bytes, so->d_jobs, n, g, dst);
+    else if (elem_size == 4) hipLaunchKernelGGL((k_place<4, false>), grid, block, 0, s, so->d_tmp, (unsigned)chunk_bytes, so->d_jobs, n, g, dst);
+    else if (shuffled) hipLaunchKernelGGL((k_place<8, true>), grid, block, 0, s, so->d_tmp, (unsigned)chunk_bytes, so->d_jobs, n, g, dst);
+    else hipLaunchKernelGGL((k_place<8, false>), grid, block, 0, s, so->d_tmp, (unsigned)chunk_bytes, so->d_jobs, n, g, dst);
     NF_HIP(hipGetLastError());
     std::vector<int> status((size_t)n, 0);
-    NF_HIP(hipMemcpyAsync(status.data(), h->d_status, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+    NF_HIP(hipMemcpyAsync(status.data(), so->d_status, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
     NF_HIP(hipStreamSynchronize(s));    // jobs / status vectors are pageable host memory: the copies above are done now
     int bad = -1;
     for (int i = 0; i < n; ++i) {
@@ -390,6 +396,27 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
 // ------------------------------------------------------------------------------------------------------- C ABI
 using namespace nf;
 extern "C" {
+
+int nf_inflater_share_scratch(nf_inflater **self, nf_inflater **owner)
+{
+    if (!self || !*self || !owner || !*owner || *self == *owner) {
+        set_error("nf_inflater_share_scratch: two different inflaters are needed");
+        return NF_ERR_ARG;
+    }
+    Inflater *h = reinterpret_cast<Inflater *>(*self), *o = reinterpret_cast<Inflater *>(*owner);
+    if (o->scratch_owner) {
+        set_error("nf_inflater_share_scratch: the owner borrows its scratch itself");
+        return NF_ERR_ARG;
+    }
+    for (void *p : {(void *)h->d_tmp, (void *)h->d_jobs, (void *)h->d_status})   // its own scratch is not needed any more
+        if (p) (void)hipFree(p);
+    h->d_tmp = nullptr;
+    h->d_jobs = nullptr;
+    h->d_status = nullptr;
+    h->tmp_cap = h->jobs_cap = 0;
+    h->scratch_owner = o;
+    return NF_OK;
+}
 
 int nf_inflater_new(nf_inflater **self)
 {

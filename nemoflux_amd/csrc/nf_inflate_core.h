@@ -626,7 +626,8 @@ NFI_FN void nfi_decode_round_cxx(NfiCtx &c, const uint8_t *flushed_out, uint32_t
 //              2  distance code longer than its table (length decoded)  3  overlapping or far copy (len, dist decoded)
 // Register plan inside the block (moved in and out at its ends): s39 literal limit, s[40:41] bit buffer, s42 valid bits, s43
 // entry at the head, s44 output position, s45 ring word, s46 stop bit, s47-s49 scratch, s50 len, s51 dist, s52 distance
-// entry, s53 OR of the entries used, s54 error, s55 / s56 word / position limits, s57 reason, s[58:59] saved exec, s60 / s61
+// entry, s53 OR of the entries used, s54 error, s55 / s56 word / position limits, s57 reason, s[58:59] saved exec (s38: saved
+// M0 -- index mode overwrites it, and a reserved register cannot go on the clobber list), s60 / s61
 // row / lane of the pending lookup, s[62:63] lane mask of a literal store; v40-v48 scratch, v60-v79 the tables.
 // ctx sits at LDS address 0 (k_inflate checks): the window is addressed from 0, the tables by immediate offsets.
 NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t out_len)
@@ -659,6 +660,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
         flags = NFI_UNI(flags); err = NFI_UNI(err);
         asm volatile(
             "s_mov_b64 s[58:59], exec\n\t"
+            "s_mov_b32 s38, m0\n\t"            // VGPR index mode below overwrites M0: the compiler's value is put back at the end
             "s_mov_b64 s[40:41], %[buf]\n\t"
             "s_mov_b32 s42, %[cnt]\n\t"
             "s_mov_b32 s43, %[e]\n\t"
@@ -914,6 +916,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             "s_mov_b32 s57, 0\n\t"
             "8:\n"
             "s_set_gpr_idx_off\n\t"
+            "s_mov_b32 m0, s38\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "s_mov_b64 exec, s[58:59]\n\t"
             "s_mov_b64 %[buf], s[40:41]\n\t"
@@ -934,7 +937,7 @@ NFI_FN void nfi_decode_round_asm(NfiCtx &c, const uint8_t *flushed_out, uint32_t
             : [word_stop] "s"(word_stop), [hard_stop] "s"(hard_stop), [lane] "v"(lane),
               [lit] "n"(__builtin_offsetof(NfiCtx, lit_tab)), [dtab] "n"(__builtin_offsetof(NfiCtx, dist_tab)),
               [ring] "n"(__builtin_offsetof(NfiCtx, ring)), [win] "n"(kNfiWindow), [wmask] "n"(kNfiWindow - 1)
-            : "memory", "scc", "vcc", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+            : "memory", "scc", "vcc", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
               "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v40", "v41", "v42", "v43", "v44",
               "v45", "v46", "v48", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73",
               "v74", "v75", "v76", "v77", "v78", "v79");

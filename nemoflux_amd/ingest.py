@@ -55,6 +55,12 @@ class ChunkDecoder(object):
         except Exception:
             pass
 
+    def share_scratch_of(self, owner):
+        """Decode into `owner`'s scratch (the decoded group, job and status arrays) instead of an own one: for decoders whose
+        decode() calls never overlap in time but which each keep their own compressed buffer (the stager's two slots)."""
+        check(lib.nf_inflater_share_scratch(ctypes.byref(self._h), ctypes.byref(owner._h)))
+        self._scratch_owner = owner      # keeps it alive
+
     @staticmethod
     def capacity():
         """chunks the device decodes at once (resident decoder wavefronts)"""

@@ -51,7 +51,10 @@ class StepStager(object):
                 self.decoder = ChunkDecoder()
                 # one decoder per slot: its compressed-bytes buffer in HBM is filled by the staging thread (early upload)
                 # while the other slot's group is being decoded
+                # (only the compressed buffer needs that: decode() is synchronous on the caller's thread, so the second decoder
+                # borrows the first one's scratch for the decoded group -- one copy of it in HBM, not two)
                 self._decoders = [self.decoder, ChunkDecoder()]
+                self._decoders[1].share_scratch_of(self.decoder)
                 self.comp_bytes = need
                 per_step = sum(len(s.device_plan(0)['chunks']) for s, n in zip(self.src, need) if n is not None)
                 # Resident decoder wavefronts: 4 per CU = 1024 streams.  A launch whose streams all start at once ends when its

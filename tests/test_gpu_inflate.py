@@ -134,7 +134,8 @@ def test_device_inflate_refuses_malformed_streams(decoder):
 
 
 def test_device_inflate_more_streams_than_resident_wavefronts(decoder):
-    """3000 different streams in ONE launch -- more than the 2560 decoder wavefronts the chip holds at once (ten per CU) --
+    """3000 different streams in ONE launch -- about three times the 1024 decoder wavefronts the chip holds at once (the
+    shipped build keeps DEFLATE's whole 32 KiB window in LDS: 39 KiB per stream, four streams per CU; nf_inflater_capacity) --
     of mixed content (text-like, runs, noise, shuffled floats, long periods), levels and strategies: every one must come
     back exact."""
     assert 256 <= decoder.capacity() < 3000

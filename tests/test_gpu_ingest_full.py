@@ -145,10 +145,12 @@ def test_tiled_layouts_with_overhanging_edge_chunks_at_c3_size(real, chunk):
 
 def test_more_megabyte_streams_than_resident_wavefronts():
     """(d) a group larger than nf_inflater_capacity: capacity + 300 streams of 1.47 MB in ONE launch -- the four byte planes
-    of shuffled float32 levels (noise -> stored blocks, Huffman literals + short matches, long matches) and, for the far
-    path of the copy, data that repeats with periods of 9 000 .. 30 000 bytes (every match reaches further back than the
-    8 KiB of history kept in LDS and reads the stream's own flushed output in HBM) -- late workgroups start while early
-    ones are mid-stream."""
+    of shuffled float32 levels (noise -> stored blocks, Huffman literals + short matches, long matches) and data that
+    repeats with periods of 9 000 .. 30 000 bytes (long-distance matches: the copy's source wraps around the window ring)
+    -- late workgroups start while early ones are mid-stream.  The shipped library is built with NFI_WINDOW = 32768 = the
+    format's maximum distance (4 streams per CU, capacity 1024), so on the device every match source lies INSIDE the LDS
+    window: the decoder's far path (sources already flushed to HBM, which a smaller window needs) never runs on a GPU; it is
+    covered by the host build of tests/test_inflate_cpu.py with -DNFI_WINDOW=8192 only."""
     from nemoflux_amd.ingest import ChunkDecoder
     dec = ChunkDecoder()
     cap = dec.capacity()
