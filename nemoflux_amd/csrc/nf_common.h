@@ -90,6 +90,15 @@ __device__ inline void unwrap_quad(double *v, double periodX)
         if (n != 0.0) v[2 * k] -= n * periodX;
     }
 }
+// a cell with a corner that is not a finite number (NaN or infinite bounds on land-only subdomains) is no cell at all: it
+// takes part in nothing and the coverage of a line through it says so
+__device__ inline bool quad_is_finite(const double *v)
+{
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ok = ok && (fabs(v[k]) <= 1.7976931348623157e308);
+    return ok;
+}
 constexpr double kCoverTol = 1.e-8;   // a target segment covered more than 1 + this is counted twice somewhere: an error
 
 // ---- launchers (defined in the .hip files) ----------------------------------------------------------

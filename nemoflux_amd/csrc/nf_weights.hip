@@ -211,11 +211,12 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
     }
     __syncthreads();
     const long c = c0 + tid;
-    const bool valid = c < ncell;
+    bool valid = c < ncell;
     double v[8];
     double cxmin = 1e300, cxmax = -1e300, cymin = 1e300, cymax = -1e300;
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = valid ? s_xy[tid * 8 + k] : 0.0;
+    valid = valid && quad_is_finite(v);            // NaN / infinite corners: not a cell
     unwrap_quad(v, nshift == 3 ? periodX : 0.0);   // date-line cells (nf_common.h)
     if (valid) {
 #pragma unroll

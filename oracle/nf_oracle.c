@@ -28,6 +28,7 @@
  * Build: see oracle/Makefile (gcc -O2 -mfma -ffp-contract=off).  fma() is used explicitly where the
  * HIP kernels use it so the two can be compared bit-for-bit; no other contraction is allowed.
  */
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -271,6 +272,13 @@ static void unwrap_quad(double *v, double periodX)
     }
 }
 
+/* a cell with a corner that is not a finite number (NaN / infinite bounds on land-only subdomains) is no cell at all */
+static int quad_is_finite(const double *v)
+{
+    for (int k = 0; k < 8; ++k) if (!(fabs(v[k]) <= DBL_MAX)) return 0;
+    return 1;
+}
+
 static int point_in_quad_evenodd(const double *v, double px, double py)
 {
     int in = 0;
@@ -357,6 +365,7 @@ long nfo_polyline_weights(const double *points, long ncell, const double *xyz, i
                     v[2 * i] = points[(c * 4 + i) * 3];
                     v[2 * i + 1] = points[(c * 4 + i) * 3 + 1];
                 }
+                if (!quad_is_finite(v)) continue;
                 unwrap_quad(v, periodX);
                 for (int i = 0; i < 4; ++i) {
                     if (v[2 * i] < cxmin) cxmin = v[2 * i];
@@ -497,6 +506,7 @@ void nfo_vector_interp(const double *points, long ncell, const double *targets, 
                 v[2 * i] = points[(c * 4 + i) * 3];
                 v[2 * i + 1] = points[(c * 4 + i) * 3 + 1];
             }
+            if (!quad_is_finite(v)) continue;
             unwrap_quad(v, periodX);   /* date-line cells: as in A6 */
             for (int i = 0; i < 4; ++i) {
                 if (v[2 * i] < xmin) xmin = v[2 * i];

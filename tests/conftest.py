@@ -218,3 +218,27 @@ def wrapped_grid_case(oracle, kind, seed):
     wr = pts.copy()
     wr[:, :, 0] = wrap180(pts[:, :, 0])
     return pts, wr, data, transects, exact
+
+
+DATELINE_LINES = ["(180,-60),(180,40)", "(-180,-60),(-180,40)", "(175,-60),(180,-60),(180,40),(185,40)", "(0,-60),(0,40)",
+                  "(360,-60),(360,40)", "(170,-55),(190,-55)", "(170,-55),(-170,-55)", "(180,-60),(180,-60),(185,-55)"]
+
+
+def orca_like_halo_grid(oracle, nx=72, ny=36, x0=73.):
+    """A global grid that starts at 73 E like ORCA and carries two halo columns in front -- exact duplicates of its last two
+    columns, one period to the west -- the way NEMO files before 4.2 store the east-west wrap.  Returns (points on continuous
+    branches, the same with every corner's longitude wrapped into [-180, 180), node psi (ny+1, nx+1) periodic, and a function
+    giving the cell-by-cell edge data of psi for this (ny, nx+2) layout)."""
+    o = oracle.DataGen(nx, ny, 1, 1, xmin=x0, xmax=x0 + 360.)
+    blon = numpy.ascontiguousarray(numpy.concatenate([o.bounds_lon[:, -2:] - 360., o.bounds_lon], axis=1))
+    blat = numpy.ascontiguousarray(numpy.concatenate([o.bounds_lat[:, -2:], o.bounds_lat], axis=1))
+    pts = oracle.assemble_points(blon, blat)
+    wr = pts.copy()
+    wr[:, :, 0] = wrap180(pts[:, :, 0])
+    rng = numpy.random.default_rng(77)
+    psi = rng.standard_normal((ny + 1, nx + 1))
+    psi[:, -1] = psi[:, 0]
+    p0, p1, p2, p3 = psi[:-1, :-1], psi[:-1, 1:], psi[1:, 1:], psi[1:, :-1]
+    d = numpy.stack([p1 - p0, p2 - p1, p2 - p3, p3 - p0], axis=-1)           # (ny, nx, 4)
+    data = numpy.ascontiguousarray(numpy.concatenate([d[:, -2:], d], axis=1)).reshape(-1, 4)
+    return o, pts, wr, psi, data

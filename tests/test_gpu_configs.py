@@ -7,7 +7,7 @@ import os
 import numpy
 import pytest
 
-from conftest import FULL_CASES, GOLDEN, ROOT, case_box, load_golden, transect_xyz, wrapped_grid_case, wrap180
+from conftest import FULL_CASES, GOLDEN, ROOT, case_box, load_golden, transect_xyz, wrapped_grid_case, wrap180, DATELINE_LINES, orca_like_halo_grid
 
 pytestmark = pytest.mark.gpu
 EPS = numpy.finfo(numpy.float64).eps
@@ -1470,3 +1470,46 @@ def test_refuses_double_counting(oracle):
     f = quiet_field(wrapped, blat, dg.deptht_bounds, dg.u, dg.v, [probe])      # periodX = 360: field.py:47
     from nemoflux_amd.fluxexact import exactFlux
     assert abs(f.computeAll()[0][0, 0] - exactFlux(PSI_CS, [(20., -40.), (100., 30.)], 1, 1)[0]) <= 1e-12
+
+
+def test_dateline_special_lines_halo_columns_and_nonfinite_corners(oracle):
+    """K2 == oracle, entry by entry, on the inputs of test_oracle_dateline_special_lines_and_halo_columns /
+    test_oracle_cells_with_nonfinite_corners_are_no_cells: lines along the cut of a wrapped grid and along its seam, an
+    ORCA-like layout with duplicated halo columns (one half each), cells whose corners are NaN / inf / a fill value (no cells:
+    coverage < 1)."""
+    def same(pts, xyz, tol=1e-13):
+        pli, _, d = _gpu_weights(pts, xyz)
+        ow = oracle.polyline_weights(pts, xyz)
+        od = ow.as_dict()
+        assert set(d) == set(od) and (not od or max(abs(d[k] - od[k]) for k in od) <= tol)
+        assert numpy.allclose(pli.getCoverage(), ow.coverage, rtol=0, atol=1e-12)
+        return pli, ow
+    _, wr, data, _, _ = wrapped_grid_case(oracle, 'g0', 40)
+    for line in DATELINE_LINES:
+        pli, ow = same(wr, transect_xyz(line))
+        assert numpy.allclose(pli.getCoverage(), 1.0, rtol=0, atol=1e-12), line
+        assert abs(pli.getIntegral(data[0]) - oracle.get_integral(ow, data[0])) <= 1e-12
+    o, ptsh, wrh, psi, datah = orca_like_halo_grid(oracle)
+    xn, yn = o.xx[0], o.yy[:, 0]
+    rng = numpy.random.default_rng(78)
+    for k in range(12):
+        ia, ja, ib, jb = rng.integers(0, 73), rng.integers(1, 36), rng.integers(0, 73), rng.integers(1, 36)
+        n = int(rng.integers(0, 4))
+        x = numpy.concatenate([[xn[ia]], rng.uniform(73., 433., n), [xn[ib]]])
+        y = numpy.concatenate([[yn[ja]], rng.uniform(-80., 80., n), [yn[jb]]])
+        if k % 3 == 1:
+            x = wrap180(x)
+        xyz = numpy.zeros((x.size, 3))
+        xyz[:, 0], xyz[:, 1] = x, y
+        for P in (ptsh, wrh):
+            pli, ow = same(P, xyz)
+            assert numpy.allclose(pli.getCoverage(), 1.0, rtol=0, atol=1e-9), k
+            assert abs(pli.getIntegral(datah) - (psi[jb, ib] - psi[ja, ia])) <= 1e-12, k
+    dg = oracle.DataGen(72, 36, 1, 1, xmin=0., xmax=360.)
+    bad = oracle.assemble_points(dg.bounds_lon, dg.bounds_lat)
+    bad[100, :, :2] = numpy.nan
+    bad[200, 2, 0] = numpy.inf
+    bad[300, :, :2] = 1e20
+    for line, width in (("(130,-82),(150,-82)", 20.), ("(270,-77),(300,-77)", 30.), ("(10,-67),(350,-67)", 340.)):
+        pli, ow = same(bad, transect_xyz(line))
+        assert abs(pli.getCoverage()[0] - (1.0 - 5.0 / width)) <= 1e-12

@@ -8,7 +8,7 @@ import os
 import numpy
 import pytest
 
-from conftest import FULL_CASES, GOLDEN, case_box, load_golden, transect_xyz, wrapped_grid_case
+from conftest import FULL_CASES, GOLDEN, case_box, load_golden, transect_xyz, wrapped_grid_case, wrap180, DATELINE_LINES, orca_like_halo_grid
 
 EPS = numpy.finfo(numpy.float64).eps
 
@@ -640,3 +640,59 @@ def test_oracle_refuses_double_counting(oracle):
         oracle.polyline_weights(wr, transect_xyz("(20,-40),(100,30)"), periodX=0.)
     w = oracle.polyline_weights(wr, transect_xyz("(20,-40),(100,30)"), periodX=360.)
     assert numpy.allclose(w.coverage, 1.0, rtol=0, atol=1e-12)
+
+
+def test_oracle_dateline_special_lines_and_halo_columns(oracle):
+    """Lines that run ALONG the cut of a wrapped global grid (every piece shared by the cell east of 180 E, stored at
+    -180, and the un-wrapped cell west of it), along the grid's own seam at 0 / 360, and across the cut both ways: the same
+    weights as on the continuous branch, each point counted once.  And an ORCA-like layout -- start at 73 E, two halo
+    columns that duplicate the last two a period away, longitudes wrapped: duplicates share every sub-segment and count one
+    half each (coverage 1, psi differences), wrapped or not."""
+    _, wr, data, _, _ = wrapped_grid_case(oracle, 'g0', 40)
+    pts = wr.copy()
+    pts[:, :, 0] = numpy.where(wr[:, :, 0] < 0, wr[:, :, 0] + 360., wr[:, :, 0])
+    pts[:, 1:3, 0] = numpy.where(pts[:, 1:3, 0] == 0., 360., pts[:, 1:3, 0])       # east corners of the last column
+    for line in DATELINE_LINES:
+        xyz = transect_xyz(line)
+        a, b = oracle.polyline_weights(pts, xyz), oracle.polyline_weights(wr, xyz)
+        da, db = a.as_dict(), b.as_dict()
+        assert set(da) == set(db) and max(abs(da[k] - db[k]) for k in da) <= 1e-12, line
+        assert numpy.allclose(b.coverage, 1.0, rtol=0, atol=1e-12), line
+        assert abs(oracle.get_integral(a, data[0]) - oracle.get_integral(b, data[0])) <= 1e-12
+    o, ptsh, wrh, psi, datah = orca_like_halo_grid(oracle)
+    xn, yn = o.xx[0], o.yy[:, 0]
+    rng = numpy.random.default_rng(78)
+    for k in range(12):
+        ia, ja, ib, jb = rng.integers(0, 73), rng.integers(1, 36), rng.integers(0, 73), rng.integers(1, 36)
+        n = int(rng.integers(0, 4))
+        x = numpy.concatenate([[xn[ia]], rng.uniform(73., 433., n), [xn[ib]]])
+        y = numpy.concatenate([[yn[ja]], rng.uniform(-80., 80., n), [yn[jb]]])
+        if k % 3 == 1:
+            x = wrap180(x)
+        xyz = numpy.zeros((x.size, 3))
+        xyz[:, 0], xyz[:, 1] = x, y
+        for P in (ptsh, wrh):
+            w = oracle.polyline_weights(P, xyz)
+            assert numpy.allclose(w.coverage, 1.0, rtol=0, atol=1e-9), k
+            assert abs(oracle.get_integral(w, datah) - (psi[jb, ib] - psi[ja, ia])) <= 1e-12, k
+    cells = set((oracle.polyline_weights(wrh, transect_xyz("(60,-42),(90,33)")).cell_edge // 4 % 74).tolist())
+    assert {0, 1, 72, 73} <= cells          # the halo columns AND their originals carry the line, one half each
+
+
+def test_oracle_cells_with_nonfinite_corners_are_no_cells(oracle):
+    """bounds of land-only subdomains may be NaN / infinite / a fill value: a cell with a corner that is not a finite number
+    takes part in nothing, a cell collapsed onto one far-away point has no area -- the line's coverage says what is missing;
+    no wrong weight, no crash."""
+    dg = oracle.DataGen(72, 36, 1, 1, xmin=0., xmax=360.)
+    pts = oracle.assemble_points(dg.bounds_lon, dg.bounds_lat)
+    bad = pts.copy()
+    bad[100, :, :2] = numpy.nan          # row 1, lon 140..145
+    bad[200, 2, 0] = numpy.inf           # row 2, lon 280..285: one corner
+    bad[300, :, :2] = 1e20               # row 4, lon 60..65: the whole cell on a fill value
+    for line, hole, width in (("(130,-82),(150,-82)", 100, 20.), ("(270,-77),(300,-77)", 200, 30.), ("(10,-67),(350,-67)", 300, 340.)):
+        w = oracle.polyline_weights(bad, transect_xyz(line))
+        ref = oracle.polyline_weights(pts, transect_xyz(line)).as_dict()
+        got = w.as_dict()
+        assert hole not in set((w.cell_edge // 4).tolist())
+        assert abs(w.coverage[0] - (1.0 - 5.0 / width)) <= 1e-12
+        assert all(abs(got[k] - ref[k]) <= 1e-13 for k in got) and set(got) == {k for k in ref if k[1] // 4 != hole}
