@@ -69,7 +69,8 @@ int nf_host_unshuffle(const void *src, void *dst, size_t n, int es);
 int nf_host_gather(const unsigned long long *src_addr, const unsigned long long *dst_addr, const long long *len, long long n,
                    int nthreads);
 /* tuning knobs for A/B measurements inside one process: "flux_variant" (0 = default store form, 5 = the other one; see nf_flux.hip),
- * "xcd_map" (1 = on), "batch_steps" (1 = small grids run all time steps in one launch), "edge_weights", "datagen_rows"
+ * "xcd_map" (1 = on), "batch_steps" (1 = small grids run all time steps in one launch), "field_split" (-1 = one-step launches
+ * of fewer than 20 000 wavefronts integrate uo and vo in different wavefronts, 0 = never, 1 = always), "edge_weights", "datagen_rows"
  * (0 = the generator's one-cell-per-lane kernel with plain division, the reference of its row kernel) */
 int nf_tuning_set(const char *name, int value);
 

@@ -880,8 +880,11 @@ static long batch_cell_steps()
 
 static bool field_can_batch(const nf_field *f)
 {
+    // launch-bound grids only: from about a million cells on, one launch per step (with the one-field form of the flux
+    // kernel for its few wavefronts) is as fast or faster -- 1440 x 1021: 700 vs 733 us per 4-step pass at float32, 1166 vs
+    // 1144 at float64; 2160 x 1080: 1035 vs 1187 and 1863 vs 1928 (tools/size_sweep.py, profiles/r04_size_sweep.txt)
     return g_batch_steps && f->uv_on_device && f->nt >= 2 && f->nt < 65536 && f->nt * f->ncell <= batch_cell_steps() &&
-           f->weights_built;
+           f->ncell <= (1l << 20) && f->weights_built;
 }
 
 // every time step of a pass, one after the other.  A rank of a multi-GPU run owns a contiguous range of steps (slab

@@ -285,6 +285,118 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
     }
 }
 
+// ---- one field per wavefront: the launch shape for grids of a few wave-rounds -------------------------------------------
+// The chip holds about 5 000 flux wavefronts at once.  A time step of the ORCA12-like grid is 50 656 of them (ten rounds);
+// one of the ORCA025 grid (1440 x 1021, BASELINE config C3) is 11 488 at float64 and 5 744 at float32 -- 2.2 and 1.1 rounds:
+// the few wavefronts of the last, partial round run a whole wave lifetime with the chip nearly empty (one 1-KiB request in
+// flight each), and the step reaches 0.71 / 0.55 of the HBM peak where the big grid reaches 0.81 (tools/size_sweep.py).
+// eU depends on uo only and eV on vo only, so the two vertical integrals of a cell can go to DIFFERENT wavefronts without
+// touching the arithmetic: twice as many wavefronts, each half as long (75 loads instead of 150), and the partial round
+// costs half as much.  blockIdx.z selects the field; a u-wave stores plane 1, |eU| and the west copies (plane 3), a
+// v-wave plane 2, |eV| and the south copies (plane 0): the same values into the same slots as k_flux (bit-identical:
+// test_field_split_bit_identical).  launch_flux picks this form by the number of wavefronts a launch has.
+template <typename T, int VEC, int UZ, bool SIGNED_ONLY, bool TWO_FILLS>
+__global__ __launch_bounds__(256) void k_flux_field(const T *__restrict__ u, const T *__restrict__ v, long ncell,
+                                                    unsigned ny, unsigned nx, int z0, int z1,
+                                                    const double *__restrict__ thickness,
+                                                    const double *__restrict__ arcE, const double *__restrict__ arcN,
+                                                    T fill, double scale, int sverdrup, double *__restrict__ iV,
+                                                    double *__restrict__ absUV, unsigned long long *maxbits,
+                                                    unsigned ntiles, int xcd_map, StepBatch sb, T fill2)
+{
+    const unsigned tile = xcd_map ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
+    const bool is_v = blockIdx.z != 0;             // workgroup-uniform
+    if (sb.zr) {
+        const long tb = blockIdx.y;
+        u += tb * sb.in_stride;
+        v += tb * sb.in_stride;
+        iV += tb * 4 * ncell;
+        absUV += tb * 2 * ncell;
+        z0 = sb.zr[2 * tb];
+        z1 = sb.zr[2 * tb + 1];
+    }
+    double tmax = 0.0;
+    const long c0 = (long)tile * 256 * VEC + (long)threadIdx.x * VEC;
+    if (tile < ntiles && c0 < ncell) {   // ncell % VEC == 0: a lane's cells are all there or all absent
+        double acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.0;
+        const T *p = (is_v ? v : u) + (long)z0 * ncell + c0;
+        for (int z = z0; z < z1; z += UZ) {
+            const int nlev = z1 - z < UZ ? z1 - z : UZ;
+            Lanes<T, VEC> l[UZ];
+#pragma unroll
+            for (int r = 0; r < UZ; ++r)
+                if (r < nlev) l[r] = load_cells<T, VEC, true>(p + (long)r * ncell);
+#pragma unroll
+            for (int r = 0; r < UZ; ++r)
+                if (r < nlev) {
+                    const double th = thickness[z + r];
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k)
+                        acc[k] = fma(th, TWO_FILLS ? fixed2<T>(l[r].x[k], fill, fill2) : fixed<T>(l[r].x[k], fill), acc[k]);
+                }
+            p += (long)UZ * ncell;
+        }
+        const double *arc = is_v ? arcN : arcE;
+        double e[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            e[k] = is_v ? -acc[k] * arc[c0 + k] : +acc[k] * arc[c0 + k];   // field.py:195-196
+            if (sverdrup) e[k] *= scale;
+            tmax = fmax(tmax, fabs(e[k]));
+        }
+        double *own = iV + (is_v ? 2 : 1) * ncell;
+        if (VEC == 1) {
+            store1<true>(own + c0, e[0]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; k += 2) store2<true>(own + c0 + k, e[k], e[k + 1], true);
+        }
+        if (!SIGNED_ONLY) {
+            double *ab = absUV + (is_v ? ncell : 0);
+            if (VEC == 1) {
+                store1<true>(ab + c0, fabs(e[0]));
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; k += 2) store2<true>(ab + c0 + k, fabs(e[k]), fabs(e[k + 1]), true);
+            }
+            // the neighbour copies (field.py:219-223): shifted copies of the lane's own stream
+            const unsigned j0 = (unsigned)(c0 / nx), i0 = (unsigned)(c0 - (long)j0 * nx);
+            if (VEC > 1 && i0 + VEC <= nx) {        // the lane's cells sit in one row
+                if (is_v) {
+                    if (j0 + 1 < ny) {              // plane 0: south slots of the row above = this stream shifted by nx
+                        const bool al = (nx & 1u) == 0;
+#pragma unroll
+                        for (int k = 0; k < VEC; k += 2) store2<true>(iV + c0 + nx + k, e[k], e[k + 1], al);
+                    }
+                } else {                            // plane 3: west slots of the cells to the right, the row's last cell wraps
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k)
+                        store1<true>(iV + 3 * ncell + ((i0 + k + 1 < nx) ? c0 + k + 1 : c0 + k + 1 - nx), e[k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {     // a row ends inside the lane's cells (or one cell per lane)
+                    const long c = c0 + k;
+                    const unsigned j = (unsigned)(c / nx), i = (unsigned)(c - (long)j * nx);
+                    if (is_v) {
+                        if (j + 1 < ny) store1<true>(iV + c + nx, e[k]);
+                    } else {
+                        store1<true>(iV + 3 * ncell + ((i + 1 < nx) ? c + 1 : c + 1 - nx), e[k]);
+                    }
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) tmax = fmax(tmax, __shfl_xor(tmax, o, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0 && tmax > 0.0) {
+        unsigned long long b;
+        __builtin_memcpy(&b, &tmax, 8);
+        if (b > __hip_atomic_load(maxbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxbits, b);
+    }
+}
+
 #ifdef NF_TUNING_BUILD
 // tuning builds only (make -C nemoflux_amd/csrc tuning): the writer-wave form of K1 (measured 4-13 % slower, kept as a
 // record of the experiment) lives with the tools that measure it
@@ -352,6 +464,12 @@ static int env_int(const char *name, int dflt)
 // tuning knobs: environment at first use, nf_tuning_set() at run time (A/B runs inside one process)
 static int g_xcd_map = env_int("NF_XCD_MAP", 1);
 static int g_variant = env_int("NF_FLUX_VARIANT", 0);
+// "field_split": -1 = by the size of the launch (default), 0 = never, 1 = always
+static int g_field_split = -1;
+// One-step launches with fewer wavefronts than this take the one-field form (about four rounds of resident wavefronts).
+// tools/size_sweep.py, profiles/r04_size_sweep.txt: 1440 x 1021 x 75 (11 488 / 5 744 wavefronts at float64 / float32) gains
+// 17 % / 41 %, 2160 x 1080 (18 225 / 9 112) 2 % / 8 %, 3600 x 1800 (50 656 / 25 312) loses 2 %
+constexpr long kFieldSplitWaves = 20000;
 static long g_tuning_version = 0;
 long tuning_version() { return g_tuning_version; }
 int tuning_set(const char *name, int value)
@@ -359,6 +477,7 @@ int tuning_set(const char *name, int value)
     ++g_tuning_version;  // captured graphs bake the variant in
     if (!strcmp(name, "xcd_map")) g_xcd_map = value;
     else if (!strcmp(name, "flux_variant")) g_variant = value;
+    else if (!strcmp(name, "field_split")) g_field_split = value;
 #ifdef NF_TUNING_BUILD
     else if (!strcmp(name, "ww_blocks_per_cu")) g_pipe_waves = value;
 #endif
@@ -381,6 +500,33 @@ static int launch_flux_t(const FluxArgs &a, hipStream_t s)
     return NF_OK;
 }
 
+template <typename T, int VEC, int UZ, bool SIGNED_ONLY, bool TWO_FILLS>
+static int launch_flux_field_t(const FluxArgs &a, hipStream_t s)
+{
+    const long per_tile = 256l * VEC;
+    const unsigned ntiles = (unsigned)((a.ncell + per_tile - 1) / per_tile);
+    const int xcd_map = g_xcd_map;
+    const unsigned grid = xcd_map ? xcd_grid(ntiles) : ntiles;
+    hipLaunchKernelGGL((k_flux_field<T, VEC, UZ, SIGNED_ONLY, TWO_FILLS>), dim3(grid, (unsigned)(a.batch.zr ? a.batch.nsteps : 1), 2),
+                       dim3(256), 0, s, (const T *)a.u, (const T *)a.v, a.ncell, (unsigned)a.ny, (unsigned)a.nx, a.z0, a.z1,
+                       a.thickness, a.arcE, a.arcN, (T)a.fill, a.scale, a.sverdrup, a.iV, a.absU, a.maxbits, ntiles, xcd_map,
+                       a.batch, (T)a.fill2);
+    NF_HIP(hipGetLastError());
+    return NF_OK;
+}
+
+// the one-field-per-wavefront form (k_flux_field).  signed_only: the caller wants planes 1 and 2 only (compact mode, partial
+// steps of a sharded run)
+template <typename T, int VEC>
+static int launch_flux_field(const FluxArgs &a, hipStream_t s)
+{
+    constexpr int kLevels = sizeof(T) == 8 ? 10 : 16;      // one field per wave: as many bytes in flight as the two-field batch
+    const bool two = (T)a.fill2 == (T)a.fill2 && !((T)a.fill2 == (T)a.fill);
+    if (a.signed_only)
+        return two ? launch_flux_field_t<T, VEC, kLevels, true, true>(a, s) : launch_flux_field_t<T, VEC, kLevels, true, false>(a, s);
+    return two ? launch_flux_field_t<T, VEC, kLevels, false, true>(a, s) : launch_flux_field_t<T, VEC, kLevels, false, false>(a, s);
+}
+
 // Store form of the vector path (NF_FLUX_VARIANT / nf_tuning_set("flux_variant")): 0 = the per-dtype default, 5 = the other
 // one; same bits either way (tests/test_gpu_configs.py).  Any other number runs the default kernel in the shipped library;
 // the measured alternatives of the load loop exist only in the tuning build (`make tuning`), where the same test checks them.
@@ -388,6 +534,11 @@ template <typename T, int VEC>
 static int launch_flux_v(const FluxArgs &a, hipStream_t s)
 {
     const int variant = a.batch.zr ? 0 : g_variant;  // the multi-step launch exists for the default kernel only
+    if (variant == 0) {   // few wavefronts (one time step of a mid-size or small grid): one field per wavefront
+        const long waves = (a.ncell / VEC + kWave - 1) / kWave;
+        const bool split = g_field_split < 0 ? (!a.batch.zr && waves < kFieldSplitWaves) : g_field_split != 0;
+        if (split) return launch_flux_field<T, VEC>(a, s);
+    }
     // a second missing value (compared in the file's dtype, like the first): the default kernels with one more compare
     const bool two = (T)a.fill2 == (T)a.fill2 && !((T)a.fill2 == (T)a.fill);
     if (a.signed_only) {  // compact resident mode: the caller expands on demand

@@ -323,6 +323,46 @@ def test_partial_steps_skip_the_derived_planes_bit_identical():
         assert numpy.array_equal(part.integratedVelocity, ref.integratedVelocity)
 
 
+@pytest.mark.parametrize('real', ['float64', 'float32'])
+def test_field_split_bit_identical(real):
+    """K1's launch shape for grids of a few wave-rounds (k_flux_field: uo and vo of a cell integrated by different
+    wavefronts; eU depends on uo only, eV on vo only) against the two-field kernel: every plane, the |.| arrays, the running
+    max and the rows bit for bit -- per-step and all-steps-in-one-launch, odd shapes (one cell per
+    lane), Sverdrup units, land (NaN / 1e20 / a second marker), compact mode and partial steps of a sharded range."""
+    from nemoflux_amd._lib import lib, check
+    cases = [(72, 36, 7, 3, {}), (35, 18, 5, 2, {}), (2, 1, 11, 1, {}), (36, 18, 4, 2, {'sverdrup': True}),
+             (72, 36, 7, 3, {'compact': True}), (72, 36, 7, 4, {'slab_range': (3, 24)})]
+    tr = [transect_xyz(T_OPEN50), transect_xyz(T_TRI50)]
+    for nx, ny, nz, nt, kw in cases:
+        dg = device_case(nx, ny, nz, nt, PSI_ZT, real=real)
+        u, v = dg.u.clone(), dg.v.clone()
+        if nx >= 36:
+            u[:, 1:3, 4:9, 10:20] = float('nan')
+            v[:, 1:3, 4:9, 10:20] = 1.e20
+            u[:, 0, 2:5, 3:8] = -999.
+        args = (dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, u, v, tr if nx >= 36 else [])
+        kw = dict(kw, fill_value=1.e20, missing_value=-999.)
+        out = {}
+        try:
+            for batch in (0, 1):
+                for fs in (0, 1):
+                    check(lib.nf_tuning_set(b'batch_steps', batch))
+                    check(lib.nf_tuning_set(b'field_split', fs))
+                    f = quiet_field(*args, **kw)
+                    tot, segs = f.computeAll()
+                    t = nt - 1 if 'slab_range' not in kw else kw['slab_range'][0] // nz
+                    f.computeFlux(t, readback=True)
+                    out[(batch, fs)] = (tot, segs, f.integratedVelocity.copy(), f.edgeFluxesUArray.copy(),
+                                        f.edgeFluxesVArray.copy(), f.maxAbsFlux)
+        finally:
+            check(lib.nf_tuning_set(b'field_split', -1))
+            check(lib.nf_tuning_set(b'batch_steps', 1))
+        ref = out[(0, 0)]
+        for key, got in out.items():
+            for a, b in zip(ref, got):
+                assert numpy.array_equal(a, b, equal_nan=True), (nx, ny, kw, key)
+
+
 def test_transect_edge_cases(oracle):
     """outside the grid -> no weights; regional (non-periodic) grid; counterclock flips edges 2,3; a polyline that
     runs along grid lines only (every sub-segment shared by two cells); repeated points (zero-length segments drop out)."""
@@ -887,15 +927,24 @@ def test_compact_resident_mode_is_bit_identical(real, nx, ny):
 def test_kernel_timing_split(real):
     """nf_field_timing_read / nf_field_timing_split: one timed entry per flux launch; float64 runs the fused store form
     (no expansion kernel), float32 the split one (flux kernel + expansion), and the shares add up to the total."""
+    from nemoflux_amd._lib import lib, check
     dg = device_case(360, 180, 6, 3, PSI_ZT, real=real)
     fld = quiet_field(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, [transect_xyz(T_OPEN)], readback=False)
-    fld.enableKernelTiming(True)
-    for t in range(3):
+    try:
+        check(lib.nf_tuning_set(b'field_split', 0))     # the two-field kernels of the headline grid, whatever the grid size
+        fld.enableKernelTiming(True)
+        for t in range(3):
+            fld.computeFlux(t)
+        n, total, flux, expand = fld.readKernelTiming(split=True)
+        assert n == 3 and total > 0 and flux > 0 and abs(flux + expand - total) <= 1e-6 * total + 1e-9
+        assert (expand == 0.0) == (real == 'float64')
+        assert fld.readKernelTiming() == (0, 0.0)          # reading resets
+    finally:
+        check(lib.nf_tuning_set(b'field_split', -1))
+    for t in range(3):                                  # a grid of this size runs the one-field form: one kernel per step
         fld.computeFlux(t)
     n, total, flux, expand = fld.readKernelTiming(split=True)
-    assert n == 3 and total > 0 and flux > 0 and abs(flux + expand - total) <= 1e-6 * total + 1e-9
-    assert (expand == 0.0) == (real == 'float64')
-    assert fld.readKernelTiming() == (0, 0.0)          # reading resets
+    assert n == 3 and expand == 0.0 and abs(flux - total) <= 1e-6 * total + 1e-9
     fld.enableKernelTiming(False)
 
 
