@@ -118,12 +118,16 @@ int main(void)
     printf("ingest: decoded %.1f (status %d)\n", decoded, status);
 
     /* ---- the multi-GPU collective from plain C: a one-rank communicator (all one GPU can form), the row summed in place.
-     * With N ranks: rank 0 makes the id, hands it to the others (MPI, a file, a socket), every rank calls comm_init. */
+     * With N ranks: every rank runs the non-collective preflight, the ranks agree that all of them passed (MPI_Allreduce
+     * MIN, say), rank 0 makes the id and hands it to the others (MPI, a file, a socket), and only then does every rank call
+     * comm_init -- ncclCommInitRank is collective, a rank that failed earlier would leave the others waiting inside it. */
     char id[NF_RCCL_UNIQUE_ID_BYTES];
     void *comm = NULL, *row_dev = NULL;
     int nranks = -1, myrank = -1, dev = -1;
     double reduced[3] = {0, 0, 0};
     const double part[3] = {1.5, -2.0, 360.0};
+    int pre_dev = -1;
+    CHECK(nf_rccl_preflight(&pre_dev));
     CHECK(nf_rccl_unique_id(id));
     CHECK(nf_rccl_comm_init(&comm, 1, id, 0));
     CHECK(nf_rccl_comm_info(comm, &nranks, &myrank, &dev));
