@@ -265,6 +265,7 @@ def main():
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--no-f32', action='store_true', help='skip the float32 sub-record (N=1, --dtype f64 only)')
     ap.add_argument('--no-ingest', action='store_true', help='skip the file-ingest sub-record (N=1)')
+    ap.add_argument('--no-c3', action='store_true', help='skip the ORCA025-like C3 sub-record (N=1)')
     ap.add_argument('--dump-totals', action='store_true', help='add the (nt, ntransect) totals to the JSON (small grids)')
     ap.add_argument('--emulate-rank', default=None, metavar='r/N',
                     help='NOT a scaling run: on ONE GPU, do exactly what rank r of an N-rank strong-scaling run does (its slab '
@@ -299,7 +300,7 @@ def main():
         if world != 1 or args.scaling != 'strong' or not (0 <= r < n):
             raise SystemExit('bench.py: --emulate-rank r/N needs --gpus 1, strong scaling and 0 <= r < N')
         emulate = (r, n)
-        args.no_cpu = args.no_f32 = args.no_ingest = True
+        args.no_cpu = args.no_f32 = args.no_ingest = args.no_c3 = True
     m = run_workload(args, args.dtype, args.scaling, rank, world, local, want_totals=args.dump_totals, emulate=emulate)
     slabs = m['nt_global'] * nz
     out = {
@@ -355,11 +356,73 @@ def main():
             out['ingest'] = ingest_record()
         except Exception as e:      # never costs the headline line
             out['ingest'] = {'error': f'{type(e).__name__}: {e}'}
+    # ---- BASELINE config C3 (ORCA025-like, one time step) beside the headline: the mid-size grid most real files have
+    if world == 1 and not args.no_c3 and not emulate:
+        try:
+            out['c3'] = c3_record()
+        except Exception as e:
+            out['c3'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         nfdist.destroy_native_comms()
         dist.destroy_process_group()
+
+
+def c3_record(steps=20):
+    """BASELINE config C3 beside the headline (N=1): the ORCA025-like 1440 x 1021 x 75 grid, ONE time step, the 50-station
+    transect data/S3_sta_bdep.txt (tests/golden/stations.json holds the reference's own parse of it), float64 and float32.
+    A step of this grid is only 2.2 / 1.1 rounds of resident wavefronts, so K1 runs in its one-field form
+    (nf::k_flux_field, DESIGN.md section 4); same events, same algorithmic bytes per unit as the headline."""
+    import contextlib
+    import ctypes
+    import io
+    import torch
+    from nemoflux_amd._lib import lib, check
+    from nemoflux_amd.datagen import DataGen, STREAM_FUNCTIONS
+    from nemoflux_amd.field import Field
+    nx, ny, nz = 1440, 1021, 75
+    with open(os.path.join(ROOT, 'tests', 'golden', 'stations.json')) as f:
+        st = json.load(f)['S3_sta_bdep.txt']
+    xyz = numpy.array([(lon, lat, 0.) for lon, lat in st])
+    out = {'workload': f'C3 ORCA025-like {nx}x{ny}x{nz}x1, psi={STREAM_FUNCTIONS[2]}, transect S3_sta_bdep.txt ({len(st)} stations), '
+                       f'{steps} timed steps'}
+    for dtype, real, es in (('f64', 'float64', 8), ('f32', 'float32', 4)):
+        dg = DataGen(real=real)
+        dg.setSizes(nx, ny, nz, 1)
+        dg.setBoundingBox(-180., 180., -90., 90., 0., 1.)
+        dg.build()
+        dg.applyStreamFunction(STREAM_FUNCTIONS[2])
+        u, v = dg.computeUVFromPotential()
+        with contextlib.redirect_stdout(io.StringIO()):
+            fld = Field.fromArrays(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, u, v, [xyz], readback=False,
+                                   stream=torch.cuda.current_stream().cuda_stream)
+        rows = torch.zeros((1, fld._rowlen), dtype=torch.float64, device='cuda')
+        for _ in range(3):
+            check(lib.nf_field_compute_all_async(ctypes.byref(fld._h), ctypes.c_void_p(rows.data_ptr())))
+        fld.enableKernelTiming(True, reserve=steps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            check(lib.nf_field_compute_all_async(ctypes.byref(fld._h), ctypes.c_void_p(rows.data_ptr())))
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps
+        nl, kms, flux_ms, expand_ms = fld.readKernelTiming(split=True)
+        k3 = fld.readTransectTiming()
+        fld.enableKernelTiming(False)
+        units = float(nz) * ny * nx
+        bpu = 2 * es + 64.0 / nz
+        k1 = kms / max(1, nl)
+        out[dtype] = {'value': units / wall, 'unit': 'integrals/s', 'ms_per_step': round(wall * 1e3, 4),
+                      'k1_ms': round(k1, 4), 'k3_ms': round(k3 / max(1, nl), 4),
+                      'frac': round(bpu * units / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      'wall_frac': round(bpu * units / wall / 1e9 / HBM_PEAK_GBS, 4),
+                      'algorithmic_bytes_per_unit': round(bpu, 3),
+                      'kernel': 'nf::k_flux_field' if expand_ms == 0 else 'nf::k_flux + nf::k_expand_planes',
+                      'flux': float(rows[0, -1].item())}
+        del fld, dg, u, v
+        torch.cuda.empty_cache()
+    return out
 
 
 def ingest_record(streams=256):

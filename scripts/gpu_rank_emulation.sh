@@ -9,7 +9,7 @@ R=${1:-r04}
 O=gpurun_out/$R
 mkdir -p $O
 : > $O/rank_emulation.jsonl
-python bench.py --no-cpu --no-f32 --no-ingest --steps 20 --warmup 3 > $O/emu_n1.json 2> $O/emu_n1.err
+python bench.py --no-cpu --no-f32 --no-ingest --no-c3 --steps 20 --warmup 3 > $O/emu_n1.json 2> $O/emu_n1.err
 for N in 2 4 8; do
   for r in $(seq 0 $((N-1))); do
     python bench.py --emulate-rank $r/$N --steps 20 --warmup 3 >> $O/rank_emulation.jsonl 2>> $O/emu.err

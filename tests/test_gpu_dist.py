@@ -155,7 +155,7 @@ def _bench_json(extra, nproc=1, launcher='torchrun', env_extra=None, with_stderr
     import json
     import subprocess
     small = ['--nx', '144', '--ny', '72', '--nz', '9', '--batch', '6', '--steps', '2', '--warmup', '1', '--no-cpu',
-             '--no-f32', '--no-ingest', '--dump-totals'] + extra
+             '--no-f32', '--no-ingest', '--no-c3', '--dump-totals'] + extra
     env = dict(os.environ)
     if nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + small
