@@ -59,6 +59,17 @@ __device__ inline bool quad_is_nonconvex(const double *v)
     if (npole == 1 || npole == 3) return true;
     if (npole == 2 && !(fabs(v[2 * ((first + 1) & 3) + 1]) >= 90.0 - 1.e-9 || (first == 0 && fabs(v[2 * 3 + 1]) >= 90.0 - 1.e-9)))
         return true;   // opposite corners
+    // a geographic pole INSIDE the cell (a rotated grid whose pole is not a mesh node): going round the four corners the
+    // longitude winds once around the globe -- the differences, each taken the short way, add up to +-360 instead of 0 --
+    // and the planar quad is a sliver along the pole line, not the image of the cell
+    double turn = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double d = v[2 * ((k + 1) & 3)] - v[2 * k];
+        d -= 360.0 * rint(d / 360.0);
+        turn += d;
+    }
+    if (fabs(turn) > 180.0) return true;
     double cmin = 0.0, cmax = 0.0, scale = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -628,7 +628,7 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
         const int kind = (int)((w >> 24) & 0xff), seg = (int)(w & 0xffffff);
         snprintf(buf, sizeof buf,
                  kind == 1 ? "computeWeights: target segment %d crosses cell %ld, which is not convex in the (lon,lat) plane "
-                             "(a reflex corner or a bow-tie, e.g. a cell touching the pole of a rotated grid): the weights "
+                             "(a reflex corner or a bow-tie, e.g. a cell touching the pole of a rotated grid, or a cell that contains the pole): the weights "
                              "are not defined there (setUnsupportedCells('skip') drops such cells instead: coverage < 1)"
                            : "computeWeights: target segment %d: the inverse bilinear map did not converge in cell %ld",
                  seg, cell);

@@ -244,6 +244,15 @@ static int quad_is_nonconvex(const double *v)
     if (npole == 1 || npole == 3) return 1;
     if (npole == 2 && !(fabs(v[2 * ((first + 1) & 3) + 1]) >= 90.0 - 1.e-9 ||
                         (first == 0 && fabs(v[2 * 3 + 1]) >= 90.0 - 1.e-9))) return 1;   /* opposite corners */
+    /* a geographic pole INSIDE the cell (rotated grid whose pole is not a mesh node): the longitude winds once around the
+     * globe going round the corners -- the differences, each taken the short way, add up to +-360 instead of 0 */
+    double turn = 0.0;
+    for (int k = 0; k < 4; ++k) {
+        double d = v[2 * ((k + 1) & 3)] - v[2 * k];
+        d -= 360.0 * rint(d / 360.0);
+        turn += d;
+    }
+    if (fabs(turn) > 180.0) return 1;
     double cmin = 0.0, cmax = 0.0, scale = 0.0;
     for (int k = 0; k < 4; ++k) {
         int k1 = (k + 1) & 3, k2 = (k + 2) & 3;
