@@ -1576,3 +1576,16 @@ def test_weights_and_point_location_fuzz_against_oracle():
     stats, kinds = fuzz_weights.run(400, 20260405, verbose=False)
     assert stats['ok'] > 1400 and stats['points'] == 6400
     assert all(k[1] == 'rotated' for k in kinds)        # refusals only where a geographic pole meets the mesh
+
+
+def test_flux_kernels_fuzz_against_oracle():
+    """tools/fuzz_flux.py, 150 random cases: shapes 1..70 x 1..40 x 1..23 x 1..4 (odd / even cell counts, rows ending inside
+    a lane's cells), float64 / float32, NaN + _FillValue + a second marker, Sverdrup units, compact mode, host-staged or
+    resident fields, sharded slab ranges, per-step launches or one launch for all steps, the one-field form of K1 forced on,
+    off or chosen by size: all six planes' worth of output and the running max bit-identical to the CPU oracle.  (1 500 cases
+    were run once in round 4: profiles/r04_fuzz_flux.txt.)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import fuzz_flux
+    forms = fuzz_flux.run(150, 20260406, verbose=False)
+    assert sum(forms.values()) == 150 and len(forms) >= 20
