@@ -152,7 +152,7 @@ def test_device_inflate_more_streams_than_resident_wavefronts(decoder):
             f = (numpy.cumsum(rng.standard_normal(size // 4)) * 1e-2).astype('<f4')
             d = numpy.ascontiguousarray(f.view(numpy.uint8).reshape(-1, 4).T).reshape(-1)
         else:
-            d = numpy.tile(rng.integers(0, 256, int(rng.integers(1, 3000)), dtype=numpy.uint8), size)[:size]
+            d = numpy.resize(rng.integers(0, 256, int(rng.integers(1, 3000)), dtype=numpy.uint8), size)   # cyclic fill (numpy.tile(...)[:size] would keep size x period bytes alive per stream)
         d = numpy.ascontiguousarray(d[:size])
         co = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, 15, 8,
                               [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_FIXED][int(rng.integers(0, 4))])
@@ -161,3 +161,21 @@ def test_device_inflate_more_streams_than_resident_wavefronts(decoder):
     out = decoder.decode_streams(streams, size)
     for i in range(n):
         assert numpy.array_equal(out[i], datas[i]), i
+
+
+def test_far_path_on_the_device():
+    """The shipped decoder keeps DEFLATE's whole 32 KiB window in LDS, so its FAR path (a match source that has already been
+    flushed to HBM) never runs on a GPU -- it would with a smaller window.  To keep that path trustworthy (round-3 advisor)
+    the library is built here with -DNFI_WINDOW=8192 (`make window8k`: one object, seconds; test-only, never loaded by the
+    package) and decodes capacity + 200 streams, a third of them made of matches 9 000 .. 30 000 bytes back, against zlib."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    subprocess.check_call(['make', '-C', os.path.join(ROOT, 'nemoflux_amd', 'csrc'), 'window8k', '-s'])
+    lib = os.path.join(ROOT, 'build', 'window8k', 'libnemoflux_amd_w8k.so')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_inflate_window.py')], env=dict(os.environ, NEMOFLUX_AMD_LIB=lib),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'bit-identical' in r.stdout and 'libnemoflux_amd_w8k.so' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    cap = int(r.stdout.split('capacity ')[1].split(')')[0])
+    assert cap > 2000            # ten streams per CU with the 8 KiB window (the shipped build: 1024)

@@ -149,8 +149,9 @@ def test_more_megabyte_streams_than_resident_wavefronts():
     repeats with periods of 9 000 .. 30 000 bytes (long-distance matches: the copy's source wraps around the window ring)
     -- late workgroups start while early ones are mid-stream.  The shipped library is built with NFI_WINDOW = 32768 = the
     format's maximum distance (4 streams per CU, capacity 1024), so on the device every match source lies INSIDE the LDS
-    window: the decoder's far path (sources already flushed to HBM, which a smaller window needs) never runs on a GPU; it is
-    covered by the host build of tests/test_inflate_cpu.py with -DNFI_WINDOW=8192 only."""
+    window: the decoder's far path (sources already flushed to HBM, which a smaller window needs) is not taken here; it is
+    covered by the host build of tests/test_inflate_cpu.py with -DNFI_WINDOW=8192 and, on the device, by the test-only 8 KiB
+    build of tests/test_gpu_inflate.py::test_far_path_on_the_device."""
     from nemoflux_amd.ingest import ChunkDecoder
     dec = ChunkDecoder()
     cap = dec.capacity()
