@@ -97,13 +97,20 @@ int mnt_polylineintegral_del(PolylineIntegral_t **self);
 int mnt_polylineintegral_setGrid(PolylineIntegral_t **self, Grid_t *grid);
 /* .buildLocator(numCellsPerBucket=128, periodX=360., enableFolding=False)   field.py:47
  * numCellsPerBucket sets the cull-tile size (rounded to the 64-cell wavefront tile); enableFolding != 0
- * is rejected (nemoflux never enables it). */
+ * is rejected (nemoflux never enables it).  periodX > 0: target lines are also tried one period to the west and to the east,
+ * and every cell's corners are brought to within periodX/2 of its corner 0 before the cell is used (a global file stores
+ * bounds_lon wrapped into one period, so the cells on the cut have corners ~355 degrees apart: datagen.py:161-166 is the
+ * reference's own form of this rule); the grid's points themselves are not touched. */
 int mnt_polylineintegral_buildLocator(PolylineIntegral_t **self, int numCellsPerBucket, double periodX,
                                       int enableFolding);
 /* .computeWeights(xyz (npoints,3), counterclock=False)   field.py:48
  * NF_ERR_ARG (with the cell id in nf_last_error) when a target segment overlaps, over a positive length, a cell the
- * weights are not defined on: a quad that is not convex in the (lon,lat) plane, or one with a corner AT a geographic
- * pole (the cells around the pole of a rotated grid) -- never a silent number. */
+ * weights are not defined on: a quad that is not convex in the (lon,lat) plane, one with a corner AT a geographic
+ * pole (the cells around the pole of a rotated grid) or one that CONTAINS a pole -- never a silent number.  NF_ERR_ARG naming
+ * the segment, too, when some stretch of a target segment lies in two cells that do not hold the same sub-segment (coverage
+ * > 1 + 1e-8: overlapping cells, e.g. a date-line-wrapped grid with periodX = 0): that stretch would be counted twice.
+ * mnt_polylineintegral_getCoverage still answers after that error.  Cells with a corner that is not a finite number take
+ * part in nothing. */
 int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, const double xyz[],
                                         int counterclock);
 /* extension (not in mint): what computeWeights does with such a cell.  skip = 0 (default): the error above.  skip = 1:
@@ -118,8 +125,8 @@ int mnt_polylineintegral_getIntegral(PolylineIntegral_t **self, const double dat
 /* extensions (not in mint): device-resident data, per-target-segment sums, weight read-back */
 int mnt_polylineintegral_getIntegralDev(PolylineIntegral_t **self, const double *data_dev, int placement,
                                         double *result, double *seg_totals_host /* nseg or NULL */);
-/* coverage[s] = fraction of target segment s that lies inside cells of the grid (1 = inside, counted once); see
- * nf_field_get_coverage.  npoints-1 values. */
+/* coverage[s] = fraction of target segment s that lies inside cells of the grid (1 = inside, counted once; < 1 = part of it
+ * lies in no cell and contributes nothing; > 1 is refused by computeWeights); see nf_field_get_coverage.  npoints-1 values. */
 int mnt_polylineintegral_getCoverage(PolylineIntegral_t **self, double *coverage);
 int mnt_polylineintegral_getNumberOfWeights(PolylineIntegral_t **self, size_t *n);
 int mnt_polylineintegral_getWeights(PolylineIntegral_t **self, int64_t *cell_edge, double *weight, int *seg);
