@@ -266,6 +266,7 @@ def main():
     ap.add_argument('--no-f32', action='store_true', help='skip the float32 sub-record (N=1, --dtype f64 only)')
     ap.add_argument('--no-ingest', action='store_true', help='skip the file-ingest sub-record (N=1)')
     ap.add_argument('--no-c3', action='store_true', help='skip the ORCA025-like C3 sub-record (N=1)')
+    ap.add_argument('--only-c3', action='store_true', help='print the C3 sub-record alone (for profiling it: scripts/gpu_profile.sh)')
     ap.add_argument('--dump-totals', action='store_true', help='add the (nt, ntransect) totals to the JSON (small grids)')
     ap.add_argument('--emulate-rank', default=None, metavar='r/N',
                     help='NOT a scaling run: on ONE GPU, do exactly what rank r of an N-rank strong-scaling run does (its slab '
@@ -293,6 +294,11 @@ def main():
         raise SystemExit('bench.py needs an MI355X: nemoflux_amd has no CPU fallback')
     torch.cuda.set_device(local)
 
+    if args.only_c3:
+        if world != 1:
+            raise SystemExit('bench.py: --only-c3 needs --gpus 1')
+        print(json.dumps({'c3': c3_record(args.steps)}))
+        return
     nx, ny, nz = args.nx, args.ny, args.nz
     emulate = None
     if args.emulate_rank:

@@ -180,6 +180,23 @@ for sub in ('k_flux<double', 'k_flux<float', 'k_expand_planes', 'k_gather_segsca
     r = stat(sub)
     if r:
         lines.append(f"| `{r['kernel'][:70]}` | {r['calls']} | {r['avg_ns'] / 1e6:.4f} |")
+# BASELINE config C3 beside the headline: its own trace pass (bench.py --only-c3), events against the CSV
+c3_csv = find('c3_trace', '*kernel_stats.csv')
+c3_json = os.path.join(src, 'bench_c3.json')
+if c3_csv and os.path.exists(c3_json):
+    with open(c3_json) as f:
+        c3 = json.loads([l for l in f if l.startswith('{')][0])['c3']
+    with open(c3_csv) as f:
+        c3rows = {short(r['Name']): r for r in csv.DictReader(f)}
+    lines.append('')
+    lines.append('| kernel (`bench.py --only-c3 --steps 20`: 1440 x 1021 x 75, one time step) | calls | avg ms (CSV) | HIP events in that run | frac of 8 TB/s (CSV) |')
+    lines.append('|---|---|---|---|---|')
+    for dtype, key in (('f64', 'k_flux_field<double'), ('f32', 'k_flux_field<float')):
+        hit = [r for n, r in c3rows.items() if key in n]
+        if hit and dtype in c3:
+            t = float(hit[0]['AverageNs']) / 1e6
+            alg = c3[dtype]['algorithmic_bytes_per_unit'] * 75 * 1021 * 1440
+            lines.append(f"| `nf::{key}, ...>` | {hit[0]['Calls']} | {t:.4f} | {c3[dtype]['k1_ms']:.4f} | {alg / (t * 1e-3) / 8e12:.4f} |")
 lines.append('')
 for dtype, roof in legs:
     s_ = 8 if dtype == 'f64' else 4
