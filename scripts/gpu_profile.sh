@@ -10,7 +10,9 @@ mkdir -p gpurun_out/$R
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu --no-c3 > gpurun_out/$R/bench_trace.json 2> gpurun_out/$R/bench_trace.err
 echo "trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/c3_trace -- python3 bench.py --only-c3 --steps 20 > gpurun_out/$R/bench_c3.json 2> gpurun_out/$R/bench_c3.err
-echo "c3 trace done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/c3_fetch -- python3 bench.py --only-c3 --steps 5 > /dev/null 2> gpurun_out/$R/bench_c3_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/c3_write -- python3 bench.py --only-c3 --steps 5 > /dev/null 2> gpurun_out/$R/bench_c3_write.err
+echo "c3 passes done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-c3 > gpurun_out/$R/bench_fetch.json 2> gpurun_out/$R/bench_fetch.err
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-c3 > gpurun_out/$R/bench_write.json 2> gpurun_out/$R/bench_write.err

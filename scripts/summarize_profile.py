@@ -92,6 +92,17 @@ for dtype, roof in legs:
                     hbm_bytes_per_launch=hbm,
                     algorithmic_bytes_per_launch=roof['algorithmic_bytes_per_unit'] * c['nz'] * c['ny'] * c['nx'])
 
+# ---- BASELINE config C3 (bench.py --only-c3): the one-field flux kernel, counters from its own two passes
+for dtype, kname, es in (('f64', 'k_flux_field<double', 8), ('f32', 'k_flux_field<float', 4)):
+    fetch, write = counter('c3_fetch', 'FETCH_SIZE', kname), counter('c3_write', 'WRITE_SIZE', kname)
+    if fetch and write:
+        f_kb, w_kb = sum(fetch) / len(fetch), sum(write) / len(write)
+        res[f'1440x1021x75x1_{dtype}'] = dict(kernel='nf::k_flux_field', launches_sampled=[len(fetch), len(write)],
+                                             FETCH_SIZE_KiB_avg=f_kb, WRITE_SIZE_KiB_avg=w_kb,
+                                             fetch_correction='x2 (gfx950, 16 B/lane coalesced stream)',
+                                             hbm_bytes_per_launch=2.0 * f_kb * 1024 + w_kb * 1024,
+                                             algorithmic_bytes_per_launch=(2 * es + 64.0 / 75) * 75 * 1021 * 1440)
+
 # ---- K3 (nf::k_gather_segscan: both dtypes' passes share it): measured bytes against the algorithmic 80 B per record
 # (40 B of record + 4 x 8 B gathered + 8 B out).  The record stream is read 16 B per lane (counted at half by FETCH_SIZE on
 # gfx950), the gathers are 8-B accesses that pull whole 64-B requests (counted in full): the true figure lies between the
@@ -189,14 +200,16 @@ if c3_csv and os.path.exists(c3_json):
     with open(c3_csv) as f:
         c3rows = {short(r['Name']): r for r in csv.DictReader(f)}
     lines.append('')
-    lines.append('| kernel (`bench.py --only-c3 --steps 20`: 1440 x 1021 x 75, one time step) | calls | avg ms (CSV) | HIP events in that run | frac of 8 TB/s (CSV) |')
-    lines.append('|---|---|---|---|---|')
+    lines.append('| kernel (`bench.py --only-c3 --steps 20`: 1440 x 1021 x 75, one time step) | calls | avg ms (CSV) | HIP events in that run | frac of 8 TB/s (CSV) | HBM traffic (two --pmc passes) |')
+    lines.append('|---|---|---|---|---|---|')
     for dtype, key in (('f64', 'k_flux_field<double'), ('f32', 'k_flux_field<float')):
         hit = [r for n, r in c3rows.items() if key in n]
         if hit and dtype in c3:
             t = float(hit[0]['AverageNs']) / 1e6
             alg = c3[dtype]['algorithmic_bytes_per_unit'] * 75 * 1021 * 1440
-            lines.append(f"| `nf::{key}, ...>` | {hit[0]['Calls']} | {t:.4f} | {c3[dtype]['k1_ms']:.4f} | {alg / (t * 1e-3) / 8e12:.4f} |")
+            pm = res.get(f'1440x1021x75x1_{dtype}', {}).get('hbm_bytes_per_launch')
+            lines.append(f"| `nf::{key}, ...>` | {hit[0]['Calls']} | {t:.4f} | {c3[dtype]['k1_ms']:.4f} | {alg / (t * 1e-3) / 8e12:.4f} |" +
+                         (f" {pm / 1e9:.4f} GB vs {alg / 1e9:.4f} GB algorithmic ({pm / alg:.3f}) |" if pm else ' |'))
 lines.append('')
 for dtype, roof in legs:
     s_ = 8 if dtype == 'f64' else 4
