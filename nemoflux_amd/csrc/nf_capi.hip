@@ -98,7 +98,7 @@ static void dev_free(T *&p)
 using namespace nf;
 
 // 1 = compute_all may put all time steps of a small grid into one launch per kernel ("batch_steps" tuning knob)
-static int g_batch_steps = (getenv("NF_BATCH_STEPS") && atoi(getenv("NF_BATCH_STEPS")) == 0) ? 0 : 1;
+static int g_batch_steps = 1;
 
 // =============================================================================================== plumbing
 extern "C" {

@@ -456,14 +456,9 @@ int launch_expand_planes(double *iV, double *absUV, long ncell, long ny, long nx
     return NF_OK;
 }
 
-static int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-// tuning knobs: environment at first use, nf_tuning_set() at run time (A/B runs inside one process)
-static int g_xcd_map = env_int("NF_XCD_MAP", 1);
-static int g_variant = env_int("NF_FLUX_VARIANT", 0);
+// tuning knobs: nf_tuning_set() at run time (A/B runs inside one process)
+static int g_xcd_map = 1;
+static int g_variant = 0;
 // "field_split": -1 = by the size of the launch (default), 0 = never, 1 = always
 static int g_field_split = -1;
 // One-step launches with fewer wavefronts than this take the one-field form (about four rounds of resident wavefronts).
@@ -527,7 +522,7 @@ static int launch_flux_field(const FluxArgs &a, hipStream_t s)
     return two ? launch_flux_field_t<T, VEC, kLevels, false, true>(a, s) : launch_flux_field_t<T, VEC, kLevels, false, false>(a, s);
 }
 
-// Store form of the vector path (NF_FLUX_VARIANT / nf_tuning_set("flux_variant")): 0 = the per-dtype default, 5 = the other
+// Store form of the vector path (nf_tuning_set("flux_variant")): 0 = the per-dtype default, 5 = the other
 // one; same bits either way (tests/test_gpu_configs.py).  Any other number runs the default kernel in the shipped library;
 // the measured alternatives of the load loop exist only in the tuning build (`make tuning`), where the same test checks them.
 template <typename T, int VEC>
