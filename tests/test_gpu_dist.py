@@ -223,6 +223,28 @@ def test_bench_start_up_fails_soft_when_a_rank_cannot_join_rccl():
     assert 'rehearsal on the gloo backend' in err and two['reduce']['path'] == 'torch.distributed.all_reduce'
 
 
+def test_bench_emulates_one_rank_of_n():
+    """`bench.py --emulate-rank r/N` (per-rank compute evidence for N > 1 on a one-GPU box): one process takes rank r's slab
+    range of the strong-scaling cut, runs its launches without a reduce and says so in the line; the partial rows of all N
+    emulated ranks add up to the N = 1 totals."""
+    from nemoflux_amd.dist import slab_range
+    nt, n = 3, 4
+    one = _bench_json(['--nt', str(nt)])
+    acc = None
+    for r in range(n):
+        d = _bench_json(['--nt', str(nt), '--emulate-rank', f'{r}/{n}'])
+        e = d['emulated_rank']
+        assert (e['rank'], e['of']) == (r, n) and tuple(e['slabs']) == slab_range(nt, 9, r, n)
+        assert d['n_gpus'] == 1 and 'EMULATION of rank' in d['config']['workload'] and 'reduce' not in d and 'cpu_baseline' not in d
+        assert e['ms_per_pass'] > 0 and e['launches_per_pass'] >= 1
+        units = (e['slabs'][1] - e['slabs'][0]) * 144 * 72
+        assert abs(d['value'] - units / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
+        t = numpy.array(d['totals'])
+        acc = t if acc is None else acc + t
+    b = numpy.array(one['totals'])
+    assert numpy.abs(acc - b).max() <= 1e-13 * numpy.abs(b).max()
+
+
 def test_rccl_preflight_is_not_collective():
     """nf_rccl_preflight: librccl resolves and this thread has a device -- answered by one rank on its own."""
     import ctypes
