@@ -355,7 +355,8 @@ long nfo_polyline_weights(const double *points, long ncell, const double *xyz, i
                           int skip_unsupported /* 1: non-convex cells contribute nothing instead of being an error */)
 {
     long nrec = 0, rcap = 1024;
-    long err = 0, err_cell = -1, err_seg = -1;
+    long err = 0, err_cell = -1, err_seg = -1;     /* kind 1: a target segment overlaps a cell the weights are not defined on */
+    long err2_cell = -1, err2_seg = -1;             /* kind 2: the inverse bilinear map did not converge (reported only when no kind 1) */
     nfo_rec *recs = (nfo_rec *)malloc(rcap * sizeof(nfo_rec));
     int nshift = periodX > 0.0 ? 3 : 1;
     for (int s = 0; s + 1 < npts; ++s) {
@@ -397,7 +398,7 @@ long nfo_polyline_weights(const double *points, long ncell, const double *xyz, i
                 double a0, a1, b0, b1;
                 int ok = inv_bilinear(v, qx + ta * dx, qy + ta * dy, &a0, &a1);
                 ok &= inv_bilinear(v, qx + tb * dx, qy + tb * dy, &b0, &b1);
-                if (!ok && (err_cell < 0 || c < err_cell)) { err = 2; err_cell = c; err_seg = s; }
+                if (!ok && (err2_cell < 0 || c < err2_cell)) { err2_cell = c; err2_seg = s; }
                 double d0 = b0 - a0, d1 = b1 - a1;
                 double m0 = 0.5 * (a0 + b0), m1 = 0.5 * (a1 + b1);
                 if (nrec == rcap) {
@@ -419,6 +420,8 @@ long nfo_polyline_weights(const double *points, long ncell, const double *xyz, i
             }
         }
     }
+    /* the device finds kind 1 in its counting pass and stops there; kind 2 can only show in the pass that solves for xi */
+    if (!err && err2_cell >= 0) { err = 2; err_cell = err2_cell; err_seg = err2_seg; }
     if (status) { status[0] = err; status[1] = err_cell; status[2] = err_seg; }
     if (err) { free(recs); return 0; }
     qsort(recs, nrec, sizeof(nfo_rec), rec_cmp);
