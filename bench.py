@@ -490,8 +490,11 @@ def visible_gpu_count():
             raise FileNotFoundError
         n = 0
         for node in os.listdir(base):
-            with open(os.path.join(base, node, 'properties')) as f:
-                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            try:
+                with open(os.path.join(base, node, 'properties')) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            except PermissionError:
+                continue        # a GPU of the host that this container may not use (device cgroup): not ours
             if int(props.get('simd_count', '0')) > 0:
                 n += 1
     except FileNotFoundError:
