@@ -56,6 +56,8 @@ def geometry():
 
 def polyline(blon, blat, periodX):
     n = int(rng.integers(2, 9))
+    if rng.random() < 0.08:
+        n = int(rng.integers(90, 400))      # a long polyline: more than 256 segment images (several chunks of the workgroup cull)
     lo, hi = blon.min(), blon.max()
     if hi - lo > 350.:
         lo, hi = lo - 20., hi + 20.
