@@ -27,6 +27,15 @@ def slab_range(nt, nz, rank, world):
     return (rank * total) // world, ((rank + 1) * total) // world
 
 
+def slab_range_by_steps(nt, nz, rank, world):
+    """The cut for callers that want FULL-FIELD outputs per time step (integratedVelocity, the |.| arrays): whole time steps
+    per rank (balanced to within one step), so every step's planes are complete on the rank that owns it (SURVEY.md 8e:
+    "when full-field outputs are requested, shard by t").  Same (begin, end) slab convention as slab_range; with fewer steps
+    than ranks the last ranks own nothing.  The transect totals need the same single all-reduce either way."""
+    t0, t1 = (rank * nt) // world, ((rank + 1) * nt) // world
+    return t0 * nz, t1 * nz
+
+
 def time_steps_touched(srange, nz):
     """[t_begin, t_end) of the time steps that contain at least one owned slab."""
     b, e = srange

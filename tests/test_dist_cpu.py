@@ -25,6 +25,15 @@ def test_slab_ranges_partition_everything():
             tb, te = time_steps_touched((b, e), nz)
             assert (e <= b and tb == te == 0) or (tb * nz <= b and e <= te * nz)
     assert slab_range(12, 75, 3, 8) == (337, 450)
+    # the cut by whole time steps (full-field outputs per step): step boundaries only, everything covered, balanced in steps
+    from nemoflux_amd.dist import slab_range_by_steps
+    for nt, nz, world in [(12, 75, 8), (12, 75, 5), (3, 4, 8), (20, 10, 3)]:
+        cuts = [slab_range_by_steps(nt, nz, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == nt * nz and all(a[1] == b[0] for a, b in zip(cuts[:-1], cuts[1:]))
+        assert all(b % nz == 0 and e % nz == 0 for b, e in cuts)
+        steps = [(e - b) // nz for b, e in cuts]
+        assert max(steps) - min(steps) <= 1
+    assert [slab_range_by_steps(12, 75, r, 8) for r in (0, 3, 7)] == [(0, 75), (300, 450), (750, 900)]
 
 
 def _partial_rows(oracle, g, m, srange, weights):
