@@ -363,6 +363,30 @@ def test_field_split_bit_identical(real):
                 assert numpy.array_equal(a, b, equal_nan=True), (nx, ny, kw, key)
 
 
+def test_sharding_by_whole_steps_keeps_full_fields():
+    """dist.slab_range_by_steps (full-field outputs -> shard by t): a rank that owns whole time steps holds, for
+    each of them, exactly the planes, |.| arrays and rows of the un-sharded run; the ranks' rows add up to the full rows."""
+    from nemoflux_amd.dist import slab_range_by_steps
+    nz, nt, world = 7, 5, 3
+    dg = device_case(72, 36, nz, nt, PSI_ZT)
+    tr = [transect_xyz(T_OPEN), transect_xyz(T_TRI)]
+    args = (dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, dg.u, dg.v, tr)
+    full = quiet_field(*args)
+    ftot, fseg = full.computeAll()
+    acc = numpy.zeros_like(ftot)
+    for r in range(world):
+        b, e = slab_range_by_steps(nt, nz, r, world)
+        part = quiet_field(*args, slab_range=(b, e))
+        ptot, pseg = part.computeAll()
+        acc += ptot
+        for t in range(b // nz, e // nz):
+            assert numpy.array_equal(ptot[t], ftot[t]) and numpy.array_equal(pseg[t], fseg[t])
+            assert part.computeFlux(t, readback=True) == full.computeFlux(t, readback=True)
+            assert numpy.array_equal(part.integratedVelocity, full.integratedVelocity)
+            assert numpy.array_equal(part.edgeFluxesUArray, full.edgeFluxesUArray)
+    assert numpy.array_equal(acc, ftot)          # every step is owned by exactly one rank: no rounding in the sum
+
+
 def test_transect_edge_cases(oracle):
     """outside the grid -> no weights; regional (non-periodic) grid; counterclock flips edges 2,3; a polyline that
     runs along grid lines only (every sub-segment shared by two cells); repeated points (zero-length segments drop out)."""
