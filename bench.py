@@ -419,11 +419,16 @@ def c3_record(steps=20):
         units = float(nz) * ny * nx
         bpu = 2 * es + 64.0 / nz
         k1 = kms / max(1, nl)
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # two separate --pmc passes of `bench.py --only-c3`
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get(f'{nx}x{ny}x{nz}x1_{dtype}', {}).get('hbm_bytes_per_launch')
         out[dtype] = {'value': units / wall, 'unit': 'integrals/s', 'ms_per_step': round(wall * 1e3, 4),
                       'k1_ms': round(k1, 4), 'k3_ms': round(k3 / max(1, nl), 4),
                       'frac': round(bpu * units / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       'wall_frac': round(bpu * units / wall / 1e9 / HBM_PEAK_GBS, 4),
-                      'algorithmic_bytes_per_unit': round(bpu, 3),
+                      'algorithmic_bytes_per_unit': round(bpu, 3), 'traffic': traffic,
                       'kernel': 'nf::k_flux_field' if expand_ms == 0 else 'nf::k_flux + nf::k_expand_planes',
                       'flux': float(rows[0, -1].item())}
         del fld, dg, u, v
