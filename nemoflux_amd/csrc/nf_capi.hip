@@ -397,11 +397,13 @@ try {
     std::vector<double> segs;
     std::vector<int> cc;
     p->nseg = polyline_segments(xyz, npoints, counterclock, segs, cc);
-    NF_TRY(build_weights(p->grid->d_xy, p->grid->ncell, segs.data(), cc.data(), p->nseg, p->periodX, &p->ws, nullptr,
-                         p->skip_unsupported));
+    // whatever a previous computeWeights left is gone first: after a refused build getIntegral must say "computeWeights
+    // first", not launch on buffers sized for another polyline
     dev_free(p->d_tr_off);
     dev_free(p->d_scratch);
     dev_free(p->d_row);
+    NF_TRY(build_weights(p->grid->d_xy, p->grid->ncell, segs.data(), cc.data(), p->nseg, p->periodX, &p->ws, nullptr,
+                         p->skip_unsupported));
     NF_TRY(dev_alloc(&p->d_tr_off, 2));
     NF_TRY(dev_alloc(&p->d_scratch, (size_t)p->ws.nrec));
     NF_TRY(dev_alloc(&p->d_row, (size_t)p->nseg + 1));

@@ -734,9 +734,8 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
                      "are not identical), so part of the line would be counted twice", q, out->coverage[(size_t)q]);
             set_error(buf);
             std::vector<double> keep = out->coverage;
-            out->release();
-            out->nseg = nseg;
-            out->coverage.swap(keep);
+            out->release();                 // no records, no segments: nothing a later getIntegral could launch on
+            out->coverage.swap(keep);       // ... but the coverage stays readable (its size says how many segments it is for)
             return NF_ERR_ARG;
         }
     return NF_OK;

@@ -1527,6 +1527,14 @@ def test_refuses_double_counting(oracle):
         pli.computeWeights(line, counterclock=False)
     cov = pli.getCoverage()                     # still readable: says how much of every segment
     assert abs(cov[1] - 1.5) <= 1e-12 and cov[0] < 1.
+    with pytest.raises(NemofluxError, match='computeWeights first'):      # ... but there is nothing to integrate with
+        pli.getIntegral(numpy.zeros((2, 4)))
+    pli.computeWeights(numpy.array([[0.2, 0.5, 0.], [0.9, 0.5, 0.]]), counterclock=False)     # the handle stays usable
+    assert abs(pli.getIntegral(numpy.array([[0., 1., 0., 1.], [0., 0., 0., 0.]])) - 0.0) <= 1e-15
+    with pytest.raises(NemofluxError, match=r'covered 1\.5 times'):       # and a refusal after a success leaves no stale buffers
+        pli.computeWeights(line, counterclock=False)
+    with pytest.raises(NemofluxError, match='computeWeights first'):
+        pli.getIntegral(numpy.zeros((2, 4)))
     with pytest.raises(oracle.OverCovered):
         oracle.polyline_weights(pts, line, periodX=0.)
     # identical duplicates (halo columns, north-fold row): one half each, no error
