@@ -220,6 +220,7 @@ struct Grid_t {
     double *host_points = nullptr;  // borrowed (ncell,4,3)
     double *d_xy = nullptr;         // corner table (ncell,4,2)
     bool owns_xy = true;
+    long version = 0;               // bumped by every build: weights / located points of an older build are refused
 };
 
 struct PolylineIntegral_t {
@@ -232,6 +233,7 @@ struct PolylineIntegral_t {
     double *d_row = nullptr;
     double *d_stage = nullptr;  // host data staged to HBM for getIntegral
     long stage_cells = 0;
+    long grid_version = -1;     // the grid build the weights belong to
     int nseg = 0;
     int skip_unsupported = 0;   // mnt_polylineintegral_setUnsupportedCells
 };
@@ -279,6 +281,7 @@ try {
     NF_HIP(hipMemcpy(points.p, g->host_points, sizeof(double) * 12 * (size_t)ncells, hipMemcpyHostToDevice));
     NF_TRY(launch_corner_table_from_points(points.as<double>(), g->ncell, g->d_xy, nullptr));
     NF_HIP(hipDeviceSynchronize());
+    ++g->version;
     return NF_OK;
 }
 NF_API_CATCH
@@ -409,6 +412,7 @@ try {
     NF_TRY(dev_alloc(&p->d_row, (size_t)p->nseg + 1));
     const int off[2] = {0, p->nseg};
     NF_HIP(hipMemcpy(p->d_tr_off, off, sizeof off, hipMemcpyHostToDevice));
+    p->grid_version = p->grid->version;
     return NF_OK;
 }
 NF_API_CATCH
@@ -419,6 +423,8 @@ try {
     NF_REQUIRE(self && *self && data_dev && result, NF_ERR_ARG, "mnt_polylineintegral_getIntegral: null argument");
     PolylineIntegral_t *p = *self;
     NF_REQUIRE(p->d_row, NF_ERR_STATE, "mnt_polylineintegral_getIntegral: computeWeights first");
+    NF_REQUIRE(p->grid && p->grid_version == p->grid->version, NF_ERR_STATE,
+               "mnt_polylineintegral_getIntegral: the grid was rebuilt after computeWeights (the weights index the old cells): computeWeights again");
     NF_REQUIRE(placement == MNT_CELL_BY_CELL_DATA, NF_ERR_ARG,
                "mnt_polylineintegral_getIntegral: only CELL_BY_CELL_DATA is supported (field.py:102)");
     NF_NEED_DEVICE();
@@ -486,6 +492,7 @@ struct VectorInterp_t {
     long *d_cell = nullptr;
     unsigned long long *d_best = nullptr;
     long stage_cells = 0;
+    long grid_version = -1;     // the grid build the located cells belong to
 };
 
 static void vi_free_points(VectorInterp_t *v)
@@ -582,6 +589,7 @@ try {
     } else {
         NF_HIP(hipDeviceSynchronize());
     }
+    v->grid_version = v->grid->version;
     return NF_OK;
 }
 NF_API_CATCH
@@ -593,6 +601,8 @@ try {
     NF_REQUIRE(v->grid, NF_ERR_STATE, "mnt_vectorinterp_getFaceVectors: setGrid first");
     if (v->npts == 0) return NF_OK;
     NF_REQUIRE(vectors, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null output");
+    NF_REQUIRE(v->grid_version == v->grid->version, NF_ERR_STATE,
+               "mnt_vectorinterp_getFaceVectors: the grid was rebuilt after findPoints (the located cells are the old grid's): findPoints again");
     NF_NEED_DEVICE();
     NF_TRY(launch_face_vectors(v->grid->d_xy, v->d_cell, v->d_pcoords, v->npts, data_dev, v->grid->ncell, layout,
                                v->periodX, v->d_vectors, nullptr));
@@ -1066,6 +1076,7 @@ try {
     for (int k = 0; k < 4; ++k) f->box[k] = box_key_to_double(keys[k]);
     f->grid_view.ncell = f->ncell;
     f->grid_view.d_xy = f->d_xy;
+    ++f->grid_view.version;
     f->grid_view.owns_xy = false;
     f->weights_built = false;
     ++f->version;

@@ -1621,3 +1621,36 @@ def test_flux_kernels_fuzz_against_oracle():
     import fuzz_flux
     forms = fuzz_flux.run(150, 20260406, verbose=False)
     assert sum(forms.values()) == 150 and len(forms) >= 20
+
+
+def test_rebuilt_grid_invalidates_weights_and_located_points(oracle):
+    """A mint.Grid that is given new points after a PolylineIntegral computed its weights / a VectorInterp located its points
+    on it: the old cell indices no longer mean anything (they may even lie outside the new grid), so getIntegral /
+    getFaceVectors refuse with a message instead of gathering through them."""
+    from nemoflux_amd import mint
+    from nemoflux_amd._lib import NemofluxError
+    big = oracle.assemble_points(*[getattr(oracle.DataGen(72, 36, 1, 1), k) for k in ('bounds_lon', 'bounds_lat')])
+    small = oracle.assemble_points(*[getattr(oracle.DataGen(12, 6, 1, 1), k) for k in ('bounds_lon', 'bounds_lat')])
+    grid = mint.Grid()
+    grid.setPoints(big)
+    pli = mint.PolylineIntegral()
+    pli.setGrid(grid)
+    pli.buildLocator(numCellsPerBucket=128, periodX=360., enableFolding=False)
+    xyz = transect_xyz("(-100,-50),(100,50)")
+    pli.computeWeights(xyz, counterclock=False)
+    vi = mint.VectorInterp()
+    vi.setGrid(grid)
+    vi.buildLocator(numCellsPerBucket=128, periodX=360., enableFolding=False)
+    vi.findPoints(numpy.array([[150., 70., 0.]]), tol2=1.e-12)
+    assert numpy.isfinite(pli.getIntegral(numpy.ones((big.shape[0], 4))))
+    grid.setPoints(small)                                   # 72 cells instead of 2592
+    with pytest.raises(NemofluxError, match='grid was rebuilt'):
+        pli.getIntegral(numpy.ones((small.shape[0], 4)))
+    with pytest.raises(NemofluxError, match='grid was rebuilt'):
+        vi.getFaceVectors(numpy.ones((small.shape[0], 4)), placement=mint.CELL_BY_CELL_DATA)
+    pli.computeWeights(xyz, counterclock=False)             # ... and work again on the new grid
+    vi.findPoints(numpy.array([[150., 70., 0.]]), tol2=1.e-12)
+    ow = oracle.polyline_weights(small, xyz)
+    data = numpy.random.default_rng(0).standard_normal((small.shape[0], 4))
+    assert abs(pli.getIntegral(data) - oracle.get_integral(ow, data)) <= 1e-13
+    assert vi.getFaceVectors(data, placement=mint.CELL_BY_CELL_DATA).shape == (1, 3)
