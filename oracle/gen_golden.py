@@ -65,7 +65,7 @@ def main():
     only = [a.split('=', 1)[1] for a in sys.argv if a.startswith('--only=')]
 
     def case(name, psi, nx, ny, nz, nt, deltaDeg=(0., 0.), transects=(), sverdrup=False,
-             full=True, land=None, box=(-180., 180., -90., 90., 0., 1.)):
+             full=True, land=None, box=(-180., 180., -90., 90., 0., 1.), wrap=False):
         if only and name not in only:
             return None
         with contextlib.redirect_stdout(io.StringIO()):
@@ -77,6 +77,9 @@ def main():
                 dg.rotatePole(deltaDeg=deltaDeg)
             dg.applyStreamFunction(psi)
             dg.computeUVFromPotential()
+        if wrap:   # what a global T-file stores: every corner's longitude on its own wrapped into [-180, 180); the cells on the
+            # cut then have corners ~350 degrees apart.  The reference's arc lengths / edge fluxes below run on THESE bounds
+            dg.bounds_lon = (dg.bounds_lon + 180.) % 360. - 180.
         u, v = dg.u.copy(), dg.v.copy()
         fill = 1.e20
         if land is not None:  # (j0, j1, i0, i1): NaN block in u, 1e20 block in v (field.py:157)
@@ -138,6 +141,8 @@ def main():
         for tname, pts in transects:
             meta['transects'][tname] = dict(points=pts, fluxexact=run_fluxexact(psi, nz, nt, pts, box[4], box[5]))
         meta['box'] = list(box)
+        if wrap:
+            meta['wrap'] = True
         print(name, 'maxAbsFlux', mx[-1])
         return meta
 
@@ -165,6 +170,11 @@ def main():
     # depth range other than [0, 1]
     metas.append(case('reg16', PSI_ZT, 16, 10, 2, 2, box=(-60., 20., -50., 10., 0., 100.),
                       transects=[('tri', "(-50,-45),(-20,-45),(-35,-10),(-50,-45)"), ('open', "(-50,-45),(-20,-45),(-35,-10)")]))
+    # a global grid on [0, 360] whose T-file bounds are wrapped into [-180, 180) (round 4: cells across the date line); one
+    # transect far from the cut, one across 180 E, one closed loop around it -- end points on nodes, so fluxexact applies
+    metas.append(case('wrap36_zt', PSI_ZT, 36, 18, 2, 2, box=(0., 360., -90., 90., 0., 1.), wrap=True,
+                      transects=[('probe', "(20,-40),(100,30)"), ('across', "(150,-40),(210,30)"),
+                                 ('loop', "(170,-60),(190,-60),(190,60),(170,60),(170,-60)")]))
     metas = [m for m in metas if m is not None]
     if only:      # regenerate single cases: merge into the existing index, leave everything else untouched
         with open(os.path.join(OUT, 'cases.json')) as f:

@@ -49,7 +49,7 @@ def cases():
     return load_cases()
 
 
-FULL_CASES = ['c1_x', 'singular', 'cossin36', 'rot36_zt', 'def36_zt', 'sv36_land', 'reg16']
+FULL_CASES = ['c1_x', 'singular', 'cossin36', 'rot36_zt', 'def36_zt', 'sv36_land', 'reg16', 'wrap36_zt']
 
 
 def case_box(m):

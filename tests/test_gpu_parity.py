@@ -135,7 +135,7 @@ def test_known_answers_readme(oracle, cases):
     assert abs(fld.maxAbsFlux - 10.0) <= 1e-14                # colour-bar max of pictures/simple.png
 
 
-@pytest.mark.parametrize('name', ['def36_zt', 'cossin36', 'reg16'])
+@pytest.mark.parametrize('name', ['def36_zt', 'cossin36', 'reg16', 'wrap36_zt'])
 def test_field_vs_fluxexact(name, oracle, cases):
     m = [c for c in cases if c['name'] == name][0]
     g = load_golden(name)
