@@ -112,6 +112,22 @@ def test_datagen_row_kernel_equals_plain_division(real):
             assert numpy.array_equal(out[0][0], out[1][0]) and numpy.array_equal(out[0][1], out[1][1]), (psi, nx)
     dg = device_case(35, 18, 4, 2, PSI_ZT, real=real)          # nx not a multiple of the lane's cells: the plain kernel
     assert numpy.isfinite(dg.u.cpu().numpy()).all()
+    rng = numpy.random.default_rng(17)                          # random shapes: slab chunks of 25 with a remainder, tiny grids
+    for _ in range(40):
+        nx, ny = 4 * int(rng.integers(1, 40)), int(rng.integers(1, 30))
+        nz, nt = int(rng.integers(1, 40)), int(rng.integers(1, 4))
+        psi = STREAM_FUNCTIONS[int(rng.integers(0, len(STREAM_FUNCTIONS)))]
+        x0, y0 = float(rng.uniform(-180., 0.)), float(rng.uniform(-90., 0.))
+        box = (x0, x0 + float(rng.uniform(10., 180.)), y0, y0 + float(rng.uniform(10., 90.)), 0., float(rng.uniform(1., 50.)))
+        out = []
+        for rows in (1, 0):
+            try:
+                check(lib.nf_tuning_set(b'datagen_rows', rows))
+                dg = device_case(nx, ny, nz, nt, psi, real=real, box=box)
+                out.append((dg.u.cpu().numpy().view(bits), dg.v.cpu().numpy().view(bits)))
+            finally:
+                check(lib.nf_tuning_set(b'datagen_rows', 1))
+        assert numpy.array_equal(out[0][0], out[1][0]) and numpy.array_equal(out[0][1], out[1][1]), (psi, nx, ny, nz, nt, box)
 
 
 # ------------------------------------------------------------------------------------------ BASELINE configs
