@@ -1,0 +1,147 @@
+"""GPU parity, part 4 (round-4 verdict W1): the flux kernel the roofline is quoted on, compared BIT FOR BIT with the oracle AT
+ITS OWN SIZE -- 3600 x 1800 cells x 75 levels, one time step generated on the device -- in every store form the engine
+can take there:
+
+  float64   fused six planes (default) | split = signed planes + k_expand_planes<2> (flux_variant 5) | compact resident
+            mode (signed planes only, the other four derived on demand) | one field per wavefront (k_flux_field)
+  float32   split (default) | fused (flux_variant 5) | compact | one field per wavefront
+  each with the XCD-aware tile map on and off, plus the Sverdrup scaling and the two-marker (_FillValue + missing_value) forms.
+
+What is compared, with numpy.array_equal: read_step's integratedVelocity (ncell,4) -- slots 0 and 3 (the neighbour copies,
+field.py:219-223) included --, edgeFluxesU/V (the two |.| planes, field.py:231-232) and maxAbsFlux (field.py:234), against
+oracle.vertical_integral (field.py:157,161) + oracle.edge_flux (field.py:195-196,209-234) on the same inputs: psi 5 (C4's
+modulated singular stream function, pole-row garbage of datagen.py:104 included) with one block of NaN and one of the
+_FillValue 1e20 written over it (field.py:157).  Through the C ABI: nf_field_compute_flux + nf_field_read_step.
+"""
+import contextlib
+import gc
+import io
+import time
+
+import numpy
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NX, NY, NZ = 3600, 1800, 75
+BOX = (-180., 180., -90., 90., 0., 1.)
+
+
+@contextlib.contextmanager
+def _knobs(**kw):
+    from nemoflux_amd._lib import lib, check
+    defaults = dict(xcd_map=1, flux_variant=0, field_split=-1)
+    try:
+        for k, v in kw.items():
+            check(lib.nf_tuning_set(k.encode(), int(v)))
+        yield
+    finally:
+        for k in kw:
+            check(lib.nf_tuning_set(k.encode(), defaults[k]))
+
+
+def _field(dg, u, v, **kw):
+    from nemoflux_amd.field import Field
+    with contextlib.redirect_stdout(io.StringIO()):
+        return Field.fromArrays(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, u, v, [], fill_value=1.e20, **kw)
+
+
+class _Case(object):
+    """One time step at the headline size on the device + the oracle's answer for it (computed once per dtype)."""
+
+    def __init__(self, real, oracle):
+        import torch
+        from nemoflux_amd.datagen import DataGen, STREAM_FUNCTIONS
+        dg = DataGen(real=real)
+        dg.setSizes(NX, NY, NZ, 1)
+        dg.setBoundingBox(*BOX)
+        dg.build()
+        dg.applyStreamFunction(STREAM_FUNCTIONS[5])
+        u, v = dg.computeUVFromPotential()
+        # land: a NaN block in uo, a _FillValue block in vo, overlapping in part, unaligned edges (field.py:157)
+        u[:, 5:40, 300:901, 1001:2002] = float('nan')
+        v[:, 20:75, 700:1203, 1503:3599] = 1.e20
+        u[:, :, 1799, 3599] = 1.e20                       # the very last cell of the last tile
+        self.dg, self.u, self.v = dg, u, v
+        self.th = numpy.ascontiguousarray(dg.deptht_bounds[:, 1] - dg.deptht_bounds[:, 0])
+        self.uh, self.vh = u[0].cpu().numpy(), v[0].cpu().numpy()
+        self.oracle = oracle
+        self._want = {}
+        self.arc = None
+
+    def want(self, arc, sverdrup=False):
+        """(integratedVelocity, edgeFluxesU, edgeFluxesV, maxAbsFlux) of the oracle for this step."""
+        if sverdrup not in self._want:
+            o = self.oracle
+            if 'UV' not in self._want:
+                self._want['UV'] = (o.vertical_integral(self.uh, self.th, fill=1.e20), o.vertical_integral(self.vh, self.th, fill=1.e20))
+            U, V = self._want['UV']
+            st = o.EdgeFluxState(NY, NX)
+            o.edge_flux(st, U, V, arc, sverdrup=sverdrup)
+            self._want[sverdrup] = (st.integratedVelocity, st.edgeFluxesU, st.edgeFluxesV, st.maxAbsFlux.value)
+        return self._want[sverdrup]
+
+    def check(self, label, sverdrup=False, **kw):
+        fld = _field(self.dg, self.u, self.v, sverdrup=sverdrup, **kw)     # the constructor runs step 0 and reads it back
+        if self.arc is None:
+            self.arc = fld.arcLengths.copy()
+        iV, eU, eV, m = self.want(self.arc, sverdrup)
+        for name, got, exp in (('integratedVelocity', fld.integratedVelocity, iV), ('edgeFluxesUArray', fld.edgeFluxesUArray, eU),
+                               ('edgeFluxesVArray', fld.edgeFluxesVArray, eV)):
+            if not numpy.array_equal(got, exp):
+                bad = numpy.argwhere(got != exp)
+                raise AssertionError(f'{label}: {name} differs from the oracle in {bad.shape[0]} of {got.size} values, first at {bad[0]}')
+        assert fld.maxAbsFlux == m, (label, fld.maxAbsFlux, m)
+        # the second call of the same step (update(), fluxviz's redraw) gives the same bits
+        fld.update()
+        assert numpy.array_equal(fld.integratedVelocity, iV) and fld.maxAbsFlux == m, label
+        del fld
+
+
+@pytest.mark.parametrize('real', ['float64', 'float32'])
+def test_headline_kernel_bit_exact_vs_oracle_at_c4_size(real, oracle):
+    import torch
+    t0 = time.time()
+    case = _Case(real, oracle)
+    try:
+        for xcd in (1, 0):
+            with _knobs(xcd_map=xcd):
+                case.check(f'{real} default xcd_map={xcd}')                   # f64: fused six planes; f32: split + k_expand_planes<2>
+                case.check(f'{real} compact xcd_map={xcd}', compact=True)      # signed-only, the rest derived at read-back
+                with _knobs(flux_variant=5):
+                    case.check(f'{real} other store form xcd_map={xcd}')      # f64: split; f32: fused
+                with _knobs(field_split=1):
+                    case.check(f'{real} one field per wavefront xcd_map={xcd}')
+                    case.check(f'{real} one field per wavefront, compact xcd_map={xcd}', compact=True)
+        case.check(f'{real} sverdrup', sverdrup=True)
+        case.check(f'{real} sverdrup compact', sverdrup=True, compact=True)
+        # some value the oracle got: the comparison above is not 0 == 0 or nan == nan
+        iV, eU, eV, m = case.want(case.arc)
+        assert numpy.isfinite(iV).all() and m > 0.
+        assert numpy.count_nonzero(iV[:, 1]) > 0.99 * iV.shape[0] and numpy.all(iV[:NX, 0] == 0)     # row 0's south slot stays 0
+    finally:
+        del case
+        gc.collect()
+        torch.cuda.empty_cache()
+    print(f'headline parity {real}: {time.time() - t0:.1f} s')
+
+
+def test_headline_kernel_two_markers_at_c4_size(oracle):
+    """The two-marker forms (kFormTwoFills) at the same size, float32 (the dtype of the files that carry a missing_value next
+    to a _FillValue): a third block holds the second marker; the oracle sees it as NaN."""
+    import torch
+    case = _Case('float32', oracle)
+    try:
+        case.v[:, 0:30, 100:180, 17:1234] = 9.96921e36                        # netCDF's default fill as missing_value
+        vh = case.v[0].cpu().numpy()
+        assert numpy.count_nonzero(vh == numpy.float32(9.96921e36)) == 30 * 80 * 1217
+        vh[vh == numpy.float32(9.96921e36)] = numpy.nan
+        case.vh = vh
+        for kw in (dict(), dict(compact=True)):
+            for fs in (-1, 1):
+                with _knobs(field_split=fs):
+                    case.check(f'two markers {kw} field_split={fs}', missing_value=9.96921e36, **kw)
+    finally:
+        del case
+        gc.collect()
+        torch.cuda.empty_cache()
