@@ -93,6 +93,64 @@ static void dev_free(T *&p)
     p = nullptr;
 }
 
+// Sparse staging of a caller's HOST (ncell,4) array for the Level-1 entry points: the 32 bytes of every cell an object
+// touches (the records of a PolylineIntegral, the located cells of a VectorInterp) are gathered into a pinned buffer in
+// record / point order, so that what crosses PCIe is n x 32 B instead of the whole array (207 MB at ORCA12 size) -- mint's
+// own getIntegral is a sparse dot over the same entries (field.py:102).  Native threads from 32 Ki rows on; ids < 0 (a
+// point outside the grid) give a row of zeros.
+template <typename I>
+static void host_gather_rows4(const double *data, const I *ids, long n, double *out)
+{
+    auto work = [=](long lo, long hi) {
+        for (long k = lo; k < hi; ++k) {
+            if (k + 16 < hi && ids[k + 16] >= 0) __builtin_prefetch(data + 4 * (long)ids[k + 16]);
+            if (ids[k] >= 0) memcpy(out + 4 * k, data + 4 * (long)ids[k], 32);
+            else memset(out + 4 * k, 0, 32);
+        }
+    };
+    const long per = 1l << 15;
+    long nthr = std::min<long>(std::min<long>(8, (long)std::thread::hardware_concurrency()), n / per);
+    if (nthr <= 1) {
+        work(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const long chunk = (n + nthr - 1) / nthr;
+    for (long t = 1; t < nthr; ++t) pool.emplace_back(work, t * chunk, std::min(n, (t + 1) * chunk));
+    work(0, std::min(n, chunk));
+    for (auto &th : pool) th.join();
+}
+
+// pinned host buffer + its HBM twin, sized once per weight build / point search
+struct GatherStage {
+    double *h = nullptr, *d = nullptr;
+    long rows = 0;
+    void release()
+    {
+        if (h) (void)hipHostFree(h);
+        if (d) (void)hipFree(d);
+        h = d = nullptr;
+        rows = 0;
+    }
+    int resize(long n)
+    {
+        release();
+        if (n <= 0) return NF_OK;
+        NF_HIP(hipHostMalloc((void **)&h, sizeof(double) * 4 * (size_t)n, hipHostMallocDefault));
+        NF_HIP(hipMalloc((void **)&d, sizeof(double) * 4 * (size_t)n));
+        rows = n;
+        return NF_OK;
+    }
+    template <typename I>
+    int upload(const double *data, const I *ids)   // gather on the host, one copy of rows x 32 B; complete at return
+    {
+        if (rows == 0) return NF_OK;
+        host_gather_rows4(data, ids, rows, h);
+        NF_HIP(hipMemcpy(d, h, sizeof(double) * 4 * (size_t)rows, hipMemcpyHostToDevice));
+        return NF_OK;
+    }
+};
+
 }  // namespace nf
 
 using namespace nf;
@@ -231,8 +289,11 @@ struct PolylineIntegral_t {
     int *d_tr_off = nullptr;
     double *d_scratch = nullptr;
     double *d_row = nullptr;
-    double *d_stage = nullptr;  // host data staged to HBM for getIntegral
-    long stage_cells = 0;
+    // getIntegral on a HOST array stages only the cells the weights touch (GatherStage): the record cell ids stay on the
+    // host after computeWeights, the gathered (nrec,4) rows are indexed by RECORD NUMBER on the device (d_iota = 0..nrec-1)
+    std::vector<int> h_cell;
+    GatherStage stage;
+    int *d_iota = nullptr;
     long grid_version = -1;     // the grid build the weights belong to
     int nseg = 0;
     int skip_unsupported = 0;   // mnt_polylineintegral_setUnsupportedCells
@@ -338,7 +399,8 @@ try {
         dev_free(p->d_tr_off);
         dev_free(p->d_scratch);
         dev_free(p->d_row);
-        dev_free(p->d_stage);
+        dev_free(p->d_iota);
+        p->stage.release();
         delete p;
         *self = nullptr;
     }
@@ -405,51 +467,85 @@ try {
     dev_free(p->d_tr_off);
     dev_free(p->d_scratch);
     dev_free(p->d_row);
+    dev_free(p->d_iota);
+    p->stage.release();
+    p->h_cell.clear();
     NF_TRY(build_weights(p->grid->d_xy, p->grid->ncell, segs.data(), cc.data(), p->nseg, p->periodX, &p->ws, nullptr,
                          p->skip_unsupported));
     NF_TRY(dev_alloc(&p->d_tr_off, 2));
     NF_TRY(dev_alloc(&p->d_scratch, (size_t)p->ws.nrec));
-    NF_TRY(dev_alloc(&p->d_row, (size_t)p->nseg + 1));
     const int off[2] = {0, p->nseg};
     NF_HIP(hipMemcpy(p->d_tr_off, off, sizeof off, hipMemcpyHostToDevice));
+    // what getIntegral needs to stage a host array sparsely: the cells of the records, here; their row numbers, there
+    p->h_cell.resize((size_t)p->ws.nrec);
+    NF_TRY(dev_alloc(&p->d_iota, (size_t)p->ws.nrec));
+    if (p->ws.nrec > 0) {
+        NF_HIP(hipMemcpy(p->h_cell.data(), p->ws.cell, sizeof(int) * (size_t)p->ws.nrec, hipMemcpyDeviceToHost));
+        std::vector<int> iota((size_t)p->ws.nrec);
+        for (long k = 0; k < p->ws.nrec; ++k) iota[(size_t)k] = (int)k;
+        NF_HIP(hipMemcpy(p->d_iota, iota.data(), sizeof(int) * iota.size(), hipMemcpyHostToDevice));
+    }
+    NF_TRY(p->stage.resize(p->ws.nrec));
+    NF_TRY(dev_alloc(&p->d_row, (size_t)p->nseg + 1));   // last: its presence means "weights are ready"
     p->grid_version = p->grid->version;
     return NF_OK;
 }
 NF_API_CATCH
 
-int mnt_polylineintegral_getIntegralDev(PolylineIntegral_t **self, const double *data_dev, int placement,
-                                        double *result, double *seg_totals_host)
-try {
-    NF_REQUIRE(self && *self && data_dev && result, NF_ERR_ARG, "mnt_polylineintegral_getIntegral: null argument");
-    PolylineIntegral_t *p = *self;
-    NF_REQUIRE(p->d_row, NF_ERR_STATE, "mnt_polylineintegral_getIntegral: computeWeights first");
-    NF_REQUIRE(p->grid && p->grid_version == p->grid->version, NF_ERR_STATE,
-               "mnt_polylineintegral_getIntegral: the grid was rebuilt after computeWeights (the weights index the old cells): computeWeights again");
-    NF_REQUIRE(placement == MNT_CELL_BY_CELL_DATA, NF_ERR_ARG,
-               "mnt_polylineintegral_getIntegral: only CELL_BY_CELL_DATA is supported (field.py:102)");
-    NF_NEED_DEVICE();
-    NF_TRY(launch_integral(p->ws, data_dev, p->grid->ncell, 0, 0, p->d_tr_off, 1, p->d_scratch, p->d_row, nullptr));
+// the reduction of one object: gather + wavefront segmented scan + the two finalize kernels, then the row comes back
+static int pli_reduce(PolylineIntegral_t *p, const WeightSet &ws, const double *data_dev, long nrows, double *result,
+                      double *seg_totals_host)
+{
+    NF_TRY(launch_integral(ws, data_dev, nrows, 0, 0, p->d_tr_off, 1, p->d_scratch, p->d_row, nullptr));
     std::vector<double> row((size_t)p->nseg + 1);
     NF_HIP(hipMemcpy(row.data(), p->d_row, sizeof(double) * row.size(), hipMemcpyDeviceToHost));
     *result = row[p->nseg];
     if (seg_totals_host) memcpy(seg_totals_host, row.data(), sizeof(double) * p->nseg);
     return NF_OK;
 }
+
+static int pli_ready(PolylineIntegral_t *p, int placement)
+{
+    NF_REQUIRE(p->d_row, NF_ERR_STATE, "mnt_polylineintegral_getIntegral: computeWeights first");
+    NF_REQUIRE(p->grid && p->grid_version == p->grid->version, NF_ERR_STATE,
+               "mnt_polylineintegral_getIntegral: the grid was rebuilt after computeWeights (the weights index the old cells): computeWeights again");
+    NF_REQUIRE(placement == MNT_CELL_BY_CELL_DATA, NF_ERR_ARG,
+               "mnt_polylineintegral_getIntegral: only CELL_BY_CELL_DATA is supported (field.py:102)");
+    return NF_OK;
+}
+
+int mnt_polylineintegral_getIntegralDev(PolylineIntegral_t **self, const double *data_dev, int placement,
+                                        double *result, double *seg_totals_host)
+try {
+    NF_REQUIRE(self && *self && data_dev && result, NF_ERR_ARG, "mnt_polylineintegral_getIntegral: null argument");
+    PolylineIntegral_t *p = *self;
+    NF_TRY(pli_ready(p, placement));
+    NF_NEED_DEVICE();
+    return pli_reduce(p, p->ws, data_dev, p->grid->ncell, result, seg_totals_host);
+}
 NF_API_CATCH
 
+// Host data: mint's getIntegral is a sparse dot over the K = 4 x (cells crossed) entries (field.py:102; fluxplot.py:55-58
+// calls it once per transect per time step), so the cost here must not depend on the size of the grid either: the 32
+// bytes of every record's cell are gathered on the host into a pinned buffer, nrec x 32 B go to HBM and the SAME kernels
+// run on them with the record number as the cell index -- the same products summed in the same tree, hence the bits of
+// mnt_polylineintegral_getIntegralDev on the whole array (tests/test_gpu_parity.py::test_level1_host_data_is_staged_sparsely).
 int mnt_polylineintegral_getIntegral(PolylineIntegral_t **self, const double data[], int placement, double *result)
 try {
     NF_REQUIRE(self && *self && data && result, NF_ERR_ARG, "mnt_polylineintegral_getIntegral: null argument");
     PolylineIntegral_t *p = *self;
     NF_REQUIRE(p->grid, NF_ERR_STATE, "mnt_polylineintegral_getIntegral: setGrid first");
+    NF_TRY(pli_ready(p, placement));
     NF_NEED_DEVICE();
-    if (p->stage_cells != p->grid->ncell) {
-        dev_free(p->d_stage);
-        NF_TRY(dev_alloc(&p->d_stage, (size_t)p->grid->ncell * 4));
-        p->stage_cells = p->grid->ncell;
-    }
-    NF_HIP(hipMemcpy(p->d_stage, data, sizeof(double) * 4 * (size_t)p->grid->ncell, hipMemcpyHostToDevice));
-    return mnt_polylineintegral_getIntegralDev(self, p->d_stage, placement, result, nullptr);
+    NF_TRY(p->stage.upload(data, p->h_cell.data()));
+    WeightSet rows;              // a view of the object's records whose cell index is the record number
+    rows.nrec = p->ws.nrec;
+    rows.cell = p->d_iota;
+    rows.w4 = p->ws.w4;
+    rows.seg = p->ws.seg;
+    rows.nseg = p->ws.nseg;
+    rows.seg_start = p->ws.seg_start;
+    return pli_reduce(p, rows, p->stage.d, p->ws.nrec, result, nullptr);
 }
 NF_API_CATCH
 
@@ -488,10 +584,12 @@ struct VectorInterp_t {
     bool locator = false;
     double periodX = 0.0;
     long npts = 0;
-    double *d_targets = nullptr, *d_pcoords = nullptr, *d_vectors = nullptr, *d_stage = nullptr;
+    double *d_targets = nullptr, *d_pcoords = nullptr, *d_vectors = nullptr;
     long *d_cell = nullptr;
     unsigned long long *d_best = nullptr;
-    long stage_cells = 0;
+    // getFaceVectors on a HOST array stages only the located cells, one (4) row per target point (GatherStage)
+    std::vector<long> h_cell;
+    GatherStage stage;
     long grid_version = -1;     // the grid build the located cells belong to
 };
 
@@ -502,6 +600,8 @@ static void vi_free_points(VectorInterp_t *v)
     dev_free(v->d_vectors);
     dev_free(v->d_cell);
     dev_free(v->d_best);
+    v->stage.release();
+    v->h_cell.clear();
     v->npts = 0;
 }
 
@@ -518,7 +618,6 @@ int mnt_vectorinterp_del(VectorInterp_t **self)
 try {
     if (self && *self) {
         vi_free_points(*self);
-        dev_free((*self)->d_stage);
         delete *self;
         *self = nullptr;
     }
@@ -580,26 +679,21 @@ try {
                                   nullptr));
         NF_HIP(hipDeviceSynchronize());
     }
+    v->h_cell.resize(numPoints);      // the located cells stay on the host too: they address the caller's host arrays
+    NF_HIP(hipMemcpy(v->h_cell.data(), v->d_cell, sizeof(long) * numPoints, hipMemcpyDeviceToHost));
+    NF_TRY(v->stage.resize((long)numPoints));
     if (numNotFound) {
-        std::vector<long> cells(numPoints);
-        NF_HIP(hipMemcpy(cells.data(), v->d_cell, sizeof(long) * numPoints, hipMemcpyDeviceToHost));
         size_t n = 0;
-        for (long c : cells) n += (c < 0);
+        for (long c : v->h_cell) n += (c < 0);
         *numNotFound = n;
-    } else {
-        NF_HIP(hipDeviceSynchronize());
     }
     v->grid_version = v->grid->version;
     return NF_OK;
 }
 NF_API_CATCH
-/* layout: 0 = (ncell,4) AoS, 1 = [4][ncell] planes (the engine's resident layout) */
-int mnt_vectorinterp_getFaceVectorsDev(VectorInterp_t **self, const double *data_dev, int layout, double vectors[])
-try {
-    NF_REQUIRE(self && *self && data_dev, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null argument");
-    VectorInterp_t *v = *self;
-    NF_REQUIRE(v->grid, NF_ERR_STATE, "mnt_vectorinterp_getFaceVectors: setGrid first");
-    if (v->npts == 0) return NF_OK;
+/* layout: 0 = (ncell,4) AoS, 1 = [4][ncell] planes (the engine's resident layout), 2 = (npts,4) rows gathered per point */
+static int vi_vectors(VectorInterp_t *v, const double *data_dev, int layout, double vectors[])
+{
     NF_REQUIRE(vectors, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null output");
     NF_REQUIRE(v->grid_version == v->grid->version, NF_ERR_STATE,
                "mnt_vectorinterp_getFaceVectors: the grid was rebuilt after findPoints (the located cells are the old grid's): findPoints again");
@@ -609,7 +703,18 @@ try {
     NF_HIP(hipMemcpy(vectors, v->d_vectors, sizeof(double) * 3 * v->npts, hipMemcpyDeviceToHost));
     return NF_OK;
 }
+int mnt_vectorinterp_getFaceVectorsDev(VectorInterp_t **self, const double *data_dev, int layout, double vectors[])
+try {
+    NF_REQUIRE(self && *self && data_dev, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null argument");
+    VectorInterp_t *v = *self;
+    NF_REQUIRE(v->grid, NF_ERR_STATE, "mnt_vectorinterp_getFaceVectors: setGrid first");
+    NF_REQUIRE(layout == 0 || layout == 1, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectorsDev: layout must be 0 ((ncell,4)) or 1 ([4][ncell] planes)");
+    if (v->npts == 0) return NF_OK;
+    return vi_vectors(v, data_dev, layout, vectors);
+}
 NF_API_CATCH
+// Host data: only the rows of the located cells travel (npts x 32 B, not ncell x 32 B): field.py:119 calls this at every
+// update() of the viewer.  Same arithmetic on the same values as the resident-data call: same bits.
 int mnt_vectorinterp_getFaceVectors(VectorInterp_t **self, const double data[], int placement, double vectors[])
 try {
     NF_REQUIRE(self && *self && data, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null argument");
@@ -617,14 +722,10 @@ try {
     NF_REQUIRE(v->grid, NF_ERR_STATE, "mnt_vectorinterp_getFaceVectors: setGrid first");
     NF_REQUIRE(placement == MNT_CELL_BY_CELL_DATA, NF_ERR_ARG,
                "mnt_vectorinterp_getFaceVectors: only CELL_BY_CELL_DATA (placement=0) is supported (field.py:94-95)");
+    if (v->npts == 0) return NF_OK;
     NF_NEED_DEVICE();
-    if (v->stage_cells != v->grid->ncell) {
-        dev_free(v->d_stage);
-        NF_TRY(dev_alloc(&v->d_stage, (size_t)v->grid->ncell * 4));
-        v->stage_cells = v->grid->ncell;
-    }
-    NF_HIP(hipMemcpy(v->d_stage, data, sizeof(double) * 4 * (size_t)v->grid->ncell, hipMemcpyHostToDevice));
-    return mnt_vectorinterp_getFaceVectorsDev(self, v->d_stage, 0, vectors);
+    NF_TRY(v->stage.upload(data, v->h_cell.data()));
+    return vi_vectors(v, v->stage.d, 2, vectors);
 }
 NF_API_CATCH
 int mnt_vectorinterp_getCells(VectorInterp_t **self, long long *cell_ids, double *pcoords)

@@ -163,7 +163,12 @@ __global__ __launch_bounds__(kBlock) void k_face_vectors(const double *__restric
         unwrap_quad(v, periodX);   // the tangent vectors of a date-line cell are those of the unwrapped quad
         const double xi = pcoords[2 * p], eta = pcoords[2 * p + 1];
         double d0, d1, d2, d3;
-        if (planes) {
+        if (planes == 2) {          // rows gathered per target point on the host: (npts,4)
+            d0 = data[4 * p];
+            d1 = data[4 * p + 1];
+            d2 = data[4 * p + 2];
+            d3 = data[4 * p + 3];
+        } else if (planes) {
             d0 = data[c];
             d1 = data[ncell + c];
             d2 = data[2 * ncell + c];

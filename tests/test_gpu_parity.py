@@ -153,3 +153,52 @@ def test_field_vs_fluxexact(name, oracle, cases):
             ex2 = oracle.fluxexact(m['psi'], ast.literal_eval(m['transects'][n]['points']), m['nz'], m['nt'],
                                    *case_box(m)[4:])[t]
             assert abs(one[i] - ex2) <= 1e-13 * max(amp, abs(ex2))
+
+
+@pytest.mark.parametrize('name', ['rot36_zt', 'cossin360', 'wrap36_zt'])
+def test_level1_host_data_is_staged_sparsely(name, oracle, cases):
+    """mint.PolylineIntegral.getIntegral / mint.VectorInterp.getFaceVectors on a HOST array (field.py:102,119; fluxplot.py:55-58:
+    one call per transect per time step) move only the cells the object touches -- nrec x 32 B, not the whole (ncell,4) array
+    (round-4 verdict W4) -- and return the BITS of the call on HBM-resident data: same products, same summation tree.  Proof
+    that nothing else is read: NaN in every cell the weights / the located points do not touch changes nothing."""
+    import torch
+    from nemoflux_amd import mint
+    m = [c for c in cases if c['name'] == name][0]
+    g = load_golden(name)
+    pts = oracle.assemble_points(g['bounds_lon'], g['bounds_lat'])
+    grid = mint.Grid()
+    grid.setPoints(pts)
+    rng = numpy.random.default_rng(11)
+    data = rng.standard_normal((pts.shape[0], 4))
+    ddev = torch.from_numpy(data).cuda()
+    for tn, tr in m['transects'].items():
+        xyz = transect_xyz(tr['points'])
+        pli = mint.PolylineIntegral()
+        pli.setGrid(grid)
+        pli.buildLocator(numCellsPerBucket=128, periodX=360., enableFolding=False)
+        pli.computeWeights(xyz, counterclock=False)
+        tot = pli.getIntegral(data, mint.CELL_BY_CELL_DATA)
+        assert tot == pli.getIntegral(ddev, mint.CELL_BY_CELL_DATA)
+        assert tot == pli.getIntegral(data.reshape(-1), mint.CELL_BY_CELL_DATA)          # flat form (field.py:102 passes either)
+        ce, w, sg = pli.getWeights()
+        holes = numpy.full_like(data, numpy.nan)
+        touched = numpy.unique(ce // 4)
+        holes[touched] = data[touched]
+        assert pli.getIntegral(holes, mint.CELL_BY_CELL_DATA) == tot
+        assert 0 < touched.size < pts.shape[0] // 2
+        # a second set of weights on the same object re-sizes the staging
+        pli.computeWeights(xyz[:2], counterclock=False)
+        assert pli.getIntegral(data) == pli.getIntegral(ddev)
+        # arrows on the same line
+        vp = numpy.concatenate([a + (b - a) * numpy.linspace(0., 1., 7)[:, None] for a, b in zip(xyz[:-1], xyz[1:])])
+        vp = numpy.concatenate([vp, [[500., 95., 0.]]])                                   # one point outside every cell
+        vi = mint.VectorInterp()
+        vi.setGrid(grid)
+        vi.buildLocator(numCellsPerBucket=128, periodX=360.)
+        assert vi.findPoints(vp, tol2=1.e-12) >= 1
+        vec = vi.getFaceVectors(data, placement=mint.CELL_BY_CELL_DATA)
+        assert numpy.array_equal(vec, vi.getFaceVectors(ddev)) and numpy.all(vec[-1] == 0.)
+        ids, _ = vi.getCells()
+        holes = numpy.full_like(data, numpy.nan)
+        holes[ids[ids >= 0]] = data[ids[ids >= 0]]
+        assert numpy.array_equal(vi.getFaceVectors(holes, placement=mint.CELL_BY_CELL_DATA), vec)
