@@ -173,9 +173,16 @@ def run_workload(args, dtype, scaling, rank, world, local, want_totals=False, em
         seen = comm.info() if comm is not None else None
         m['reduce']['path'] = ('nf_rows_allreduce (ncclAllReduce on the library\'s own communicator)' if comm is not None
                                else 'torch.distributed.all_reduce')
+        m['reduce']['fell_back'] = comm is None and os.environ.get('NF_NATIVE_REDUCE', '1') != '0' and dist.get_backend() == 'nccl'
+        if m['reduce']['fell_back']:
+            m['reduce']['fell_back_reason'] = nfdist.fell_back_reason.get(None, 'unknown')
         if seen is not None:
             m['reduce']['world_size_rccl'] = seen['world_size']
             m['reduce']['library'] = seen['library']
+            if seen['world_size'] != world:     # a communicator over fewer ranks would sum fewer partial rows under the same name
+                print(f'bench.py: rank {rank}: the RCCL communicator spans {seen["world_size"]} ranks, the job has {world}; '
+                      'refusing to report a value', file=sys.stderr, flush=True)
+                raise SystemExit(4)
         prop = torch.cuda.get_device_properties(local)
         mine = {'rank': rank, 'device_index': local, 'device_name': prop.name,
                 'device_uuid': str(getattr(prop, 'uuid', '')), 'pci_bus_id': int(getattr(prop, 'pci_bus_id', -1)),
@@ -271,6 +278,8 @@ def main():
     ap.add_argument('--emulate-rank', default=None, metavar='r/N',
                     help='NOT a scaling run: on ONE GPU, do exactly what rank r of an N-rank strong-scaling run does (its slab '
                          'range, its launches; no reduce) and report its ms per pass -- per-rank compute evidence for N > 1')
+    ap.add_argument('--knob', action='append', default=[], metavar='name=value',
+                    help='NOT the headline configuration: nf_tuning_set(name, value) before anything runs (A/B and counter passes)')
     ap.add_argument('--compact', action='store_true',
                     help='NOT the headline configuration: keep only (eU, eV) resident per step (nf_field_set_compact); the '
                          '(ncell,4) copies and |.| arrays are derived at read-back, which a batch driver never asks for')
@@ -293,6 +302,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: nemoflux_amd has no CPU fallback')
     torch.cuda.set_device(local)
+    for kv in args.knob:
+        from nemoflux_amd._lib import lib, check
+        name, val = kv.split('=')
+        check(lib.nf_tuning_set(name.encode(), int(val)))
 
     if args.only_c3:
         if world != 1:
@@ -340,6 +353,14 @@ def main():
     # ---- CPU baseline (rank 0, N=1 only): the reference's numpy statements on one time step
     if rank == 0 and world == 1 and not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(m['dg'], m['u'], m['v'], nz, ny, nx, m['polys'], args)
+        # the CPU leg integrates time step 0 across the README transect with the oracle's own weights: the same number as the
+        # GPU's row, from an independent implementation end to end (geometry, vertical integral, weights, reduction)
+        out['accuracy']['cpu_flux_t0'] = out['cpu_baseline']['legs']['flux_t0']
+        out['accuracy']['cpu_gpu_flux_abs_diff'] = abs(out['cpu_baseline']['legs']['flux_t0'] - m['accuracy']['singular_transect_t0'])
+        if not out['accuracy']['cpu_gpu_flux_abs_diff'] <= 1e-11 * max(1.0, abs(m['accuracy']['singular_transect_t0'])):
+            print(f'bench.py: CPU and GPU disagree on the flux of step 0: {out["accuracy"]["cpu_flux_t0"]!r} vs '
+                  f'{m["accuracy"]["singular_transect_t0"]!r}', file=sys.stderr, flush=True)
+            raise SystemExit(5)
 
     # ---- float32 inputs (real NEMO files are float32: SURVEY 2 row 13): same workload, same checks, short record
     if world == 1 and args.dtype == 'f64' and not args.no_f32:
@@ -483,15 +504,15 @@ def ingest_record(streams=256):
             'kernels': 'nf::k_inflate + nf::k_place16', 'resident_streams_capacity': ChunkDecoder.capacity()}
 
 
-def visible_gpu_count():
+def visible_gpu_count(kfd='/sys/class/kfd'):
     """GPUs a child process would see, counted WITHOUT touching the HIP runtime (the launcher must stay a process that has
     never initialised the GPU): the KFD topology in sysfs (GPU nodes have simd_count > 0), narrowed by HIP_VISIBLE_DEVICES /
     ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.  None when sysfs cannot be read (the ranks then fail loudly
     themselves if a device is missing)."""
     n = None
     try:
-        base = '/sys/class/kfd/kfd/topology/nodes'
-        if not os.path.exists('/sys/class/kfd'):
+        base = os.path.join(kfd, 'kfd', 'topology', 'nodes')
+        if not os.path.exists(kfd):
             raise FileNotFoundError
         n = 0
         for node in os.listdir(base):
@@ -533,11 +554,9 @@ def self_launch(ngpus):
         port = sock.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={ngpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: what RCCL needs between processes on this host
-    env.setdefault('OMP_NUM_THREADS', '4')
-    env.setdefault('NF_DIST_TIMEOUT_S', '300')            # a rank that cannot join ends the job with a message (dist._Deadline)
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, close_fds=True)
+    # No environment of its own: what a rank needs (dmabuf IPC for RCCL, the start-up time limit, its host threads) is set by
+    # the rank itself in nemoflux_amd.dist.rank_environment(), so that `torchrun ... bench.py --gpus N` runs identical ranks
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, close_fds=True)
     for line in child.stdout:               # rank 0's JSON line (and anything else the ranks print) goes straight through
         sys.stdout.write(line)
         sys.stdout.flush()
@@ -621,7 +640,7 @@ def cpu_baseline(dg, u, v, nz, ny, nx, polys, args):
         with ThreadPoolExecutor(max_workers=ncores) as ex:
             list(ex.map(one, sample))
         t_a6 = time.perf_counter() - t0
-    legs = {'numpy_default_threads_s_per_step': round(best, 4), 'numpy_threads': int(threads),
+    legs = {'flux_t0': float(tot), 'numpy_default_threads_s_per_step': round(best, 4), 'numpy_threads': int(threads),
             'numpy_1_thread_s_per_step': None if t_1 is None else round(t_1, 4),
             'numpy_1_thread_integrals_per_s': None if t_1 is None else units / t_1,
             'c_openmp_s_per_step': round(t_c, 4), 'c_openmp_threads': omp, 'c_openmp_integrals_per_s': units / t_c,

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(BLOCK) void k_flux(const T *__restrict__ u, const T
 // costs half as much.  blockIdx.z selects the field; a u-wave stores plane 1, |eU| and the west copies (plane 3), a
 // v-wave plane 2, |eV| and the south copies (plane 0): the same values into the same slots as k_flux (bit-identical:
 // test_field_split_bit_identical).  launch_flux picks this form by the number of wavefronts a launch has.
-template <typename T, int VEC, int UZ, bool SIGNED_ONLY, bool TWO_FILLS>
+template <typename T, int VEC, int UZ, bool SIGNED_ONLY, bool TWO_FILLS, bool WSHIFT = false>
 __global__ __launch_bounds__(256) void k_flux_field(const T *__restrict__ u, const T *__restrict__ v, long ncell,
                                                     unsigned ny, unsigned nx, int z0, int z1,
                                                     const double *__restrict__ thickness,
@@ -370,6 +370,21 @@ __global__ __launch_bounds__(256) void k_flux_field(const T *__restrict__ u, con
 #pragma unroll
                         for (int k = 0; k < VEC; k += 2) store2<true>(iV + c0 + nx + k, e[k], e[k + 1], al);
                     }
+                } else if (WSHIFT && nx % VEC == 0) {
+                    // plane 3 in ALIGNED 16-byte pieces (round-4 verdict W5): the lane's own west slots are (eU of the lane to
+                    // the left's last cell, e[0], ..., e[VEC-2]); the value from the left comes by a lane shift.  The first
+                    // lane of a wavefront and of a grid row has no left neighbour in reach: its slot is stored (8 bytes) by
+                    // the lane that owns the value -- the last lane of the wavefront before, or the row's last lane (the
+                    // periodic wrap, field.py:223).  nx % VEC == 0: every lane's cells sit in one row.
+                    const int lane = threadIdx.x & (kWave - 1);
+                    const double left = __shfl_up(e[VEC - 1], 1, kWave);
+                    double *p3 = iV + 3 * ncell;
+                    if (lane > 0 && i0 > 0) store2<true>(p3 + c0, left, e[0], true);
+                    else store1<true>(p3 + c0 + 1, e[0]);
+#pragma unroll
+                    for (int k = 2; k < VEC; k += 2) store2<true>(p3 + c0 + k, e[k - 1], e[k], true);
+                    if (lane == kWave - 1 || i0 + VEC >= nx || c0 + VEC >= ncell)
+                        store1<true>(p3 + ((i0 + VEC < nx) ? c0 + VEC : c0 + VEC - nx), e[VEC - 1]);
                 } else {                            // plane 3: west slots of the cells to the right, the row's last cell wraps
 #pragma unroll
                     for (int k = 0; k < VEC; ++k)
@@ -461,6 +476,8 @@ static int g_xcd_map = 1;
 static int g_variant = 0;
 // "field_split": -1 = by the size of the launch (default), 0 = never, 1 = always
 static int g_field_split = -1;
+// "west_shift": 1 = the one-field kernel builds the west slots from lane-shifted values (aligned 16-byte stores)
+static int g_west_shift = 0;
 // One-step launches with fewer wavefronts than this take the one-field form (about four rounds of resident wavefronts).
 // tools/size_sweep.py, profiles/r04_size_sweep.txt: 1440 x 1021 x 75 (11 488 / 5 744 wavefronts at float64 / float32) gains
 // 17 % / 41 %, 2160 x 1080 (18 225 / 9 112) 2 % / 8 %, 3600 x 1800 (50 656 / 25 312) loses 2 %
@@ -473,6 +490,7 @@ int tuning_set(const char *name, int value)
     if (!strcmp(name, "xcd_map")) g_xcd_map = value;
     else if (!strcmp(name, "flux_variant")) g_variant = value;
     else if (!strcmp(name, "field_split")) g_field_split = value;
+    else if (!strcmp(name, "west_shift")) g_west_shift = value;
 #ifdef NF_TUNING_BUILD
     else if (!strcmp(name, "ww_blocks_per_cu")) g_pipe_waves = value;
 #endif
@@ -495,14 +513,14 @@ static int launch_flux_t(const FluxArgs &a, hipStream_t s)
     return NF_OK;
 }
 
-template <typename T, int VEC, int UZ, bool SIGNED_ONLY, bool TWO_FILLS>
+template <typename T, int VEC, int UZ, bool SIGNED_ONLY, bool TWO_FILLS, bool WSHIFT = false>
 static int launch_flux_field_t(const FluxArgs &a, hipStream_t s)
 {
     const long per_tile = 256l * VEC;
     const unsigned ntiles = (unsigned)((a.ncell + per_tile - 1) / per_tile);
     const int xcd_map = g_xcd_map;
     const unsigned grid = xcd_map ? xcd_grid(ntiles) : ntiles;
-    hipLaunchKernelGGL((k_flux_field<T, VEC, UZ, SIGNED_ONLY, TWO_FILLS>), dim3(grid, (unsigned)(a.batch.zr ? a.batch.nsteps : 1), 2),
+    hipLaunchKernelGGL((k_flux_field<T, VEC, UZ, SIGNED_ONLY, TWO_FILLS, WSHIFT>), dim3(grid, (unsigned)(a.batch.zr ? a.batch.nsteps : 1), 2),
                        dim3(256), 0, s, (const T *)a.u, (const T *)a.v, a.ncell, (unsigned)a.ny, (unsigned)a.nx, a.z0, a.z1,
                        a.thickness, a.arcE, a.arcN, (T)a.fill, a.scale, a.sverdrup, a.iV, a.absU, a.maxbits, ntiles, xcd_map,
                        a.batch, (T)a.fill2);
@@ -519,6 +537,7 @@ static int launch_flux_field(const FluxArgs &a, hipStream_t s)
     const bool two = (T)a.fill2 == (T)a.fill2 && !((T)a.fill2 == (T)a.fill);
     if (a.signed_only)
         return two ? launch_flux_field_t<T, VEC, kLevels, true, true>(a, s) : launch_flux_field_t<T, VEC, kLevels, true, false>(a, s);
+    if (g_west_shift && VEC > 1 && !two) return launch_flux_field_t<T, VEC, kLevels, false, false, true>(a, s);
     return two ? launch_flux_field_t<T, VEC, kLevels, false, true>(a, s) : launch_flux_field_t<T, VEC, kLevels, false, false>(a, s);
 }
 

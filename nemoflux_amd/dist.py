@@ -44,9 +44,31 @@ def time_steps_touched(srange, nz):
     return b // nz, (e - 1) // nz + 1
 
 
+RANK_THREADS = 4      # host threads of one rank of a multi-process run (NF_RANK_THREADS)
+
+
+def rank_environment():
+    """What every rank of a multi-process run needs in its environment BEFORE its first GPU call, whoever started it
+    (`python bench.py --gpus N`, which starts its own ranks, or `torchrun ... bench.py --gpus N`: the ranks are identical
+    either way -- round-4 verdict W6).  `import torch` and loading libnemoflux_amd.so do not initialise HIP, so this is
+    early enough when it runs first thing in init_from_env.
+      HSA_ENABLE_IPC_MODE_LEGACY=0  dmabuf IPC: what RCCL needs between the processes of one host (read at hsa_init)
+      NF_DIST_TIMEOUT_S=300         a rank that cannot join ends the job with a message (_Deadline), it does not hang it
+    Values already present win.  The host threads of a rank are set through torch (the OpenMP runtime has read
+    OMP_NUM_THREADS when torch was imported; torchrun exports OMP_NUM_THREADS=1 for N > 1 on both paths)."""
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('NF_DIST_TIMEOUT_S', '300')
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        try:
+            torch.set_num_threads(max(1, int(os.environ.get('NF_RANK_THREADS', RANK_THREADS))))
+        except (RuntimeError, ValueError):
+            pass
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun) if WORLD_SIZE > 1.
     Returns (rank, world, local_rank)."""
+    rank_environment()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -60,14 +82,16 @@ def init_from_env(backend=None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         import datetime
-        # a rank that never arrives must not hang the job: rendezvous and every torch collective give up after this long
-        timeout = datetime.timedelta(seconds=startup_timeout_s())
-        if backend == 'nccl':     # RCCL: bind the communicator to this rank's GPU at init (one process per GPU)
-            torch.cuda.set_device(local)
-            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout,
-                                    device_id=torch.device('cuda', local))
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
+        # Two different bounds (round-4 advisor): a rank that never arrives must not hang the job -- the rendezvous gives up
+        # after startup_timeout_s() (_Deadline) --, while the collectives of a running job keep their own, longer limit
+        timeout = datetime.timedelta(seconds=collective_timeout_s())
+        with _Deadline(startup_timeout_s(), 'the torch.distributed rendezvous (init_process_group)'):
+            if backend == 'nccl':     # RCCL: bind the communicator to this rank's GPU at init (one process per GPU)
+                torch.cuda.set_device(local)
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout,
+                                        device_id=torch.device('cuda', local))
+            else:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local
@@ -116,12 +140,43 @@ def startup_timeout_s():
     return float(os.environ.get('NF_DIST_TIMEOUT_S', '300'))
 
 
+def collective_timeout_s():
+    """Seconds a torch.distributed collective of a RUNNING job may take (NF_DIST_COLLECTIVE_TIMEOUT_S, default 1800 --
+    torch's own default for gloo; the start-up steps have their own, shorter bound: startup_timeout_s)."""
+    return float(os.environ.get('NF_DIST_COLLECTIVE_TIMEOUT_S', '1800'))
+
+
+_agree_seq = {}
+
+
 def _agree(flag, group=None):
-    """MIN over the ranks of an int flag, through torch.distributed on whatever backend the group has."""
-    dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
-    t = torch.tensor([int(flag)], dtype=torch.int32, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-    return int(t.item())
+    """MIN over the ranks of an int flag, through the rendezvous STORE (host-side key/value, TCP): a rank whose GPU turned
+    out to be unusable can still say so -- on the 'nccl' backend an all_reduce would need a device tensor on exactly the
+    device that failed, the rank would raise instead of reporting 0 and the others would wait for it (round-4 advisor).
+    Every rank of the group calls this the same number of times (the sequence number is part of the key).  Falls back to an
+    all_reduce on the group's backend when the process group has no store to offer."""
+    flag = int(flag)
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        ranks = list(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+        me = dist.get_rank()
+    except Exception:
+        store = None
+    if store is None:
+        try:
+            dev = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+            t = torch.tensor([flag], dtype=torch.int32, device=dev)
+        except Exception:       # no usable device on this rank: it must still take part, with the answer "no"
+            t = torch.tensor([0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return int(t.item())
+    import datetime
+    seq = _agree_seq[group] = _agree_seq.get(group, 0) + 1
+    prefix = f'nemoflux_amd/agree/{ranks[0]}-{ranks[-1]}-{len(ranks)}/{seq}'
+    store.set(f'{prefix}/{me}', str(flag))
+    keys = [f'{prefix}/{r}' for r in ranks]
+    store.wait(keys, datetime.timedelta(seconds=startup_timeout_s()))
+    return min(int(store.get(k)) for k in keys)
 
 
 class NativeComm(object):
@@ -183,6 +238,7 @@ class NativeComm(object):
 
 
 _native = {}   # group -> NativeComm, or False when it could not be created on every rank
+fell_back_reason = {}   # group -> why the ranks reduce through torch.distributed instead (bench.py: reduce.fell_back)
 
 
 def _fallback(group, err, comm=None):
@@ -195,6 +251,7 @@ def _fallback(group, err, comm=None):
         print(f'# nemoflux_amd.dist: native RCCL communicator unavailable ({err or "failed on another rank"}); '
               'reducing through torch.distributed', file=sys.stderr, flush=True)
     _native[group] = False
+    fell_back_reason[group] = err or 'failed on another rank'
     return None
 
 
@@ -219,6 +276,7 @@ def native_comm(group=None):
         comm.preflight(group)
     except Exception as e:
         err = f'{type(e).__name__}: {e}'
+    fell_back_reason.pop(group, None)
     # 2. agreement BEFORE the collective ncclCommInitRank (a rank that failed above would leave the others inside it)
     with _Deadline(startup_timeout_s(), 'the agreement before nf_rccl_comm_init'):
         all_ok = _agree(0 if err else 1, group)

@@ -361,19 +361,21 @@ def test_field_split_bit_identical(real):
         out = {}
         try:
             for batch in (0, 1):
-                for fs in (0, 1):
+                for fs, ws in ((0, 0), (1, 0), (1, 1)):     # ws: west slots from lane-shifted values (aligned 16-byte stores)
                     check(lib.nf_tuning_set(b'batch_steps', batch))
                     check(lib.nf_tuning_set(b'field_split', fs))
+                    check(lib.nf_tuning_set(b'west_shift', ws))
                     f = quiet_field(*args, **kw)
                     tot, segs = f.computeAll()
                     t = nt - 1 if 'slab_range' not in kw else kw['slab_range'][0] // nz
                     f.computeFlux(t, readback=True)
-                    out[(batch, fs)] = (tot, segs, f.integratedVelocity.copy(), f.edgeFluxesUArray.copy(),
-                                        f.edgeFluxesVArray.copy(), f.maxAbsFlux)
+                    out[(batch, fs, ws)] = (tot, segs, f.integratedVelocity.copy(), f.edgeFluxesUArray.copy(),
+                                            f.edgeFluxesVArray.copy(), f.maxAbsFlux)
         finally:
             check(lib.nf_tuning_set(b'field_split', -1))
             check(lib.nf_tuning_set(b'batch_steps', 1))
-        ref = out[(0, 0)]
+            check(lib.nf_tuning_set(b'west_shift', 0))
+        ref = out[(0, 0, 0)]
         for key, got in out.items():
             for a, b in zip(ref, got):
                 assert numpy.array_equal(a, b, equal_nan=True), (nx, ny, kw, key)
