@@ -215,7 +215,7 @@ def run_workload(args, dtype, scaling, rank, world, local, want_totals=False, em
                          'k_flux_ms': round(flux_ms / max(1, args.steps), 4),
                          'k_expand_ms': round(expand_ms / max(1, args.steps), 4),
                          'k3_ms': round(k3_ms / max(1, args.steps), 4),
-                         'partial_step_planes': os.environ.get('NF_PARTIAL_STEP_PLANES', 'signed-only (default)')}
+                         'partial_step_planes': 'full (knob)' if 'partial_step_planes=1' in args.knob else 'signed-only (default)'}
     m['accuracy'] = {'max_abs_err_vs_fluxexact': max_err, 'max_abs_exact': max_ref,
                      'singular_transect_t0': float(res[0, nseg + 0]), 'transect_steps_checked': len(polys) * nt_global}
     if want_totals:

@@ -71,7 +71,10 @@ int nf_host_gather(const unsigned long long *src_addr, const unsigned long long 
 /* tuning knobs for A/B measurements inside one process: "flux_variant" (0 = default store form, 5 = the other one; see nf_flux.hip),
  * "xcd_map" (1 = on), "batch_steps" (1 = small grids run all time steps in one launch), "field_split" (-1 = one-step launches
  * of fewer than 20 000 wavefronts integrate uo and vo in different wavefronts, 0 = never, 1 = always), "edge_weights", "datagen_rows"
- * (0 = the generator's one-cell-per-lane kernel with plain division, the reference of its row kernel) */
+ * (0 = the generator's one-cell-per-lane kernel with plain division, the reference of its row kernel), "west_shift" (0 = the
+ * west slots of integratedVelocity as 8-byte stores, the form before round 5), "batch_cellsteps_m" (all-steps-in-one-launch
+ * limit in Mi cell-steps, 32), "partial_step_planes" (1 = six-plane epilogue on a rank's partial time steps), "graph" (0 =
+ * no graph replay of a pass).  The library reads NO environment variable: these calls are the only switches. */
 int nf_tuning_set(const char *name, int value);
 
 /* ------------------------------------------------------------------ Level 1: mint-shaped API */
@@ -119,7 +122,9 @@ int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, 
  * transect's physics; mint itself returns a number there, pinned by nothing in the reference). */
 int mnt_polylineintegral_setUnsupportedCells(PolylineIntegral_t **self, int skip);
 /* .getIntegral(data (ncell,4) float64 HOST, placement) -> *result   field.py:102, fluxplot.py:56
- * Host data is staged to HBM (PCIe-inclusive path); see ...getIntegralDev for resident data. */
+ * Host data is staged SPARSELY: only the 32 bytes of every cell the weights touch are gathered (pinned buffer) and sent
+ * to HBM -- the cost follows the number of weights, not the size of the grid, like mint's own sparse dot -- and the same
+ * kernels run on them: the result has the bits of ...getIntegralDev on the whole array (see that for resident data). */
 int mnt_polylineintegral_getIntegral(PolylineIntegral_t **self, const double data[], int placement,
                                      double *result);
 /* extensions (not in mint): device-resident data, per-target-segment sums, weight read-back */
@@ -142,7 +147,8 @@ int mnt_vectorinterp_buildLocator(VectorInterp_t **self, int numCellsPerBucket, 
 /* .findPoints(targetPoints (n,3) host, tol2=1.e-12)    field.py:93; *numNotFound (may be NULL) counts points outside */
 int mnt_vectorinterp_findPoints(VectorInterp_t **self, size_t numPoints, const double targetPoints[], double tol2,
                                 size_t *numNotFound);
-/* .getFaceVectors(data (ncell,4) host, placement=0) -> vectors (n,3) host   field.py:94-95,119 */
+/* .getFaceVectors(data (ncell,4) host, placement=0) -> vectors (n,3) host   field.py:94-95,119
+ * Only the rows of the located cells travel to HBM (n x 32 B); same bits as ...getFaceVectorsDev on the whole array. */
 int mnt_vectorinterp_getFaceVectors(VectorInterp_t **self, const double data[], int placement, double vectors[]);
 /* extensions: data resident in HBM (layout 0 = (ncell,4), 1 = the engine's [4][ncell] planes); located cells */
 int mnt_vectorinterp_getFaceVectorsDev(VectorInterp_t **self, const double *data_dev, int layout, double vectors[]);

@@ -157,6 +157,14 @@ using namespace nf;
 
 // 1 = compute_all may put all time steps of a small grid into one launch per kernel ("batch_steps" tuning knob)
 static int g_batch_steps = 1;
+// nf_tuning_set knobs of this file (the library reads no environment variable):
+//   "batch_cellsteps_m"    the all-steps-in-one-launch form is used while nt*ncell stays under this many Mi cell-steps (32)
+//   "partial_step_planes"  1 = a rank's PARTIAL time steps keep the six-plane epilogue (the code before round 4: the before
+//                          leg of profiles/r04_rank_emulation.txt); 0 = signed planes only (default)
+//   "graph"                0 = nf_field_compute_all_async never replays a captured graph of the pass (default 1)
+static long g_batch_cellsteps = 32l << 20;
+static int g_partial_full = 0;
+static int g_use_graph = 1;
 
 // =============================================================================================== plumbing
 extern "C" {
@@ -251,6 +259,19 @@ try {
     if (!strcmp(name, "edge_weights")) {   // K3 on the engine's planes: 1 = unique-edge entries (built by the next
                                            // nf_field_build_weights), 0 = (cell, 4 weights) records (default)
         integral_use_edges(value);
+        return NF_OK;
+    }
+    if (!strcmp(name, "batch_cellsteps_m")) {
+        NF_REQUIRE(value >= 0 && value <= 2047, NF_ERR_ARG, "nf_tuning_set: batch_cellsteps_m must be in [0, 2047]");
+        g_batch_cellsteps = (long)value << 20;
+        return NF_OK;
+    }
+    if (!strcmp(name, "partial_step_planes")) {
+        g_partial_full = value != 0;
+        return NF_OK;
+    }
+    if (!strcmp(name, "graph")) {
+        g_use_graph = value != 0;
         return NF_OK;
     }
     if (!strcmp(name, "datagen_rows")) {   // generator: 1 = the row kernel (default), 0 = one cell per lane with plain division
@@ -962,10 +983,9 @@ static int field_step_async(nf_field *f, long t, double *row_dev)
     // partial sums: its south / west copies and |.| planes mean nothing (only a step owned whole has full-field outputs),
     // the transect reduction reads the two signed planes only, so the step runs in the signed-only form and the four derived
     // planes are written on demand (read_step / device_ptr), exactly as in the compact mode.  0.116 ms per such launch at
-    // the C4 size; the rows are bit-identical (test_slab_sharding_sums_to_full).  NF_PARTIAL_STEP_PLANES=full keeps the
+    // the C4 size; the rows are bit-identical (test_slab_sharding_sums_to_full).  nf_tuning_set("partial_step_planes", 1) keeps the
     // six-plane epilogue on partial steps (the before / after measurement of profiles/r04_rank_emulation.txt).
-    static const bool partial_full = getenv("NF_PARTIAL_STEP_PLANES") && !strcmp(getenv("NF_PARTIAL_STEP_PLANES"), "full");
-    const bool partial = (z0 > 0 || z1 < (int)f->nz) && !partial_full;
+    const bool partial = (z0 > 0 || z1 < (int)f->nz) && !g_partial_full;
     a.signed_only = (f->compact || partial) && flux_supports_signed_only(a);
     f->derived_stale = a.signed_only != 0;
     if (f->timing) {
@@ -984,12 +1004,8 @@ static int field_step_async(nf_field *f, long t, double *row_dev)
 
 // All nt steps in FOUR launches (flux kernel with blockIdx.y = step, then the three reduction kernels): small grids
 // are launch-bound (4 launches of a few microseconds per step otherwise).  Needs HBM-resident fields and per-step
-// planes (nt x 48 B per cell), so it is used while nt*ncell stays under 32 M cell-steps (NF_BATCH_CELLSTEPS).
-static long batch_cell_steps()
-{
-    static const long v = getenv("NF_BATCH_CELLSTEPS") ? atol(getenv("NF_BATCH_CELLSTEPS")) : (32l << 20);
-    return v;
-}
+// planes (nt x 48 B per cell), so it is used while nt*ncell stays under 32 Mi cell-steps ("batch_cellsteps_m").
+static long batch_cell_steps() { return g_batch_cellsteps; }
 
 static bool field_can_batch(const nf_field *f)
 {
@@ -1437,8 +1453,7 @@ try {
     if (field_can_batch(f)) return field_all_steps_batched(f, rows_dev);
     // Replay a captured graph of the whole pass when nothing changed since it was captured.  Capture needs a real
     // (non-null) stream, resident fields, and no per-launch timing events.
-    static const bool use_graph = !(getenv("NF_GRAPH") && atoi(getenv("NF_GRAPH")) == 0);
-    const bool can_graph = use_graph && f->stream != nullptr && f->uv_on_device && !f->timing;
+    const bool can_graph = g_use_graph && f->stream != nullptr && f->uv_on_device && !f->timing;
     if (can_graph && f->graph_exec && f->graph_rows == rows_dev && f->graph_version == f->version + tuning_version()) {
         NF_HIP(hipGraphLaunch(f->graph_exec, f->stream));
         return NF_OK;

@@ -123,7 +123,9 @@ __device__ inline void store_cells(long c0, const double *eU, const double *eV, 
                 for (int k = 0; k < VEC; k += 2) store2<NTS>(p0 + c0 + nx + k, eV[k], eV[k + 1], al);
             }
             // west slots of the cells to the right: shifted by one (8 B stores; the row's last cell wraps to
-            // column 0, field.py:223)
+            // column 0, field.py:223).  The lane-shifted 16-byte form of k_flux_field was measured here too (round 5,
+            // profiles/r05_west_shift.txt): float64 -0.3 % at the headline size, inside the noise -- not taken, the
+            // headline kernel keeps the instruction stream it has had since round 2
 #pragma unroll
             for (int k = 0; k < VEC; ++k) store1<NTS>(p3 + ((i0 + k + 1 < nx) ? c0 + k + 1 : c0 + k + 1 - nx), eU[k]);
         } else {
@@ -476,8 +478,11 @@ static int g_xcd_map = 1;
 static int g_variant = 0;
 // "field_split": -1 = by the size of the launch (default), 0 = never, 1 = always
 static int g_field_split = -1;
-// "west_shift": 1 = the one-field kernel builds the west slots from lane-shifted values (aligned 16-byte stores)
-static int g_west_shift = 0;
+// "west_shift": 1 (default) = the one-field kernel builds the west slots from lane-shifted values (aligned 16-byte stores);
+// 0 = 8-byte stores at a 16 / 32-byte lane stride, the form before round 5.  In-process A/B on the ORCA025-like step
+// (profiles/r05_west_shift.txt): float32 0.1585 -> 0.1549 ms (-2.3 %), WRITE_SIZE 1.38 -> 1.23 x the algorithmic store
+// bytes; float64 0.2816 -> 0.2797 ms (-0.7 %), 1.048 -> 1.010 x.  Bit-identical planes (test_field_split_bit_identical).
+static int g_west_shift = 1;
 // One-step launches with fewer wavefronts than this take the one-field form (about four rounds of resident wavefronts).
 // tools/size_sweep.py, profiles/r04_size_sweep.txt: 1440 x 1021 x 75 (11 488 / 5 744 wavefronts at float64 / float32) gains
 // 17 % / 41 %, 2160 x 1080 (18 225 / 9 112) 2 % / 8 %, 3600 x 1800 (50 656 / 25 312) loses 2 %
@@ -537,7 +542,8 @@ static int launch_flux_field(const FluxArgs &a, hipStream_t s)
     const bool two = (T)a.fill2 == (T)a.fill2 && !((T)a.fill2 == (T)a.fill);
     if (a.signed_only)
         return two ? launch_flux_field_t<T, VEC, kLevels, true, true>(a, s) : launch_flux_field_t<T, VEC, kLevels, true, false>(a, s);
-    if (g_west_shift && VEC > 1 && !two) return launch_flux_field_t<T, VEC, kLevels, false, false, true>(a, s);
+    if (g_west_shift && VEC > 1)
+        return two ? launch_flux_field_t<T, VEC, kLevels, false, true, true>(a, s) : launch_flux_field_t<T, VEC, kLevels, false, false, true>(a, s);
     return two ? launch_flux_field_t<T, VEC, kLevels, false, true>(a, s) : launch_flux_field_t<T, VEC, kLevels, false, false>(a, s);
 }
 

@@ -174,3 +174,63 @@ def test_multi_gpu_start_up_is_bounded():
     assert rc0 != 0 and 'rows' not in so0, (so0, se0[-2000:])
     assert 'did not finish within 5 s' in se0 or 'imed out' in se0 or 'timeout' in se0.lower(), se0[-3000:]
     assert time.time() - t0 < 80
+
+
+def test_visible_gpu_count_reads_the_kfd_topology(tmp_path, monkeypatch):
+    """bench.py's launcher counts GPUs without touching HIP: the KFD topology in sysfs (round-4 verdict W6).  A fake tree with
+    8 GPU nodes and 1 CPU node (simd_count 0), one GPU node's properties unreadable (a GPU of the host that the container's
+    device cgroup hides): 7; narrowed by HIP_VISIBLE_DEVICES; 0 without a KFD node; None when sysfs cannot be read at all."""
+    import builtins
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(k, raising=False)
+    nodes = tmp_path / 'kfd' / 'kfd' / 'topology' / 'nodes'
+    for n in range(9):
+        d = nodes / str(n)
+        d.mkdir(parents=True)
+        simd = 0 if n == 0 else 1024
+        (d / 'properties').write_text(f'cpu_cores_count {96 if n == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\ngfx_target_version 90500\n')
+    hidden = str(nodes / '5' / 'properties')
+    real_open = builtins.open
+
+    def guarded(path, *a, **kw):      # the test may run as root, which chmod does not stop
+        if str(path) == hidden:
+            raise PermissionError(13, 'Operation not permitted', hidden)
+        return real_open(path, *a, **kw)
+    monkeypatch.setattr(bench, 'open', guarded, raising=False)
+    kfd = str(tmp_path / 'kfd')
+    assert bench.visible_gpu_count(kfd) == 7
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1,2,3')
+    assert bench.visible_gpu_count(kfd) == 4
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1,2,3,4,5,6,7,8,9')
+    assert bench.visible_gpu_count(kfd) == 7                       # the variable cannot add devices
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '')
+    assert bench.visible_gpu_count(kfd) == 0
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    assert bench.visible_gpu_count(str(tmp_path / 'no_such_kfd')) == 0
+    (nodes / '3' / 'properties').write_text('simd_count many\n')   # unparsable: the count is unknown, not a guess
+    assert bench.visible_gpu_count(kfd) is None
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '0,1')
+    assert bench.visible_gpu_count(kfd) == 2
+
+
+def test_rank_environment_is_set_by_the_rank_itself(monkeypatch):
+    """Both ways of starting N ranks (`python bench.py --gpus N` and `torchrun ... bench.py --gpus N`) run the same ranks: what
+    a rank needs in its environment is set by nemoflux_amd.dist.rank_environment(), first thing in init_from_env, and the
+    launcher adds nothing of its own.  Values already present win."""
+    import inspect
+    sys.path.insert(0, ROOT)
+    import bench
+    from nemoflux_amd import dist as nfdist
+    for k in ('HSA_ENABLE_IPC_MODE_LEGACY', 'NF_DIST_TIMEOUT_S', 'WORLD_SIZE'):
+        monkeypatch.delenv(k, raising=False)
+    nfdist.rank_environment()
+    assert os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and os.environ['NF_DIST_TIMEOUT_S'] == '300'
+    monkeypatch.setenv('NF_DIST_TIMEOUT_S', '17')
+    nfdist.rank_environment()
+    assert os.environ['NF_DIST_TIMEOUT_S'] == '17' and nfdist.startup_timeout_s() == 17.0
+    assert nfdist.collective_timeout_s() == 1800.0                 # the run-time bound is a different one
+    src = inspect.getsource(bench.self_launch)
+    assert 'setdefault' not in src and 'env=' not in src           # the launcher hands its own environment down unchanged
+    assert inspect.getsource(nfdist.init_from_env).split('rank_environment()')[0].count('torch.cuda') == 0

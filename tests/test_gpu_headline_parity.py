@@ -30,7 +30,7 @@ BOX = (-180., 180., -90., 90., 0., 1.)
 @contextlib.contextmanager
 def _knobs(**kw):
     from nemoflux_amd._lib import lib, check
-    defaults = dict(xcd_map=1, flux_variant=0, field_split=-1, west_shift=0)
+    defaults = dict(xcd_map=1, flux_variant=0, field_split=-1, west_shift=1)
     try:
         for k, v in kw.items():
             check(lib.nf_tuning_set(k.encode(), int(v)))
@@ -113,8 +113,8 @@ def test_headline_kernel_bit_exact_vs_oracle_at_c4_size(real, oracle):
                 with _knobs(field_split=1):
                     case.check(f'{real} one field per wavefront xcd_map={xcd}')
                     case.check(f'{real} one field per wavefront, compact xcd_map={xcd}', compact=True)
-                    with _knobs(west_shift=1):
-                        case.check(f'{real} one field per wavefront, lane-shifted west slots xcd_map={xcd}')
+                    with _knobs(west_shift=0):
+                        case.check(f'{real} one field per wavefront, 8-byte west-slot stores xcd_map={xcd}')
         case.check(f'{real} sverdrup', sverdrup=True)
         case.check(f'{real} sverdrup compact', sverdrup=True, compact=True)
         # some value the oracle got: the comparison above is not 0 == 0 or nan == nan
