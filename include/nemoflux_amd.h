@@ -111,7 +111,9 @@ int mnt_polylineintegral_buildLocator(PolylineIntegral_t **self, int numCellsPer
  * weights are not defined on: a quad that is not convex in the (lon,lat) plane, one with a corner AT a geographic
  * pole (the cells around the pole of a rotated grid) or one that CONTAINS a pole -- never a silent number.  NF_ERR_ARG naming
  * the segment, too, when some stretch of a target segment lies in two cells that do not hold the same sub-segment (coverage
- * > 1 + 1e-8: overlapping cells, e.g. a date-line-wrapped grid with periodX = 0): that stretch would be counted twice.
+ * > 1 + 1e-8 AND the excess, as a length, > 1e-9 max(1, |coordinates|) degrees: overlapping cells, e.g. a date-line-wrapped
+ * grid with periodX = 0): that stretch would be counted twice.  (The length condition keeps rounding noise on target
+ * segments of ~1e-8 degrees and shorter -- near-duplicate vertices on a grid node -- from refusing a whole line.)
  * mnt_polylineintegral_getCoverage still answers after that error.  Cells with a corner that is not a finite number take
  * part in nothing. */
 int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, const double xyz[],
@@ -121,6 +123,10 @@ int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, 
  * the fraction of every target segment that was (real ORCA grids with a few distorted polar cells far from the
  * transect's physics; mint itself returns a number there, pinned by nothing in the reference). */
 int mnt_polylineintegral_setUnsupportedCells(PolylineIntegral_t **self, int skip);
+/* extension (not in mint): what computeWeights does with a target segment that is covered more than once (see above).
+ * warn = 0 (default): NF_ERR_ARG.  warn = 1: the weights are built as mint would build them -- the stretch counts twice --
+ * and mnt_polylineintegral_getCoverage reports > 1 for the segment (the Python wrapper warns). */
+int mnt_polylineintegral_setOverlappingCells(PolylineIntegral_t **self, int warn);
 /* .getIntegral(data (ncell,4) float64 HOST, placement) -> *result   field.py:102, fluxplot.py:56
  * Host data is staged SPARSELY: only the 32 bytes of every cell the weights touch are gathered (pinned buffer) and sent
  * to HBM -- the cost follows the number of weights, not the size of the grid, like mint's own sparse dot -- and the same
@@ -195,6 +201,8 @@ int nf_field_set_slab_range(nf_field **self, long s_begin, long s_end);
 int nf_field_add_transect(nf_field **self, const double *xyz, int npts, int counterclock, int *transect_id);
 /* same policy switch as mnt_polylineintegral_setUnsupportedCells, for the batched build below; call before build_weights */
 int nf_field_set_unsupported_cells(nf_field **self, int skip);
+/* same policy switch as mnt_polylineintegral_setOverlappingCells, for the batched build below; call before build_weights */
+int nf_field_set_overlapping_cells(nf_field **self, int warn);
 int nf_field_build_weights(nf_field **self, int numCellsPerBucket, double periodX);
 int nf_field_num_transects(nf_field **self, int *n);
 int nf_field_num_segments(nf_field **self, int *nseg_total);             /* over all transects */

@@ -68,6 +68,7 @@ _sig('mnt_polylineintegral_setGrid', [_pp, _h])
 _sig('mnt_polylineintegral_buildLocator', [_pp, ctypes.c_int, ctypes.c_double, ctypes.c_int])
 _sig('mnt_polylineintegral_computeWeights', [_pp, ctypes.c_int, c_double_p, ctypes.c_int])
 _sig('mnt_polylineintegral_setUnsupportedCells', [_pp, ctypes.c_int])
+_sig('mnt_polylineintegral_setOverlappingCells', [_pp, ctypes.c_int])
 _sig('mnt_polylineintegral_getIntegral', [_pp, c_double_p, ctypes.c_int, c_double_p])
 _sig('mnt_polylineintegral_getIntegralDev', [_pp, ctypes.c_void_p, ctypes.c_int, c_double_p, c_double_p])
 _sig('mnt_polylineintegral_getCoverage', [_pp, c_double_p])
@@ -98,6 +99,7 @@ _sig('nf_field_set_compact', [_pp, ctypes.c_int])
 _sig('nf_field_set_slab_range', [_pp, ctypes.c_long, ctypes.c_long])
 _sig('nf_field_add_transect', [_pp, c_double_p, ctypes.c_int, ctypes.c_int, c_int_p])
 _sig('nf_field_set_unsupported_cells', [_pp, ctypes.c_int])
+_sig('nf_field_set_overlapping_cells', [_pp, ctypes.c_int])
 _sig('nf_field_build_weights', [_pp, ctypes.c_int, ctypes.c_double])
 _sig('nf_field_num_transects', [_pp, c_int_p])
 _sig('nf_field_num_segments', [_pp, c_int_p])

@@ -318,6 +318,7 @@ struct PolylineIntegral_t {
     long grid_version = -1;     // the grid build the weights belong to
     int nseg = 0;
     int skip_unsupported = 0;   // mnt_polylineintegral_setUnsupportedCells
+    int overlap_warn = 0;       // mnt_polylineintegral_setOverlappingCells
 };
 
 extern "C" {
@@ -459,6 +460,15 @@ try {
 }
 NF_API_CATCH
 
+int mnt_polylineintegral_setOverlappingCells(PolylineIntegral_t **self, int warn)
+try {
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_polylineintegral_setOverlappingCells: null argument");
+    NF_REQUIRE(warn == 0 || warn == 1, NF_ERR_ARG, "mnt_polylineintegral_setOverlappingCells: policy must be 0 (refuse) or 1 (warn)");
+    (*self)->overlap_warn = warn;
+    return NF_OK;
+}
+NF_API_CATCH
+
 static int polyline_segments(const double *xyz, int npoints, int counterclock, std::vector<double> &segs,
                              std::vector<int> &cc)
 {
@@ -492,7 +502,7 @@ try {
     p->stage.release();
     p->h_cell.clear();
     NF_TRY(build_weights(p->grid->d_xy, p->grid->ncell, segs.data(), cc.data(), p->nseg, p->periodX, &p->ws, nullptr,
-                         p->skip_unsupported));
+                         p->skip_unsupported, p->overlap_warn));
     NF_TRY(dev_alloc(&p->d_tr_off, 2));
     NF_TRY(dev_alloc(&p->d_scratch, (size_t)p->ws.nrec));
     const int off[2] = {0, p->nseg};
@@ -800,6 +810,7 @@ struct nf_field {
     WeightSet ws;
     bool weights_built = false;
     int skip_unsupported = 0;   // nf_field_set_unsupported_cells
+    int overlap_warn = 0;       // nf_field_set_overlapping_cells
     int *d_tr_off = nullptr;
     double *d_scratch = nullptr, *d_row = nullptr;
     Grid_t grid_view;
@@ -1301,6 +1312,15 @@ try {
 }
 NF_API_CATCH
 
+int nf_field_set_overlapping_cells(nf_field **self, int warn)
+try {
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_overlapping_cells: null field");
+    NF_REQUIRE(warn == 0 || warn == 1, NF_ERR_ARG, "nf_field_set_overlapping_cells: policy must be 0 (refuse) or 1 (warn)");
+    (*self)->overlap_warn = warn;
+    return NF_OK;
+}
+NF_API_CATCH
+
 int nf_field_build_weights(nf_field **self, int numCellsPerBucket, double periodX)
 try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_build_weights: null field");
@@ -1317,11 +1337,11 @@ try {
     }
     f->weights_built = false;
     const int bw = build_weights(f->d_xy, f->ncell, segs.data(), cc.data(), (int)cc.size(), periodX, &f->ws, f->stream,
-                                 f->skip_unsupported);
+                                 f->skip_unsupported, f->overlap_warn);
     if (bw != NF_OK) {
         // over-covered segment (overlapping cells): name the transect and its own segment index, not the batch's
         for (size_t q = 0; q < f->ws.coverage.size(); ++q)
-            if (f->ws.coverage[q] > 1.0 + kCoverTol) {
+            if ((long)q == (long)f->ws.over_seg) {
                 size_t p = 0;
                 while (p + 2 < f->tr_off.size() && (size_t)f->tr_off[p + 1] <= q) ++p;
                 char buf[320];

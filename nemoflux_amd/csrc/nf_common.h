@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <cmath>
+#include <initializer_list>
 #include <vector>
 
 #include "../../include/nemoflux_amd.h"
@@ -110,7 +112,22 @@ __device__ inline bool quad_is_finite(const double *v)
     for (int k = 0; k < 8; ++k) ok = ok && (fabs(v[k]) <= 1.7976931348623157e308);
     return ok;
 }
-constexpr double kCoverTol = 1.e-8;   // a target segment covered more than 1 + this is counted twice somewhere: an error
+// A target segment covered more than once is counted twice somewhere (overlapping cells): an error.  Two conditions, both
+// needed (round-4 advisor): the excess in the segment's parameter, cov - 1 > kCoverTol, AND the same excess as a LENGTH,
+// (cov - 1) |d| > kCoverLenTol max(1, |coordinates|) degrees.  The parameter of a sub-segment end carries a rounding error of
+// about eps |coordinates| / |d|: on a target segment of 1e-9 degrees across a cell edge that is 1e-6 in t -- the two cells'
+// pieces then no longer match within kTolT and the shared stretch counts twice, an excess of up to 5e-7 in t but 1e-15
+// degrees of line.  Real overlaps (a date-line cell with periodX = 0, duplicated cells) double whole cell crossings.
+constexpr double kCoverTol = 1.e-8;
+constexpr double kCoverLenTol = 1.e-9;
+inline bool over_covered(double cov, const double *seg4 /* x0, y0, dx, dy */)
+{
+    if (!(cov > 1.0 + kCoverTol)) return false;
+    const double len = std::sqrt(seg4[2] * seg4[2] + seg4[3] * seg4[3]);
+    double m = 1.0;
+    for (double c : {seg4[0], seg4[1], seg4[0] + seg4[2], seg4[1] + seg4[3]}) m = std::fabs(c) > m ? std::fabs(c) : m;
+    return (cov - 1.0) * len > kCoverLenTol * m;
+}
 
 // ---- launchers (defined in the .hip files) ----------------------------------------------------------
 // K0: geometry.  bounds (ncell,4) of T -> corner table xy (ncell,4,2), arc (ncell,4), arcE/arcN (ncell),
@@ -168,6 +185,7 @@ struct WeightSet {  // device-resident result: one record per (target segment, c
     // host: fraction of every target segment that lies inside cells of the grid (sum of coef*(tb-ta) over its records);
     // 1 = inside the grid, each point counted once; < 1 = part of the segment is outside (contributes 0, like mint)
     std::vector<double> coverage;
+    int over_seg = -1;         // first target segment build_weights found covered more than once (over_covered), or -1
     // Unique-edge form for the engine's own planes (fold_weights): the south / west slots of integratedVelocity are copies
     // of the neighbours' north / east values (field.py:219-223), so every (cell, edge) weight is folded onto the element
     // of the two signed planes that really carries it and duplicates are merged per target segment (adjacent cells
@@ -190,8 +208,10 @@ int weights_to_host(const WeightSet &ws, int64_t *cell_edge, double *weight, int
 // segs_host: (nseg,4) = x0,y0,dx,dy ; seg_cc_host: counterclock flag per segment
 // skip_unsupported: 0 = a target segment that overlaps a non-convex / pole-vertex cell is an error (default); 1 = such
 // cells contribute nothing and the segment's coverage is < 1
+// overlap_warn: 0 = a target segment covered more than once (over_covered) is an error (default); 1 = the build goes through,
+// out->over_seg names the first such segment and the coverage says how much (the caller warns)
 int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
-                  double periodX, WeightSet *out, hipStream_t s, int skip_unsupported = 0);
+                  double periodX, WeightSet *out, hipStream_t s, int skip_unsupported = 0, int overlap_warn = 0);
 
 // K3: gather + wavefront segmented reduction -> per-segment sums, then per-transect sums.
 // row: (nseg + ntransect) doubles in HBM; tr_offsets_dev: (ntransect+1) segment offsets.

@@ -191,6 +191,61 @@ constexpr int kTaBits = 40;
 constexpr unsigned long long kTaOne = 1ull << kTaBits;
 constexpr unsigned long long kTaWindow = 112;  // > kTolT * 2^40 + 1
 
+// The clip stage of k_clip for up to 64 queued (image, cell-of-this-wave's-tile) pairs, one per lane, in queue order -- which
+// is (image, lane) order, the order the records of a tile have always been written in.  tile_xy: the tile's 64 unwrapped
+// corner rows in LDS; tile_c0: its first cell.  Returns the number of records of the batch (wave-uniform).
+template <bool FILL>
+__device__ inline int clip_pairs(volatile int *wq, int q_head, int n, const double *tile_xy, long tile_c0,
+                                 const double *__restrict__ segs, const int *__restrict__ seg_cc, int nshift, double periodX,
+                                 long base, Records rec, unsigned long long *__restrict__ err, int lane,
+                                 unsigned long long lt_mask)
+{
+    bool hit = false;
+    double ta = 0.0, tb = 0.0, qx = 0.0, qy = 0.0, dx = 0.0, dy = 0.0;
+    double vv[8];
+    int s = 0, cl = 0;
+    if (lane < n) {
+        const int e = wq[(q_head + lane) & (2 * kWave - 1)];
+        const int im = e >> 6;
+        cl = e & (kWave - 1);
+        s = im / nshift;
+        const int k = im - s * nshift;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vv[i] = tile_xy[cl * 8 + i];
+        dx = segs[4 * s + 2];
+        dy = segs[4 * s + 3];
+        qx = segs[4 * s] + (nshift == 3 ? k - 1 : 0) * periodX;
+        qy = segs[4 * s + 1];
+        hit = clip_cell(vv, qx, qy, dx, dy, ta, tb);
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (FILL && hit) {
+        const long pos = base + __popcll(mask & lt_mask);
+        const long c = tile_c0 + cl;
+        double a0, a1, b0, b1;
+        bool ok = inv_bilinear(vv, qx + ta * dx, qy + ta * dy, a0, a1);
+        ok = inv_bilinear(vv, qx + tb * dx, qy + tb * dy, b0, b1) && ok;
+        if (!ok) flag_cell(err, c, 2, s);
+        const double d0 = b0 - a0, d1 = b1 - a1;
+        const double m0 = 0.5 * (a0 + b0), m1 = 0.5 * (a1 + b1);
+        double w0 = d0 * (1.0 - m1), w1 = d1 * m0, w2 = d0 * m1, w3 = d1 * (1.0 - m0);
+        if (seg_cc[s]) {
+            w2 = -w2;
+            w3 = -w3;
+        }
+        unsigned long long q = (unsigned long long)(ta * (double)kTaOne);
+        if (q >= kTaOne) q = kTaOne - 1;
+        rec.key[pos] = ((unsigned long long)s << kTaBits) | q;
+        rec.cell[pos] = (int)c;
+        rec.ta[pos] = ta;
+        rec.tb[pos] = tb;
+        double2 *pw = reinterpret_cast<double2 *>(rec.w + 4 * pos);
+        pw[0] = make_double2(w0, w1);
+        pw[1] = make_double2(w2, w3);
+    }
+    return __popcll(mask);
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, long ncell,
                                                  const double *__restrict__ segs,
@@ -218,6 +273,8 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
     for (int k = 0; k < 8; ++k) v[k] = valid ? s_xy[tid * 8 + k] : 0.0;
     valid = valid && quad_is_finite(v);            // NaN / infinite corners: not a cell
     unwrap_quad(v, nshift == 3 ? periodX : 0.0);   // date-line cells (nf_common.h)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_xy[tid * 8 + k] = v[k];   // the clip stage below reads ANY cell of the wave's tile from LDS
     if (valid) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -259,6 +316,11 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
         bymin = fmin(bymin, s_box[2][w]);
         bymax = fmax(bymax, s_box[3][w]);
     }
+    // per-wave queue of (image << 6 | lane) pairs waiting for the clip (ring of kQueue entries, wave-private: no barrier)
+    constexpr int kQueue = 2 * kWave;
+    __shared__ int s_queue[kBlock / kWave][kQueue];
+    volatile int *wq = s_queue[tid / kWave];
+    int q_head = 0, q_tail = 0;
     const int nimg = nseg * nshift;
     for (int chunk = 0; chunk < nimg; chunk += kBlock) {
         const int img = chunk + tid;
@@ -309,44 +371,50 @@ __global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, 
             const double sxmin = qx < qx + dx ? qx : qx + dx, sxmax = qx < qx + dx ? qx + dx : qx;
             const double symin = qy < qy + dy ? qy : qy + dy, symax = qy < qy + dy ? qy + dy : qy;
             if (wxmin > sxmax || wxmax < sxmin || wymin > symax || wymax < symin) continue;  // wave-uniform
-            bool hit = valid && !(cxmin > sxmax + slack || cxmax < sxmin - slack || cymin > symax + slack ||
-                                  cymax < symin - slack);
-            double ta = 0.0, tb = 0.0;
-            if (hit && nonconvex) {   // not a cell the weights are defined on: refuse if the line really crosses it
+            bool pass = valid && !(cxmin > sxmax + slack || cxmax < sxmin - slack || cymin > symax + slack ||
+                                   cymax < symin - slack);
+            // Level 3a, one lane per cell: is the cell's corner set entirely on one side of the target LINE, by more than
+            // 1e-9 x the size of the coordinates (a thousand times the clip's own distance tolerance)?  Then the clip below
+            // finds nothing either -- whatever the quad's shape: it lies in the hull of its corners -- and the cell drops
+            // out here, for four cross products.  A long segment's bounding box holds whole tiles of cells it never touches.
+            if (pass) {
+                double M = dmax2(dmax2(fabs(qx), fabs(qy)), dmax2(fabs(qx + dx), fabs(qy + dy)));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) M = dmax2(M, fabs(v[i]));
+                const double m2 = (1.e-9 * M) * (1.e-9 * M) * (dx * dx + dy * dy);
+                bool all_pos = true, all_neg = true;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double sd = dx * (v[2 * i + 1] - qy) - dy * (v[2 * i] - qx);
+                    const bool far = sd * sd > m2;
+                    all_pos = all_pos && far && sd > 0.0;
+                    all_neg = all_neg && far && sd < 0.0;
+                }
+                pass = !(all_pos || all_neg);
+            }
+            if (pass && nonconvex) {   // not a cell the weights are defined on: refuse if the line really crosses it
                 // (skip policy: the cell contributes nothing and the segment's coverage says so)
                 if (!FILL && !skip_unsupported && segment_overlaps_quad(v, qx, qy, dx, dy)) flag_cell(err, c, 1, s);
-                hit = false;
+                pass = false;
             }
-            if (hit) hit = clip_cell(v, qx, qy, dx, dy, ta, tb);
-            const unsigned long long mask = __ballot(hit);
-            if (mask == 0ull) continue;
-            if (FILL && hit) {
-                const long pos = (long)base + count + __popcll(mask & lt_mask);
-                double a0, a1, b0, b1;
-                bool ok = inv_bilinear(v, qx + ta * dx, qy + ta * dy, a0, a1);
-                ok = inv_bilinear(v, qx + tb * dx, qy + tb * dy, b0, b1) && ok;
-                if (!ok) flag_cell(err, c, 2, s);
-                const double d0 = b0 - a0, d1 = b1 - a1;
-                const double m0 = 0.5 * (a0 + b0), m1 = 0.5 * (a1 + b1);
-                double w0 = d0 * (1.0 - m1), w1 = d1 * m0, w2 = d0 * m1, w3 = d1 * (1.0 - m0);
-                if (seg_cc[s]) {
-                    w2 = -w2;
-                    w3 = -w3;
-                }
-                unsigned long long q = (unsigned long long)(ta * (double)kTaOne);
-                if (q >= kTaOne) q = kTaOne - 1;
-                rec.key[pos] = ((unsigned long long)s << kTaBits) | q;
-                rec.cell[pos] = (int)c;
-                rec.ta[pos] = ta;
-                rec.tb[pos] = tb;
-                double2 *pw = reinterpret_cast<double2 *>(rec.w + 4 * pos);
-                pw[0] = make_double2(w0, w1);
-                pw[1] = make_double2(w2, w3);
+            // Level 3b, one lane per (cell, image) PAIR: the cells that are left -- one to three of a tile's 64 -- are queued
+            // in (image, lane) order, and the expensive part (the clip's four divisions, in the fill pass two Newton
+            // solves) runs on 64 queued pairs at a time with every lane busy, instead of once per image with two lanes busy.
+            const unsigned long long pmask = __ballot(pass);
+            if (pmask == 0ull) continue;
+            if (pass) wq[(q_tail + __popcll(pmask & lt_mask)) & (kQueue - 1)] = (im << 6) | lane;
+            q_tail += __popcll(pmask);
+            while (q_tail - q_head >= kWave) {
+                count += clip_pairs<FILL>(wq, q_head, kWave, s_xy + (tid - lane) * 8, c0 + (tid - lane), segs, seg_cc, nshift,
+                                          periodX, base + count, rec, err, lane, lt_mask);
+                q_head += kWave;
             }
-            count += __popcll(mask);
         }
         __syncthreads();  // s_hits is reused by the next chunk
     }
+    if (q_tail > q_head)
+        count += clip_pairs<FILL>(wq, q_head, q_tail - q_head, s_xy + (tid - lane) * 8, c0 + (tid - lane), segs, seg_cc, nshift,
+                                  periodX, base + count, rec, err, lane, lt_mask);
     if (!FILL && lane == 0 && wave_id * kWave < ncell) wave_cnt[wave_id] = count;
 }
 
@@ -520,6 +588,7 @@ void WeightSet::release()
     if (seg) (void)hipFree(seg);
     if (seg_start) (void)hipFree(seg_start);
     coverage.clear();
+    over_seg = -1;
     cell = nullptr;
     w4 = nullptr;
     seg = nullptr;
@@ -607,7 +676,7 @@ int fold_weights(WeightSet *ws, long ncell, long nx, hipStream_t s)
 }
 
 int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
-                  double periodX, WeightSet *out, hipStream_t s, int skip_unsupported)
+                  double periodX, WeightSet *out, hipStream_t s, int skip_unsupported, int overlap_warn)
 {
     out->release();
     out->nseg = nseg;
@@ -726,7 +795,9 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     // A stretch of a target segment found in two cells that do not hold the SAME sub-segment (overlapping cells) would be
     // counted twice: refuse, naming the segment.  The coverage stays readable (getCoverage) so the caller can see how much.
     for (int q = 0; q < nseg; ++q)
-        if (out->coverage[(size_t)q] > 1.0 + kCoverTol) {
+        if (over_covered(out->coverage[(size_t)q], segs_host + 4 * q)) {
+            out->over_seg = q;
+            if (overlap_warn) break;    // policy 'warn': the numbers stand, the coverage and over_seg tell the caller
             char buf[320];
             snprintf(buf, sizeof buf,
                      "computeWeights: target segment %d is covered %.9g times by the cells of the grid: cells overlap along it "
@@ -736,6 +807,7 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
             std::vector<double> keep = out->coverage;
             out->release();                 // no records, no segments: nothing a later getIntegral could launch on
             out->coverage.swap(keep);       // ... but the coverage stays readable (its size says how many segments it is for)
+            out->over_seg = q;
             return NF_ERR_ARG;
         }
     return NF_OK;

@@ -130,7 +130,7 @@ class Field(object):
         """Same positional signature as the reference (field.py:17).  tFile/uFile/vFile: NetCDF-4 files (read by
         nemoflux_amd.io / hdf5min; compressed uo/vo one time step at a time) or the .npz bundles of
         nemoflux_amd.datagen / subsetnemo; see fromArrays for in-memory / HBM data and _setup for the keywords
-        (fill_value, periodX, slab_range, readback, compact, stream, unsupportedCells, ...)."""
+        (fill_value, periodX, slab_range, readback, compact, stream, unsupportedCells, overlappingCells, ...)."""
         t = open_tfile(tFile)
         if 'deptht_bounds' not in t:
             raise RuntimeError(f'ERROR: {tFile} has no variable deptht_bounds')
@@ -165,7 +165,7 @@ class Field(object):
                fill_value=numpy.nan, missing_value=numpy.nan, periodX=360., numCellsPerBucket=128, slab_range=None,
                readback=True,
                timeValues=None, stream=None, timeObj=None, compact=False, prefetch=True, gpu_decode=True,
-               unsupportedCells='refuse'):
+               unsupportedCells='refuse', overlappingCells='refuse'):
         _lib.require_gpu()
         self.sverdrup = sverdrup
         self.periodX = periodX
@@ -260,6 +260,10 @@ class Field(object):
             raise RuntimeError("ERROR: unsupportedCells must be 'refuse' or 'skip'")
         if unsupportedCells == 'skip':   # non-convex / pole-vertex cells drop out; the coverage warning below reports it
             check(lib.nf_field_set_unsupported_cells(ctypes.byref(self._h), 1))
+        if overlappingCells not in ('refuse', 'warn'):
+            raise RuntimeError("ERROR: overlappingCells must be 'refuse' or 'warn'")
+        if overlappingCells == 'warn':   # a stretch of a line found in two overlapping cells counts twice; the warning below says so
+            check(lib.nf_field_set_overlapping_cells(ctypes.byref(self._h), 1))
         check(lib.nf_field_build_weights(ctypes.byref(self._h), int(numCellsPerBucket), float(periodX)))
         n = ctypes.c_int()
         check(lib.nf_field_num_segments(ctypes.byref(self._h), ctypes.byref(n)))
@@ -270,9 +274,16 @@ class Field(object):
         self._rowlen = n.value
         self._row = numpy.zeros(max(self._rowlen, 1), numpy.float64)
         self._row_valid = False
-        # coverage > 1 (overlapping cells: a stretch of the line would be counted twice) was refused by build_weights above;
-        # coverage < 1 means part of the line lies in no cell: mint only warns there [recall], and so does this
+        # coverage > 1 (overlapping cells: a stretch of the line would be counted twice) was refused by build_weights above
+        # unless overlappingCells='warn'; coverage < 1 means part of the line lies in no cell: mint only warns there [recall],
+        # and so does this
         for i, cov in enumerate(self.getCoverage()):
+            over = numpy.nonzero(cov > 1.0 + 1.e-8)[0] if overlappingCells == 'warn' else numpy.zeros(0, int)
+            if over.size:
+                import warnings
+                warnings.warn(f'transect {i}: {over.size} of {cov.size} target segments are covered more than once by the cells '
+                              f'of the grid (up to {cov[over].max():.9g} times, first: segment {over[0]}): that part of the line '
+                              f'is counted twice', RuntimeWarning, stacklevel=3)
             low = numpy.nonzero(cov < 1.0 - 1.e-8)[0]
             if low.size:
                 import warnings

@@ -97,6 +97,14 @@ class PolylineIntegral(object):
         self.numSegments = xyz.shape[0] - 1
         check(lib.mnt_polylineintegral_computeWeights(ctypes.byref(self.obj), xyz.shape[0], _lib.dptr(xyz),
                                                       1 if counterclock else 0))
+        if getattr(self, '_overlap_warn', False):
+            cov = self.getCoverage()
+            over = numpy.nonzero(cov > 1.0 + 1.e-8)[0]
+            if over.size:
+                import warnings
+                warnings.warn(f'{over.size} of {cov.size} target segments are covered more than once by the cells of the grid '
+                              f'(up to {cov[over].max():.9g} times, first: segment {over[0]}): that part of the line is counted '
+                              f'twice', RuntimeWarning, stacklevel=2)
 
     def getIntegral(self, data, placement=CELL_BY_CELL_DATA):
         """data: float64 (ncell, 4) [or flat]; host numpy (staged over PCIe) or HBM-resident
@@ -122,6 +130,15 @@ class PolylineIntegral(object):
         if policy not in ('refuse', 'skip'):
             raise RuntimeError("ERROR: policy must be 'refuse' or 'skip'")
         check(lib.mnt_polylineintegral_setUnsupportedCells(ctypes.byref(self.obj), 1 if policy == 'skip' else 0))
+
+    def setOverlappingCells(self, policy='refuse'):
+        """What computeWeights does when a stretch of the line lies in two cells that do not hold the same sub-segment
+        (overlapping cells: it would be counted twice): 'refuse' (default) raises, 'warn' builds the weights as they come
+        and warns -- getCoverage() then reports > 1 for the segments concerned."""
+        if policy not in ('refuse', 'warn'):
+            raise RuntimeError("ERROR: policy must be 'refuse' or 'warn'")
+        self._overlap_warn = policy == 'warn'
+        check(lib.mnt_polylineintegral_setOverlappingCells(ctypes.byref(self.obj), 1 if policy == 'warn' else 0))
 
     def getCoverage(self):
         """Fraction of every target segment that lies inside cells of the grid (1 = inside, each point counted once)."""

@@ -147,7 +147,9 @@ void nfo_edge_flux(const double *uInt, const double *vInt, const double *arc /* 
 #define NFO_TOL_DIST_REL 1.e-12 /* on-the-edge distance tolerance, relative to max |coordinate| */
 #define NFO_TOL_T 1.e-10        /* min sub-segment length / interval matching tolerance, in t */
 #define NFO_NEWTON_MAX 16
-#define NFO_COVER_TOL 1.e-8     /* a target segment covered more than 1 + this is counted twice somewhere: an error */
+#define NFO_COVER_TOL 1.e-8     /* a target segment covered more than 1 + this is counted twice somewhere: an error ... */
+#define NFO_COVER_LEN_TOL 1.e-9 /* ... provided the excess, as a length, exceeds this x max(1, |coordinates|) degrees (the rounding
+                                   of t on target segments of ~1e-8 degrees and shorter is not an overlap of cells) */
 
 typedef struct {
     int seg;
@@ -443,6 +445,11 @@ long nfo_polyline_weights(const double *points, long ncell, const double *xyz, i
         if (coverage) for (int q = 0; q + 1 < npts; ++q) coverage[q] = cov[q];
         for (int q = 0; q + 1 < npts; ++q)
             if (cov[q] > 1.0 + NFO_COVER_TOL) {
+                const double ddx = xyz[3 * (q + 1)] - xyz[3 * q], ddy = xyz[3 * (q + 1) + 1] - xyz[3 * q + 1];
+                double m = 1.0;
+                const double cs[4] = {xyz[3 * q], xyz[3 * q + 1], xyz[3 * q] + ddx, xyz[3 * q + 1] + ddy};
+                for (int k = 0; k < 4; ++k) if (fabs(cs[k]) > m) m = fabs(cs[k]);
+                if (!((cov[q] - 1.0) * sqrt(ddx * ddx + ddy * ddy) > NFO_COVER_LEN_TOL * m)) continue;
                 if (status) { status[0] = 3; status[1] = -1; status[2] = q; }
                 free(cov); free(recs);
                 return 0;

@@ -242,3 +242,38 @@ def orca_like_halo_grid(oracle, nx=72, ny=36, x0=73.):
     d = numpy.stack([p1 - p0, p2 - p1, p2 - p3, p3 - p0], axis=-1)           # (ny, nx, 4)
     data = numpy.ascontiguousarray(numpy.concatenate([d[:, -2:], d], axis=1)).reshape(-1, 4)
     return o, pts, wr, psi, data
+
+
+# ---- irregular global grid + tiny target segments on its edges and nodes (round-5: over-coverage is measured as a length) ----
+def irregular_wrapped_grid(oracle, seed=5, nx=72, ny=36):
+    """A global mesh whose nodes are jittered by up to 1.2 degrees (cells abut exactly: they share the jittered nodes), seam
+    column periodic, longitudes wrapped per corner into [-180, 180).  Returns (node lon, node lat, points (ncell,4,3))."""
+    rng = numpy.random.default_rng(seed)
+    xx, yy = numpy.meshgrid(numpy.linspace(0., 360., nx + 1), numpy.linspace(-90., 90., ny + 1))
+    xx = xx + rng.uniform(-1.2, 1.2, xx.shape)
+    yy = yy + rng.uniform(-1.2, 1.2, yy.shape)
+    xx[:, -1] = xx[:, 0] + 360.
+    yy[:, -1] = yy[:, 0]
+    yy[0], yy[-1] = -90., 90.
+    blon = numpy.stack([xx[:-1, :-1], xx[:-1, 1:], xx[1:, 1:], xx[1:, :-1]], axis=-1)
+    blat = numpy.stack([yy[:-1, :-1], yy[:-1, 1:], yy[1:, 1:], yy[1:, :-1]], axis=-1)
+    return xx, yy, oracle.assemble_points(wrap180(blon), blat)
+
+
+def tiny_segment_lines(xx, yy, half, n, seed):
+    """n four-point lines whose middle segment has half-length `half` degrees and is centred on a grid node (even k) or on a
+    point of a cell edge (odd k), direction random; the two outer segments are ordinary ones."""
+    rng = numpy.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        i, j = int(rng.integers(1, xx.shape[1] - 1)), int(rng.integers(2, xx.shape[0] - 2))
+        ang = rng.uniform(0., 2. * numpy.pi)
+        if k % 2 == 0:
+            cx, cy = xx[j, i], yy[j, i]
+        else:
+            s = rng.uniform(0.2, 0.8)
+            cx, cy = xx[j, i] + s * (xx[j, i + 1] - xx[j, i]), yy[j, i] + s * (yy[j, i + 1] - yy[j, i])
+        d = half * numpy.array([numpy.cos(ang), numpy.sin(ang)])
+        out.append(numpy.array([[cx - 7.3, cy - 3.1, 0.], [cx - d[0], cy - d[1], 0.], [cx + d[0], cy + d[1], 0.],
+                                [cx + 5.2, cy + 6.4, 0.]]))
+    return out

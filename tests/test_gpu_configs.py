@@ -1571,6 +1571,64 @@ def test_refuses_double_counting(oracle):
     assert abs(f.computeAll()[0][0, 0] - exactFlux(PSI_CS, [(20., -40.), (100., 30.)], 1, 1)[0]) <= 1e-12
 
 
+def test_tiny_segments_are_not_overlaps_and_the_overlap_policy(oracle):
+    """Round-4 advisor.  (a) Target segments of 1e-7 .. 1e-10 degrees on the edges and nodes of an irregular wrapped grid: the
+    rounding of t (~ eps |coordinates| / |d|) makes the two cells' pieces miss each other's tolerance and the shared stretch
+    count twice -- excess coverage up to 3e-5 in t, 1e-14 degrees of line.  Not refused any more (the excess is measured as a
+    length); weights and coverage equal the oracle's.  (b) overlappingCells='warn': real overlaps (wrapped grid, periodX = 0)
+    go through with a warning and coverage 2, through both surfaces; the default still refuses."""
+    import warnings
+    from conftest import irregular_wrapped_grid, tiny_segment_lines
+    from nemoflux_amd import mint
+    from nemoflux_amd._lib import NemofluxError
+    xx, yy, pts = irregular_wrapped_grid(oracle)
+    grid = mint.Grid()
+    grid.setPoints(pts)
+    noisy = 0
+    for half in (1e-7, 1e-8, 1e-9, 1e-10):
+        for xyz in tiny_segment_lines(xx, yy, half, 60, seed=int(-numpy.log10(half))):
+            pli = mint.PolylineIntegral()
+            pli.setGrid(grid)
+            pli.buildLocator(numCellsPerBucket=128, periodX=360., enableFolding=False)
+            pli.computeWeights(xyz, counterclock=False)                 # raises if refused
+            cov = pli.getCoverage()
+            ow = oracle.polyline_weights(pts, xyz)
+            noisy += cov[1] - 1.0 > 1e-8
+            assert (cov[1] - 1.0) * 2. * half <= 1e-12 and abs(cov[0] - 1.0) <= 1e-9 and abs(cov[2] - 1.0) <= 1e-9
+            ce, w, sg = pli.getWeights()
+            assert ce.size == ow.weight.size
+            gd = {}
+            for a, b, c in zip(sg.tolist(), ce.tolist(), w.tolist()):
+                gd[(a, b)] = gd.get((a, b), 0.0) + c
+            od = ow.as_dict()
+            assert set(gd) == set(od) and max(abs(gd[k] - od[k]) for k in od) <= 1e-12
+    assert noisy > 15
+    # (b) the policy switch
+    dg = device_case(36, 18, 1, 1, PSI_CS, box=(0., 360., -90., 90., 0., 1.))
+    wrapped, blat = wrap180(dg.bounds_lon.cpu().numpy()), dg.bounds_lat.cpu().numpy()
+    probe = transect_xyz("(20,-40),(100,30)")
+    with pytest.raises(RuntimeError, match=r'covered 2 times'):
+        quiet_field(wrapped, blat, dg.deptht_bounds, dg.u, dg.v, [probe], periodX=0.)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        f = quiet_field(wrapped, blat, dg.deptht_bounds, dg.u, dg.v, [probe], periodX=0., overlappingCells='warn')
+    assert any('covered more than once' in str(r.message) for r in rec)
+    assert abs(f.getCoverage()[0][0] - 2.0) <= 1e-9
+    g2 = mint.Grid()
+    g2.setPoints(oracle.assemble_points(wrapped, blat))
+    pli = mint.PolylineIntegral()
+    pli.setGrid(g2)
+    pli.buildLocator(numCellsPerBucket=128, periodX=0., enableFolding=False)
+    with pytest.raises(NemofluxError, match=r'covered 2 times'):
+        pli.computeWeights(probe, counterclock=False)
+    pli.setOverlappingCells('warn')
+    with pytest.warns(RuntimeWarning, match='covered more than once'):
+        pli.computeWeights(probe, counterclock=False)
+    assert abs(pli.getCoverage()[0] - 2.0) <= 1e-9 and numpy.isfinite(pli.getIntegral(numpy.ones((g2.getNumberOfCells(), 4))))
+    with pytest.raises(RuntimeError):
+        pli.setOverlappingCells('ignore')
+
+
 def test_dateline_special_lines_halo_columns_and_nonfinite_corners(oracle):
     """K2 == oracle, entry by entry, on the inputs of test_oracle_dateline_special_lines_and_halo_columns /
     test_oracle_cells_with_nonfinite_corners_are_no_cells: lines along the cut of a wrapped grid and along its seam, an

@@ -643,6 +643,31 @@ def test_oracle_refuses_double_counting(oracle):
     assert numpy.allclose(w.coverage, 1.0, rtol=0, atol=1e-12)
 
 
+def test_oracle_tiny_segments_on_edges_and_nodes_are_not_overlaps(oracle):
+    """Round-4 advisor: the rounding of a sub-segment's parameter t grows as 1 / |segment length|, so on target segments of
+    1e-8 .. 1e-9 degrees across a cell edge or a grid node the pieces found in the two cells stop matching within the t
+    tolerance and the shared stretch counts twice -- an 'excess coverage' of up to 5e-7 in t that is 1e-15 degrees of line.
+    That is rounding noise, not overlapping cells: such a line must not be refused (a closed loop whose points sit on
+    nodes, a line with near-duplicate vertices).  A real overlap still is, however short the segment's neighbours are."""
+    from conftest import irregular_wrapped_grid, tiny_segment_lines
+    xx, yy, pts = irregular_wrapped_grid(oracle)
+    noisy = 0
+    for half in (1e-7, 1e-8, 1e-9, 1e-10):
+        for xyz in tiny_segment_lines(xx, yy, half, 200, seed=int(-numpy.log10(half))):
+            w = oracle.polyline_weights(pts, xyz)                     # raises OverCovered if the line is refused
+            excess = float(w.coverage[1]) - 1.0
+            noisy += excess > 1e-8                                    # what the t-only rule of round 4 refused
+            assert excess * 2. * half <= 1e-12                        # ... is 1e-12 degrees of line at most
+            assert abs(w.coverage[0] - 1.0) <= 1e-9 and abs(w.coverage[2] - 1.0) <= 1e-9      # ordinary neighbours
+    assert noisy > 50                                                 # the case is real on this grid
+    # the real thing is still refused, next to a tiny segment or not
+    quad = lambda x0, x1: [[x0, 0., 0.], [x1, 0., 0.], [x1, 1., 0.], [x0, 1., 0.]]
+    two = numpy.array([quad(0., 2.), quad(1., 3.)])
+    with pytest.raises(oracle.OverCovered) as e:
+        oracle.polyline_weights(two, numpy.array([[0.2, 0.5, 0.], [0.2 + 1e-9, 0.5, 0.], [2.5, 0.5, 0.]]), periodX=0.)
+    assert e.value.seg == 1
+
+
 def test_oracle_dateline_special_lines_and_halo_columns(oracle):
     """Lines that run ALONG the cut of a wrapped global grid (every piece shared by the cell east of 180 E, stored at
     -180, and the un-wrapped cell west of it), along the grid's own seam at 0 / 360, and across the cut both ways: the same
