@@ -74,12 +74,6 @@ struct DevTmp {
     template <typename T> T *as() const { return static_cast<T *>(p); }
 };
 
-#define NF_TRY(call)                  \
-    do {                              \
-        int rc_ = (call);             \
-        if (rc_ != NF_OK) return rc_; \
-    } while (0)
-
 template <typename T>
 static int dev_alloc(T **p, size_t count)
 {

@@ -36,6 +36,12 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         }                                      \
     } while (0)
 
+#define NF_TRY(call)                  \
+    do {                              \
+        int rc_ = (call);             \
+        if (rc_ != NF_OK) return rc_; \
+    } while (0)
+
 // ---- XCD-aware tile mapping -------------------------------------------------------------------------
 // Workgroup b lands on XCD b % 8.  Give every XCD one CONTIGUOUS band of logical tiles so that (a) the
 // neighbour-slot stores of the edge-flux kernel (row j -> row j+1, column i -> i+1) meet the owning row's

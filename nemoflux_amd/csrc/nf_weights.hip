@@ -12,18 +12,23 @@
 // (all edges oriented in +xi: counterclock = False), times 1/n when the same [ta,tb] is found in n cells
 // (a sub-segment running along a shared edge is counted once).
 //
-// Mapping to the hardware.  One wavefront owns 64 consecutive cells.  Their corner table rows (64 x 64 B =
-// 4 KiB contiguous) are read coalesced and staged in LDS, then each lane keeps its own 4 corners in
-// registers for the whole kernel.  The locator has three levels: the 256 lanes of a workgroup clip 256 segment
-// images at a time against the workgroup's box (exact segment-vs-box test) and compact the survivors into an
-// LDS list; each wave then checks the survivors against its own 64-cell box (numCellsPerBucket -> the wave tile)
-// with a uniform branch, and each lane against its cell.  Hits are compacted with ballot/popcount into a deterministic order
-// (tile, segment, shift, lane): pass 1 counts per wave, a single-workgroup scan turns counts into offsets,
-// pass 2 recomputes and writes records.  Records are then stably radix-sorted (rocPRIM) by the 64-bit key
-// (global segment id, ta quantised to 2^-40), the multiplicity is resolved per record against its
-// neighbours in that order (same segment, |dta|,|dtb| <= 1e-10), and each record is written out as
-// (cell, 4 edge weights, segment) -- already in the order K3's wavefront segmented reduction wants.
-// No atomics, so the result is bitwise reproducible run to run.
+// Mapping to the hardware (round 5; until round 4 one wavefront owned 64 cells and walked ALL segment images, two lanes of 64
+// busy in the clip -- 16 / 95 / 723 ms for 65 / 512 / 4096 transects on the ORCA12-like grid, now 4.3 / 15 / 90 ms with the
+// same bits: profiles/r05_weights_scaling.txt).  Everything is one lane per unit of work, compacted with ballot / popcount
+// and a scan between a count pass and a fill pass, so every list has a fixed order and the result is bitwise reproducible:
+//   1. locator (buildLocator): bounding boxes of the cells and of groups of 16, 256, 4096 ... consecutive cells, 16 bytes
+//      each, from one pass over the corner table;
+//   2. walk: (group, segment image) pairs from the root down, one lane per (pair, child): boxes apart? box corners on one
+//      side of the target line? -- no divisions; the last level leaves (cell, image) candidates;
+//   3. clip: one lane per candidate (Cyrus-Beck against the cell's four edges); hits become records (key, cell, image, ta,
+//      tb); a candidate cell the weights are not defined on is refused here;
+//   4. records are stably radix-sorted (rocPRIM) by the 64-bit key (global segment id, ta quantised to 2^-40), runs of equal
+//      keys are put into the engine's historical (64-cell tile, image, cell) order, the multiplicity is resolved per record
+//      against its neighbours in that order (same segment, |dta|,|dtb| <= 1e-10), both ends of the piece are mapped into the
+//      cell (Newton) and each record is written out as (cell, 4 edge weights, segment) -- already in the order K3's wavefront
+//      segmented reduction wants.
+// numCellsPerBucket (field.py:47: 128) has no counterpart to tune: the groups are 16-fold, the leaves single cells.
+// No atomics except the error word.
 #include <cstring>  // rocprim's texture iterator needs host memset declared first
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -171,276 +176,296 @@ __device__ inline void flag_cell(unsigned long long *err, long cell, int kind, i
     atomicMin(err, ((unsigned long long)cell << 32) | ((unsigned long long)kind << 24) | (unsigned)(seg & 0xffffff));
 }
 
-__device__ inline double wmin(double x)
-{
-    for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o, kWave));
-    return x;
-}
-__device__ inline double wmax(double x)
-{
-    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, kWave));
-    return x;
-}
-
 struct Records {  // SoA, device
     unsigned long long *key;  // (segment << 40) | floor(ta * 2^40)
     int *cell;
-    double *ta, *tb, *w;  // w: 4 per record
+    unsigned char *kshift;    // which periodic image of the target segment (0 .. nshift-1) found the cell
+    double *ta, *tb;          // the piece of the target segment inside the cell
 };
 constexpr int kTaBits = 40;
 constexpr unsigned long long kTaOne = 1ull << kTaBits;
 constexpr unsigned long long kTaWindow = 112;  // > kTolT * 2^40 + 1
 
-// The clip stage of k_clip for up to 64 queued (image, cell-of-this-wave's-tile) pairs, one per lane, in queue order -- which
-// is (image, lane) order, the order the records of a tile have always been written in.  tile_xy: the tile's 64 unwrapped
-// corner rows in LDS; tile_c0: its first cell.  Returns the number of records of the batch (wave-uniform).
-template <bool FILL>
-__device__ inline int clip_pairs(volatile int *wq, int q_head, int n, const double *tile_xy, long tile_c0,
-                                 const double *__restrict__ segs, const int *__restrict__ seg_cc, int nshift, double periodX,
-                                 long base, Records rec, unsigned long long *__restrict__ err, int lane,
-                                 unsigned long long lt_mask)
+// ---- the locator: a box hierarchy over the cells, walked breadth-first by all segment images at once ----------------------
+// mint's buildLocator bins the cells into buckets (field.py:47: numCellsPerBucket = 128) and computeWeights asks the buckets a
+// target segment passes through.  Here: the cells in their storage order are grouped 16 by 16 by 16 ... (16 cells, 256, 4096,
+// ... up to one root), every group with the bounding box of its cells (a row-major grid makes these strips of a grid row,
+// then bundles of rows; nothing is assumed about that -- any order gives valid boxes, a coherent one gives small boxes).
+// All (group, segment image) pairs whose box the segment may touch are expanded level by level, ONE LANE PER (pair, child):
+// bounding boxes first, then -- no divisions -- on which side of the target line the box's corners lie.  Every level is a count
+// pass (ballot masks per wavefront), a scan and a fill pass, so the pairs of a level come out in (image, group) order, run to
+// run the same; the last level tests the boxes of the cells and leaves the (cell, image) candidates of the clip stage.
+// The work follows the number of cells the lines cross, not cells x segments: profiles/r05_weights_scaling.txt.
+struct Box4 {
+    float xmin, xmax, ymin, ymax;    // expanded by the slack of the cells inside, then rounded OUTWARD to float (a box only has to
+                                     // hold its cells: 16 bytes per box instead of 32 halve the walk's traffic); xmin > xmax:
+                                     // nothing inside
+};
+__device__ inline Box4 outward(double xmin, double xmax, double ymin, double ymax)
 {
+    return Box4{__double2float_rd(xmin), __double2float_ru(xmax), __double2float_rd(ymin), __double2float_ru(ymax)};
+}
+constexpr int kFan = 16;
+
+// one cell's unwrapped corners, its bounding box and the slack the tests give it; false: not a cell (non-finite corner)
+__device__ inline bool cell_geometry(const double *__restrict__ xy, long c, double period, double *v, double &cxmin,
+                                     double &cxmax, double &cymin, double &cymax, double &slack)
+{
+    const double2 *p = reinterpret_cast<const double2 *>(xy + 8 * c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double2 t = p[k];
+        v[2 * k] = t.x;
+        v[2 * k + 1] = t.y;
+    }
+    cxmin = 1e300, cxmax = -1e300, cymin = 1e300, cymax = -1e300, slack = 0.0;
+    if (!quad_is_finite(v)) return false;   // NaN / infinite corners: not a cell
+    unwrap_quad(v, period);                  // date-line cells (nf_common.h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        cxmin = fmin(cxmin, v[2 * i]);
+        cxmax = fmax(cxmax, v[2 * i]);
+        cymin = fmin(cymin, v[2 * i + 1]);
+        cymax = fmax(cymax, v[2 * i + 1]);
+    }
+    slack = 1.e-9 * (fabs(cxmin) + fabs(cxmax) + fabs(cymin) + fabs(cymax) + 1.0);
+    return true;
+}
+
+// box of kFan consecutive lanes' boxes -> the group's first lane
+__device__ inline Box4 fan_union(double xmin, double xmax, double ymin, double ymax)
+{
+#pragma unroll
+    for (int o = kFan / 2; o > 0; o >>= 1) {
+        xmin = fmin(xmin, __shfl_xor(xmin, o, kFan));
+        xmax = fmax(xmax, __shfl_xor(xmax, o, kFan));
+        ymin = fmin(ymin, __shfl_xor(ymin, o, kFan));
+        ymax = fmax(ymax, __shfl_xor(ymax, o, kFan));
+    }
+    return outward(xmin, xmax, ymin, ymax);
+}
+
+// levels 0 and 1: the box of every cell and of every 16 consecutive cells, from the corner table
+__global__ __launch_bounds__(kBlock) void k_boxes_cells(const double *__restrict__ xy, long ncell, double period,
+                                                        Box4 *__restrict__ box0, Box4 *__restrict__ box1)
+{
+    const long c = (long)blockIdx.x * kBlock + threadIdx.x;
+    double v[8], cxmin = 1e300, cxmax = -1e300, cymin = 1e300, cymax = -1e300, slack = 0.0;
+    if (c < ncell) cell_geometry(xy, c, period, v, cxmin, cxmax, cymin, cymax, slack);
+    // an absent or non-finite cell has an empty box and no slack: it adds nothing to its group
+    if (c < ncell) box0[c] = outward(cxmin - slack, cxmax + slack, cymin - slack, cymax + slack);
+    const Box4 b = fan_union(cxmin - slack, cxmax + slack, cymin - slack, cymax + slack);
+    if ((threadIdx.x & (kFan - 1)) == 0 && c < ncell) box1[c / kFan] = b;
+}
+
+// level l + 1 from level l
+__global__ __launch_bounds__(kBlock) void k_boxes_up(const Box4 *__restrict__ in, long n_in, Box4 *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    Box4 b = outward(1e300, -1e300, 1e300, -1e300);
+    if (i < n_in) b = in[i];
+    b = fan_union(b.xmin, b.xmax, b.ymin, b.ymax);     // floats are doubles: nothing moves
+    if ((threadIdx.x & (kFan - 1)) == 0 && i < n_in) out[i / kFan] = b;
+}
+
+// count pass of a count / scan / fill step: every wavefront leaves its ballot mask, every workgroup the number of set bits
+// of its four masks (the scan then runs over workgroups: a quarter of the entries)
+__device__ inline void block_count(unsigned long long mask, unsigned long long *__restrict__ wmask, int *__restrict__ bcnt)
+{
+    __shared__ int s_c[kBlock / kWave];
+    const int w = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        wmask[(long)blockIdx.x * (kBlock / kWave) + w] = mask;
+        s_c[w] = __popcll(mask);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < kBlock / kWave; ++k) n += s_c[k];
+        bcnt[blockIdx.x] = n;
+    }
+}
+// fill pass: where the set bits of wavefront w of a workgroup start = the workgroup's offset + the bits of the waves before it
+__device__ inline long wave_offset(const unsigned long long *__restrict__ wmask, const long *__restrict__ boff, long block, int w)
+{
+    long pos = boff[block];
+    for (int k = 0; k < w; ++k) pos += __popcll(wmask[block * (kBlock / kWave) + k]);
+    return pos;
+}
+
+struct SegImage {   // one periodic image of a target segment: q + t d, t in [0, 1]
+    double qx, qy, dx, dy;
+    int s, k;
+};
+__device__ inline SegImage load_image(const double *__restrict__ segs, int img, int nshift, double periodX)
+{
+    SegImage g;
+    g.s = img / nshift;
+    g.k = img - g.s * nshift;
+    g.dx = segs[4 * g.s + 2];
+    g.dy = segs[4 * g.s + 3];
+    g.qx = segs[4 * g.s] + (nshift == 3 ? g.k - 1 : 0) * periodX;
+    g.qy = segs[4 * g.s + 1];
+    return g;
+}
+
+// Can the segment touch anything inside the (slack-expanded) box with corners (x0,y0) .. (x1,y1) given as 4 points p?  No, when
+// the bounding boxes are apart, or when the four points lie on one side of the target LINE by more than 1e-9 x the size of
+// the coordinates -- a thousand times the clip's own distance tolerance: whatever lies in the hull of the points is then
+// missed by the clip too.  Conservative, no divisions.
+__device__ inline bool line_may_touch(const SegImage &g, const double *p /* 4 (x,y) pairs */, double xmin, double xmax,
+                                      double ymin, double ymax)
+{
+    const double sxmin = g.dx < 0.0 ? g.qx + g.dx : g.qx, sxmax = g.dx < 0.0 ? g.qx : g.qx + g.dx;
+    const double symin = g.dy < 0.0 ? g.qy + g.dy : g.qy, symax = g.dy < 0.0 ? g.qy : g.qy + g.dy;
+    if (xmin > sxmax || xmax < sxmin || ymin > symax || ymax < symin) return false;
+    double M = dmax2(dmax2(fabs(g.qx), fabs(g.qy)), dmax2(fabs(g.qx + g.dx), fabs(g.qy + g.dy)));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) M = dmax2(M, fabs(p[i]));
+    const double m2 = (1.e-9 * M) * (1.e-9 * M) * (g.dx * g.dx + g.dy * g.dy);
+    bool all_pos = true, all_neg = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double sd = g.dx * (p[2 * i + 1] - g.qy) - g.dy * (p[2 * i] - g.qx);
+        const bool far = sd * sd > m2;
+        all_pos = all_pos && far && sd > 0.0;
+        all_neg = all_neg && far && sd < 0.0;
+    }
+    return !(all_pos || all_neg);
+}
+
+// One level of the walk, count pass: lane t tests child (t % 16) of pair (t / 16) -- the box of a group of the level below or,
+// at the last level, of a cell.  pnode == nullptr: the pairs are (root, image p) for every image.  Writes the ballot mask per
+// wavefront and the number of set bits per workgroup.
+__global__ __launch_bounds__(kBlock) void k_walk_count(const int *__restrict__ pnode, const int *__restrict__ pimg, long np,
+                                                       const Box4 *__restrict__ box, long nchild,
+                                                       const double *__restrict__ segs, int nshift, double periodX,
+                                                       unsigned long long *__restrict__ wmask, int *__restrict__ bcnt)
+{
+    const long t = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long p = t / kFan;
+    bool pass = false;
+    if (p < np) {
+        const long child = (long)(pnode ? pnode[p] : 0) * kFan + (t & (kFan - 1));
+        if (child < nchild) {
+            const SegImage g = load_image(segs, pimg ? pimg[p] : (int)p, nshift, periodX);
+            if (!(g.dx == 0.0 && g.dy == 0.0)) {
+                const Box4 b = box[child];
+                const double c4[8] = {b.xmin, b.ymin, b.xmax, b.ymin, b.xmax, b.ymax, b.xmin, b.ymax};
+                pass = line_may_touch(g, c4, b.xmin, b.xmax, b.ymin, b.ymax);
+            }
+        }
+    }
+    block_count(__ballot(pass), wmask, bcnt);
+}
+
+// fill pass: the children that passed, in (pair, child) order = (image, group) order
+__global__ __launch_bounds__(kBlock) void k_walk_fill(const int *__restrict__ pnode, const int *__restrict__ pimg, long np,
+                                                      const unsigned long long *__restrict__ wmask,
+                                                      const long *__restrict__ boff, int *__restrict__ cnode,
+                                                      int *__restrict__ cimg)
+{
+    // one lane per PAIR (its 16 children are 16 bits of one count-pass mask): a sixteenth of the lanes of the count pass
+    const long p = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (p >= np) return;
+    constexpr int kPairsPerWave = kWave / kFan, kPairsPerBlock = kBlock / kFan;
+    const long cblock = p / kPairsPerBlock;                        // workgroup of the count pass
+    const int w = (int)(p % kPairsPerBlock) / kPairsPerWave, sub = (int)(p % kPairsPerWave);
+    const unsigned long long mask = wmask[cblock * (kBlock / kWave) + w];
+    unsigned bits = (unsigned)(mask >> (kFan * sub)) & ((1u << kFan) - 1u);
+    if (!bits) return;
+    long pos = wave_offset(wmask, boff, cblock, w) + __popcll(mask & ((1ull << (kFan * sub)) - 1ull));
+    const long first = (long)(pnode ? pnode[p] : 0) * kFan;
+    const int img = pimg ? pimg[p] : (int)p;
+    while (bits) {
+        const int j = __ffs(bits) - 1;
+        bits &= bits - 1;
+        cnode[pos] = (int)(first + j);
+        cimg[pos] = img;
+        ++pos;
+    }
+}
+
+// The clip stage: one lane per (cell, image) candidate, in (image, cell) order.  Count pass (FILL = false): clip, ballot mask
+// and count per wavefront; a candidate cell the weights are not defined on is refused here (flag_cell) or dropped.  Fill pass:
+// the lanes of the mask clip again (same inputs, same bits) and write the record (key, cell, image, ta, tb); the weights
+// themselves are formed after the sort (k_expand), straight into their final place.
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_clip_pairs(const double *__restrict__ xy, const int *__restrict__ ccell,
+                                                       const int *__restrict__ cimg, long nc, double period,
+                                                       const double *__restrict__ segs, const int *__restrict__ seg_cc,
+                                                       int nshift, double periodX, unsigned long long *__restrict__ wmask,
+                                                       int *__restrict__ bcnt, const long *__restrict__ boff, Records rec,
+                                                       unsigned long long *__restrict__ err, int skip_unsupported)
+{
+    const long t = (long)blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
     bool hit = false;
-    double ta = 0.0, tb = 0.0, qx = 0.0, qy = 0.0, dx = 0.0, dy = 0.0;
-    double vv[8];
-    int s = 0, cl = 0;
-    if (lane < n) {
-        const int e = wq[(q_head + lane) & (2 * kWave - 1)];
-        const int im = e >> 6;
-        cl = e & (kWave - 1);
-        s = im / nshift;
-        const int k = im - s * nshift;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) vv[i] = tile_xy[cl * 8 + i];
-        dx = segs[4 * s + 2];
-        dy = segs[4 * s + 3];
-        qx = segs[4 * s] + (nshift == 3 ? k - 1 : 0) * periodX;
-        qy = segs[4 * s + 1];
-        hit = clip_cell(vv, qx, qy, dx, dy, ta, tb);
+    if (FILL) {
+        if (t < nc) hit = (wmask[t / kWave] >> lane) & 1ull;
+        if (!hit) return;
     }
-    const unsigned long long mask = __ballot(hit);
-    if (FILL && hit) {
-        const long pos = base + __popcll(mask & lt_mask);
-        const long c = tile_c0 + cl;
-        double a0, a1, b0, b1;
-        bool ok = inv_bilinear(vv, qx + ta * dx, qy + ta * dy, a0, a1);
-        ok = inv_bilinear(vv, qx + tb * dx, qy + tb * dy, b0, b1) && ok;
-        if (!ok) flag_cell(err, c, 2, s);
-        const double d0 = b0 - a0, d1 = b1 - a1;
-        const double m0 = 0.5 * (a0 + b0), m1 = 0.5 * (a1 + b1);
-        double w0 = d0 * (1.0 - m1), w1 = d1 * m0, w2 = d0 * m1, w3 = d1 * (1.0 - m0);
-        if (seg_cc[s]) {
-            w2 = -w2;
-            w3 = -w3;
+    double v[8], ta = 0.0, tb = 0.0;
+    SegImage g{};
+    long c = 0;
+    if (t < nc) {
+        c = ccell[t];
+        g = load_image(segs, cimg[t], nshift, periodX);
+        double cxmin, cxmax, cymin, cymax, slack;
+        cell_geometry(xy, c, period, v, cxmin, cxmax, cymin, cymax, slack);   // a candidate is a finite cell
+        if (FILL) {
+            clip_cell(v, g.qx, g.qy, g.dx, g.dy, ta, tb);
+        } else if (quad_is_nonconvex(v)) {   // not a cell the weights are defined on: refuse if the line really crosses it
+            // (skip policy: the cell contributes nothing and the segment's coverage says so)
+            if (!skip_unsupported && segment_overlaps_quad(v, g.qx, g.qy, g.dx, g.dy)) flag_cell(err, c, 1, g.s);
+        } else {
+            hit = clip_cell(v, g.qx, g.qy, g.dx, g.dy, ta, tb);
         }
-        unsigned long long q = (unsigned long long)(ta * (double)kTaOne);
-        if (q >= kTaOne) q = kTaOne - 1;
-        rec.key[pos] = ((unsigned long long)s << kTaBits) | q;
-        rec.cell[pos] = (int)c;
-        rec.ta[pos] = ta;
-        rec.tb[pos] = tb;
-        double2 *pw = reinterpret_cast<double2 *>(rec.w + 4 * pos);
-        pw[0] = make_double2(w0, w1);
-        pw[1] = make_double2(w2, w3);
     }
-    return __popcll(mask);
+    if (!FILL) {
+        block_count(__ballot(hit), wmask, bcnt);
+        return;
+    }
+    const unsigned long long mask = wmask[t / kWave];
+    const long pos = wave_offset(wmask, boff, blockIdx.x, threadIdx.x / kWave) + __popcll(mask & ((1ull << lane) - 1ull));
+    unsigned long long q = (unsigned long long)(ta * (double)kTaOne);
+    if (q >= kTaOne) q = kTaOne - 1;
+    rec.key[pos] = ((unsigned long long)g.s << kTaBits) | q;
+    rec.cell[pos] = (int)c;
+    rec.kshift[pos] = (unsigned char)g.k;
+    rec.ta[pos] = ta;
+    rec.tb[pos] = tb;
 }
 
-template <bool FILL>
-__global__ __launch_bounds__(kBlock) void k_clip(const double *__restrict__ xy, long ncell,
-                                                 const double *__restrict__ segs,
-                                                 const int *__restrict__ seg_cc, int nseg, int nshift,
-                                                 double periodX, const int *__restrict__ wave_off,
-                                                 int *__restrict__ wave_cnt, Records rec,
-                                                 unsigned long long *__restrict__ err, int skip_unsupported)
+// Records with the same sort key (same target segment, same quantised ta: a sub-segment along an edge that two cells share, or
+// found through two periodic images) keep, through the stable sort, the order the clip stage wrote them in: (image, cell).
+// The engine has always listed them in (64-cell tile, image, cell) order -- the order its first weight kernel worked in --
+// and the order of the records is the order K3 adds them up in: this pass puts every run of equal keys into that order, so
+// that weights, rows and their checksums stay bit for bit what they were.  Runs are two to four records long.
+__global__ __launch_bounds__(kBlock) void k_tie_order(const unsigned long long *__restrict__ keys,
+                                                      const unsigned *__restrict__ perm_in, long nrec, Records rec,
+                                                      unsigned *__restrict__ perm_out)
 {
-    __shared__ double s_xy[kBlock * 8];
-    const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const long c0 = (long)blockIdx.x * kBlock;
-    const long nval = ncell * 8;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {  // coalesced stage of 256 cells x 4 corners x (lon,lat)
-        long g = c0 * 8 + tid + r * kBlock;
-        if (g < nval) s_xy[tid + r * kBlock] = xy[g];
+    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nrec) return;
+    const unsigned long long key = keys[i];
+    long a = i, b = i + 1;
+    while (a > 0 && keys[a - 1] == key) --a;
+    while (b < nrec && keys[b] == key) ++b;
+    const unsigned r = perm_in[i];
+    if (b - a == 1) {
+        perm_out[i] = r;
+        return;
     }
-    __syncthreads();
-    const long c = c0 + tid;
-    bool valid = c < ncell;
-    double v[8];
-    double cxmin = 1e300, cxmax = -1e300, cymin = 1e300, cymax = -1e300;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = valid ? s_xy[tid * 8 + k] : 0.0;
-    valid = valid && quad_is_finite(v);            // NaN / infinite corners: not a cell
-    unwrap_quad(v, nshift == 3 ? periodX : 0.0);   // date-line cells (nf_common.h)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s_xy[tid * 8 + k] = v[k];   // the clip stage below reads ANY cell of the wave's tile from LDS
-    if (valid) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            cxmin = fmin(cxmin, v[2 * i]);
-            cxmax = fmax(cxmax, v[2 * i]);
-            cymin = fmin(cymin, v[2 * i + 1]);
-            cymax = fmax(cymax, v[2 * i + 1]);
-        }
-    }
-    const double slack = valid ? 1.e-9 * (fabs(cxmin) + fabs(cxmax) + fabs(cymin) + fabs(cymax) + 1.0) : 0.0;
-    const bool nonconvex = valid && quad_is_nonconvex(v);
-    // wave tile bounding box (the locator bucket)
-    const double wslack = wmax(slack);
-    const double wxmin = wmin(cxmin) - wslack, wxmax = wmax(cxmax) + wslack;
-    const double wymin = wmin(cymin) - wslack, wymax = wmax(cymax) + wslack;
-    const long wave_id = (c0 + tid) / kWave;
-    int count = 0;
-    const int base = (FILL && wave_id * kWave < ncell) ? wave_off[wave_id] : 0;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    // Locator, level 1 (workgroup): the 256 lanes test 256 segment images at a time against the workgroup's box
-    // with an exact segment-vs-box clip and compact the survivors, in image order, into an LDS list; level 2 (wave)
-    // and level 3 (cell) then only look at those.  A workgroup is a 256-cell strip of one grid row, so almost every
-    // image is rejected here: tens of candidates instead of nseg*nshift loop trips per wave.
-    __shared__ int s_hits[kBlock];
-    __shared__ int s_wcount[kBlock / kWave];
-    __shared__ double s_box[4][kBlock / kWave];
-    if (lane == 0) {
-        s_box[0][tid / kWave] = wxmin;
-        s_box[1][tid / kWave] = wxmax;
-        s_box[2][tid / kWave] = wymin;
-        s_box[3][tid / kWave] = wymax;
-    }
-    __syncthreads();
-    double bxmin = s_box[0][0], bxmax = s_box[1][0], bymin = s_box[2][0], bymax = s_box[3][0];
-#pragma unroll
-    for (int w = 1; w < kBlock / kWave; ++w) {
-        bxmin = fmin(bxmin, s_box[0][w]);
-        bxmax = fmax(bxmax, s_box[1][w]);
-        bymin = fmin(bymin, s_box[2][w]);
-        bymax = fmax(bymax, s_box[3][w]);
-    }
-    // per-wave queue of (image << 6 | lane) pairs waiting for the clip (ring of kQueue entries, wave-private: no barrier)
-    constexpr int kQueue = 2 * kWave;
-    __shared__ int s_queue[kBlock / kWave][kQueue];
-    volatile int *wq = s_queue[tid / kWave];
-    int q_head = 0, q_tail = 0;
-    const int nimg = nseg * nshift;
-    for (int chunk = 0; chunk < nimg; chunk += kBlock) {
-        const int img = chunk + tid;
-        bool cand = false;
-        if (img < nimg) {
-            const int s = img / nshift, k = img - s * nshift;
-            const double dx = segs[4 * s + 2], dy = segs[4 * s + 3];
-            if (!(dx == 0.0 && dy == 0.0)) {
-                const double qx = segs[4 * s] + (nshift == 3 ? k - 1 : 0) * periodX, qy = segs[4 * s + 1];
-                // Liang-Barsky clip of q + t d, t in [0,1], against the (slack-expanded) box; conservative
-                double t0 = 0.0, t1 = 1.0;
-                cand = true;
-                if (dx == 0.0) cand = qx >= bxmin && qx <= bxmax;
-                else {
-                    double ta = (bxmin - qx) / dx, tb = (bxmax - qx) / dx;
-                    if (ta > tb) { const double tt = ta; ta = tb; tb = tt; }
-                    t0 = fmax(t0, ta);
-                    t1 = fmin(t1, tb);
-                }
-                if (dy == 0.0) cand = cand && qy >= bymin && qy <= bymax;
-                else {
-                    double ta = (bymin - qy) / dy, tb = (bymax - qy) / dy;
-                    if (ta > tb) { const double tt = ta; ta = tb; tb = tt; }
-                    t0 = fmax(t0, ta);
-                    t1 = fmin(t1, tb);
-                }
-                cand = cand && t0 <= t1 + 1.e-9;
-            }
-        }
-        const unsigned long long cmask = __ballot(cand);
-        if (lane == 0) s_wcount[tid / kWave] = __popcll(cmask);
-        __syncthreads();
-        int before = 0, nhit = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / kWave; ++w) {
-            if (w < tid / kWave) before += s_wcount[w];
-            nhit += s_wcount[w];
-        }
-        if (cand) s_hits[before + __popcll(cmask & lt_mask)] = img;
-        __syncthreads();
-        for (int h = 0; h < nhit; ++h) {  // workgroup-uniform trip count, image order preserved
-            const int im = s_hits[h];
-            const int s = im / nshift, k = im - s * nshift;
-            const double p0x = segs[4 * s], p0y = segs[4 * s + 1];
-            const double dx = segs[4 * s + 2], dy = segs[4 * s + 3];
-            const int shift = nshift == 3 ? k - 1 : 0;
-            const double qx = p0x + shift * periodX, qy = p0y;
-            const double sxmin = qx < qx + dx ? qx : qx + dx, sxmax = qx < qx + dx ? qx + dx : qx;
-            const double symin = qy < qy + dy ? qy : qy + dy, symax = qy < qy + dy ? qy + dy : qy;
-            if (wxmin > sxmax || wxmax < sxmin || wymin > symax || wymax < symin) continue;  // wave-uniform
-            bool pass = valid && !(cxmin > sxmax + slack || cxmax < sxmin - slack || cymin > symax + slack ||
-                                   cymax < symin - slack);
-            // Level 3a, one lane per cell: is the cell's corner set entirely on one side of the target LINE, by more than
-            // 1e-9 x the size of the coordinates (a thousand times the clip's own distance tolerance)?  Then the clip below
-            // finds nothing either -- whatever the quad's shape: it lies in the hull of its corners -- and the cell drops
-            // out here, for four cross products.  A long segment's bounding box holds whole tiles of cells it never touches.
-            if (pass) {
-                double M = dmax2(dmax2(fabs(qx), fabs(qy)), dmax2(fabs(qx + dx), fabs(qy + dy)));
-#pragma unroll
-                for (int i = 0; i < 8; ++i) M = dmax2(M, fabs(v[i]));
-                const double m2 = (1.e-9 * M) * (1.e-9 * M) * (dx * dx + dy * dy);
-                bool all_pos = true, all_neg = true;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const double sd = dx * (v[2 * i + 1] - qy) - dy * (v[2 * i] - qx);
-                    const bool far = sd * sd > m2;
-                    all_pos = all_pos && far && sd > 0.0;
-                    all_neg = all_neg && far && sd < 0.0;
-                }
-                pass = !(all_pos || all_neg);
-            }
-            if (pass && nonconvex) {   // not a cell the weights are defined on: refuse if the line really crosses it
-                // (skip policy: the cell contributes nothing and the segment's coverage says so)
-                if (!FILL && !skip_unsupported && segment_overlaps_quad(v, qx, qy, dx, dy)) flag_cell(err, c, 1, s);
-                pass = false;
-            }
-            // Level 3b, one lane per (cell, image) PAIR: the cells that are left -- one to three of a tile's 64 -- are queued
-            // in (image, lane) order, and the expensive part (the clip's four divisions, in the fill pass two Newton
-            // solves) runs on 64 queued pairs at a time with every lane busy, instead of once per image with two lanes busy.
-            const unsigned long long pmask = __ballot(pass);
-            if (pmask == 0ull) continue;
-            if (pass) wq[(q_tail + __popcll(pmask & lt_mask)) & (kQueue - 1)] = (im << 6) | lane;
-            q_tail += __popcll(pmask);
-            while (q_tail - q_head >= kWave) {
-                count += clip_pairs<FILL>(wq, q_head, kWave, s_xy + (tid - lane) * 8, c0 + (tid - lane), segs, seg_cc, nshift,
-                                          periodX, base + count, rec, err, lane, lt_mask);
-                q_head += kWave;
-            }
-        }
-        __syncthreads();  // s_hits is reused by the next chunk
-    }
-    if (q_tail > q_head)
-        count += clip_pairs<FILL>(wq, q_head, q_tail - q_head, s_xy + (tid - lane) * 8, c0 + (tid - lane), segs, seg_cc, nshift,
-                                  periodX, base + count, rec, err, lane, lt_mask);
-    if (!FILL && lane == 0 && wave_id * kWave < ncell) wave_cnt[wave_id] = count;
-}
-
-// exclusive scan of n ints by ONE workgroup (n ~ ncell/64: 1e5 for ORCA12); total -> out[n]
-__global__ __launch_bounds__(1024) void k_scan(const int *__restrict__ in, long n, int *__restrict__ out)
-{
-    __shared__ long s_sum[1024];
-    const int tid = threadIdx.x;
-    const long chunk = (n + 1023) / 1024;
-    const long lo = tid * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-    long acc = 0;
-    for (long k = lo; k < hi; ++k) acc += in[k];
-    s_sum[tid] = acc;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive
-        long t = (tid >= o) ? s_sum[tid - o] : 0;
-        __syncthreads();
-        s_sum[tid] += t;
-        __syncthreads();
-    }
-    long run = s_sum[tid] - acc;
-    for (long k = lo; k < hi; ++k) {
-        out[k] = (int)run;
-        run += in[k];
-    }
-    if (tid == 1023) out[n] = s_sum[1023] > 0x7fffffffl ? -1 : (int)s_sum[1023];  // -1: too many records
+    auto order = [&](unsigned q) {
+        const unsigned long long cell = (unsigned)rec.cell[q];
+        return ((cell / kWave) << 8) | ((unsigned long long)rec.kshift[q] << 6) | (cell & (kWave - 1));
+    };
+    const unsigned long long mine = order(r);
+    long rank = 0;
+    for (long j = a; j < b; ++j) rank += order(perm_in[j]) < mine;
+    perm_out[a + rank] = r;
 }
 
 __global__ __launch_bounds__(kBlock) void k_iota(unsigned *p, long n)
@@ -464,9 +489,13 @@ __global__ __launch_bounds__(kBlock) void k_seg_bounds(const unsigned long long 
     rec_start[s] = (int)lo;
 }
 
-// multiplicity + expansion into 4 entries per record
+// multiplicity, the four edge weights of the record (both ends of the piece mapped into the cell: Newton) and the output
+// arrays, one lane per record in sorted order
 __global__ __launch_bounds__(kBlock) void k_expand(const unsigned long long *__restrict__ keys,
                                                    const unsigned *__restrict__ perm, long nrec, Records rec,
+                                                   const double *__restrict__ xy, double period,
+                                                   const double *__restrict__ segs, const int *__restrict__ seg_cc, int nshift,
+                                                   double periodX, unsigned long long *__restrict__ err,
                                                    int *__restrict__ cell_out, double *__restrict__ w4_out,
                                                    int *__restrict__ seg_out, double *__restrict__ len_out)
 {
@@ -487,12 +516,25 @@ __global__ __launch_bounds__(kBlock) void k_expand(const unsigned long long *__r
         if (fabs(rec.ta[rj] - ta) <= kTolT && fabs(rec.tb[rj] - tb) <= kTolT) ++n;
     }
     const double coef = 1.0 / (double)n;
-    const double2 *pw = reinterpret_cast<const double2 *>(rec.w + 4 * (long)r);
-    const double2 a = pw[0], b = pw[1];
+    const long c = rec.cell[r];
+    const SegImage g = load_image(segs, (int)s * nshift + rec.kshift[r], nshift, periodX);
+    double v[8], cxmin, cxmax, cymin, cymax, slack;
+    cell_geometry(xy, c, period, v, cxmin, cxmax, cymin, cymax, slack);
+    double a0, a1, b0, b1;
+    bool ok = inv_bilinear(v, g.qx + ta * g.dx, g.qy + ta * g.dy, a0, a1);
+    ok = inv_bilinear(v, g.qx + tb * g.dx, g.qy + tb * g.dy, b0, b1) && ok;
+    if (!ok) flag_cell(err, c, 2, g.s);
+    const double d0 = b0 - a0, d1 = b1 - a1;
+    const double m0 = 0.5 * (a0 + b0), m1 = 0.5 * (a1 + b1);
+    double w0 = d0 * (1.0 - m1), w1 = d1 * m0, w2 = d0 * m1, w3 = d1 * (1.0 - m0);
+    if (seg_cc[g.s]) {
+        w2 = -w2;
+        w3 = -w3;
+    }
     double2 *po = reinterpret_cast<double2 *>(w4_out + 4 * i);
-    po[0] = make_double2(a.x * coef, a.y * coef);
-    po[1] = make_double2(b.x * coef, b.y * coef);
-    cell_out[i] = rec.cell[r];
+    po[0] = make_double2(w0 * coef, w1 * coef);
+    po[1] = make_double2(w2 * coef, w3 * coef);
+    cell_out[i] = (int)c;
     seg_out[i] = (int)s;
     len_out[i] = coef * (tb - ta);   // the piece of the target segment this record accounts for
 }
@@ -613,8 +655,58 @@ int weights_to_host(const WeightSet &ws, int64_t *cell_edge, double *weight, int
 }
 
 namespace {
+// Scratch memory of one weight build.  A build needs a few dozen buffers (two per level of the walk, the records, the sort's
+// buffers); through hipMalloc / hipFree every one is a round trip to the driver and hipFree a device synchronisation on top --
+// for the 65-transect batch that was more time than the build's kernels take.  So the buffers are cut from a few large
+// blocks (32 MiB, doubling): an arena hands out pieces, rewinds when its owner says so (the walk ping-pongs between two
+// arenas: the pairs of one level are dead once the next level is written), and frees its blocks when the build ends.
+// (Stream-ordered memory pools were tried for this: fine up to 512 transects, but with gigabytes in the pool every later
+// hipMalloc took 40 ms -- profiles/r05_weights_scaling.txt.)
+struct Arena {
+    struct Block {
+        char *p;
+        size_t size, used;
+    };
+    std::vector<Block> blocks;
+    size_t next_size = 32ull << 20;
+    Arena() = default;
+    Arena(const Arena &) = delete;
+    Arena &operator=(const Arena &) = delete;
+    ~Arena()
+    {
+        for (Block &b : blocks) (void)hipFree(b.p);
+    }
+    void rewind()
+    {
+        for (Block &b : blocks) b.used = 0;
+    }
+    hipError_t take(void **out, size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes == 0) bytes = 256;
+        for (Block &b : blocks)
+            if (b.size - b.used >= bytes) {
+                *out = b.p + b.used;
+                b.used += bytes;
+                return hipSuccess;
+            }
+        Block nb{nullptr, bytes > next_size ? bytes : next_size, 0};
+        const hipError_t e = hipMalloc((void **)&nb.p, nb.size);
+        if (e != hipSuccess) return e;
+        if (next_size < (4ull << 30)) next_size *= 2;
+        nb.used = bytes;
+        blocks.push_back(nb);
+        *out = nb.p;
+        return hipSuccess;
+    }
+    template <typename T> hipError_t take(T **out, size_t count) { return take((void **)out, sizeof(T) * count); }
+};
+
 struct DevBuf {  // frees on scope exit
     void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
     template <typename T> T *as() { return reinterpret_cast<T *>(p); }
@@ -684,12 +776,14 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     NF_REQUIRE(ncell > 0 && ncell < (1l << 31), NF_ERR_ARG, "weights: ncell out of range");
     NF_REQUIRE(nseg >= 0 && nseg < (1 << 23), NF_ERR_ARG, "weights: segment count out of range");
     const int nshift = periodX > 0.0 ? 3 : 1;
-    const long nwaves = (ncell + kWave - 1) / kWave;
-    const unsigned nblocks = (unsigned)((ncell + kBlock - 1) / kBlock);
+    const double period = nshift == 3 ? periodX : 0.0;
 
-    DevBuf d_segs, d_cc, d_cnt, d_off, d_err;
-    NF_HIP(d_err.alloc(sizeof(unsigned long long)));
-    NF_HIP(hipMemsetAsync(d_err.p, 0xff, sizeof(unsigned long long), s));
+    Arena misc, level[2];    // freed when the build returns, on every path
+    double *d_segs = nullptr;
+    int *d_cc = nullptr;
+    unsigned long long *d_err = nullptr;
+    NF_HIP(misc.take(&d_err, 1));
+    NF_HIP(hipMemsetAsync(d_err, 0xff, sizeof(unsigned long long), s));
     unsigned long long err_word = ~0ull;
     auto refuse = [&](unsigned long long w) {
         char buf[256];
@@ -705,28 +799,123 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
         out->release();
         return NF_ERR_ARG;
     };
-    NF_HIP(d_segs.alloc(sizeof(double) * 4 * (size_t)nseg));
-    NF_HIP(d_cc.alloc(sizeof(int) * (size_t)nseg));
-    NF_HIP(d_cnt.alloc(sizeof(int) * (size_t)nwaves));
-    NF_HIP(d_off.alloc(sizeof(int) * (size_t)(nwaves + 1)));
+    NF_HIP(misc.take(&d_segs, 4 * (size_t)nseg));
+    NF_HIP(misc.take(&d_cc, (size_t)nseg));
     if (nseg > 0) {
-        NF_HIP(hipMemcpyAsync(d_segs.p, segs_host, sizeof(double) * 4 * (size_t)nseg, hipMemcpyHostToDevice, s));
-        NF_HIP(hipMemcpyAsync(d_cc.p, seg_cc_host, sizeof(int) * (size_t)nseg, hipMemcpyHostToDevice, s));
+        NF_HIP(hipMemcpyAsync(d_segs, segs_host, sizeof(double) * 4 * (size_t)nseg, hipMemcpyHostToDevice, s));
+        NF_HIP(hipMemcpyAsync(d_cc, seg_cc_host, sizeof(int) * (size_t)nseg, hipMemcpyHostToDevice, s));
     }
-    NF_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(int) * (size_t)nwaves, s));
 
+    // ---- the locator: box hierarchy over the cells (level 0 = the cells themselves, level l = groups of 16^l)
+    std::vector<long> nlev{ncell};
+    while (nlev.back() > 1) nlev.push_back((nlev.back() + kFan - 1) / kFan);
+    const int top = (int)nlev.size() - 1;            // the root: one box (top == 0: a one-cell grid)
+    std::vector<Box4 *> boxes(nlev.size(), nullptr);
+    NF_HIP(misc.take(&boxes[0], (size_t)ncell));
+    for (int l = 1; l <= top; ++l) {
+        NF_HIP(misc.take(&boxes[(size_t)l], (size_t)nlev[(size_t)l]));
+        const long n_in = nlev[(size_t)l - 1];
+        const unsigned nb = (unsigned)((n_in + kBlock - 1) / kBlock);
+        if (l == 1)
+            hipLaunchKernelGGL(k_boxes_cells, dim3(nb), dim3(kBlock), 0, s, xy, ncell, period, boxes[0], boxes[1]);
+        else
+            hipLaunchKernelGGL(k_boxes_up, dim3(nb), dim3(kBlock), 0, s, (const Box4 *)boxes[(size_t)l - 1], n_in,
+                               boxes[(size_t)l]);
+    }
+    NF_HIP(hipGetLastError());
+
+    // per-wavefront masks and per-workgroup counts / offsets of one count-scan-fill step over n lanes; *total = the set bits
+    unsigned long long *w_mask = nullptr;
+    int *w_cnt = nullptr;
+    long *w_off = nullptr;
+    void *scan_tmp = nullptr;
+    long w_cap = 0;
+    size_t scan_cap = 0;
+    auto lanes_to_waves = [](long nlanes) { return ((nlanes + kBlock - 1) / kBlock) * (kBlock / kWave); };
+    auto reserve_waves = [&](long nw) -> int {
+        if (nw <= w_cap) return NF_OK;
+        nw += nw / 2;                       // the levels grow towards the cells: fewer re-sizes (the old pieces stay in the arena)
+        NF_HIP(misc.take(&w_mask, (size_t)nw));
+        NF_HIP(misc.take(&w_cnt, (size_t)nw / (kBlock / kWave) + 1));
+        NF_HIP(misc.take(&w_off, (size_t)nw / (kBlock / kWave) + 1));
+        w_cap = nw;
+        return NF_OK;
+    };
+    auto scan_waves = [&](long nwaves, long *total) -> int {
+        const long nw = nwaves / (kBlock / kWave);     // one count per workgroup
+        size_t need = 0;
+        NF_HIP(rocprim::exclusive_scan(nullptr, need, w_cnt, w_off, 0l, (size_t)nw, rocprim::plus<long>(), s));
+        if (need > scan_cap) {
+            NF_HIP(misc.take(&scan_tmp, need + need / 2));
+            scan_cap = need + need / 2;
+        }
+        NF_HIP(rocprim::exclusive_scan(scan_tmp, need, w_cnt, w_off, 0l, (size_t)nw, rocprim::plus<long>(), s));
+        long last_off = 0;
+        int last_cnt = 0;
+        NF_HIP(hipMemcpyAsync(&last_off, w_off + (nw - 1), sizeof(long), hipMemcpyDeviceToHost, s));
+        NF_HIP(hipMemcpyAsync(&last_cnt, w_cnt + (nw - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+        NF_HIP(hipStreamSynchronize(s));
+        *total = last_off + last_cnt;
+        return NF_OK;
+    };
+
+    // ---- the walk: (group, image) pairs from the root down to (cell, image) candidates, in (image, cell) order
+    int *p_node = nullptr, *p_img = nullptr;   // pairs of the level being expanded (both null: (root, image) for every image)
+    long np = (long)nseg * nshift;
+    for (int l = top; l >= 1 && np > 0; --l) {
+        const long nlanes = np * kFan;
+        NF_REQUIRE(nlanes / kBlock < (1l << 31), NF_ERR_ARG, "weights: too many (cell group, segment) pairs; split the transect set");
+        const long nw = lanes_to_waves(nlanes);
+        const unsigned nb = (unsigned)(nw / (kBlock / kWave));
+        NF_TRY(reserve_waves(nw));
+        const int *pn = p_node, *pi = p_img;
+        hipLaunchKernelGGL(k_walk_count, dim3(nb), dim3(kBlock), 0, s, pn, pi, np, (const Box4 *)boxes[(size_t)l - 1],
+                           nlev[(size_t)l - 1], (const double *)d_segs, nshift, periodX, w_mask, w_cnt);
+        long nchild = 0;
+        NF_TRY(scan_waves(nw, &nchild));
+        // the children go to the other arena: what it held (the parents of this level's parents) is dead.  Kernels that read
+        // it have been waited for: scan_waves synchronised the stream after them.
+        Arena &dst = level[l & 1];
+        dst.rewind();
+        int *c_node = nullptr, *c_img = nullptr;
+        NF_HIP(dst.take(&c_node, (size_t)nchild));
+        NF_HIP(dst.take(&c_img, (size_t)nchild));
+        if (nchild > 0)
+            hipLaunchKernelGGL(k_walk_fill, dim3((unsigned)((np + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, pn, pi, np,
+                               (const unsigned long long *)w_mask, (const long *)w_off, c_node, c_img);
+        NF_HIP(hipGetLastError());
+        p_node = c_node;
+        p_img = c_img;
+        np = nchild;
+    }
+    if (top == 0 && np > 0) {   // a grid of one cell: every image is a candidate for it
+        std::vector<int> zeros((size_t)np, 0), iota((size_t)np);
+        for (long k = 0; k < np; ++k) iota[(size_t)k] = (int)k;
+        NF_HIP(misc.take(&p_node, (size_t)np));
+        NF_HIP(misc.take(&p_img, (size_t)np));
+        NF_HIP(hipMemcpyAsync(p_node, zeros.data(), sizeof(int) * (size_t)np, hipMemcpyHostToDevice, s));
+        NF_HIP(hipMemcpyAsync(p_img, iota.data(), sizeof(int) * (size_t)np, hipMemcpyHostToDevice, s));
+        NF_HIP(hipStreamSynchronize(s));
+    }
+    const long ncand = np;
+
+    // ---- the clip stage over the candidates: count, scan, fill
+    long nrec = 0;
+    const long cw = lanes_to_waves(ncand);
+    const unsigned cb = (unsigned)(cw / (kBlock / kWave));
     Records none{};
-    hipLaunchKernelGGL(k_clip<false>, dim3(nblocks), dim3(kBlock), 0, s, xy, ncell, d_segs.as<double>(),
-                       d_cc.as<int>(), nseg, nshift, periodX, (const int *)nullptr, d_cnt.as<int>(), none,
-                       d_err.as<unsigned long long>(), skip_unsupported);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, d_cnt.as<int>(), nwaves, d_off.as<int>());
-    int nrec_i = 0;
-    NF_HIP(hipMemcpyAsync(&nrec_i, d_off.as<int>() + nwaves, sizeof(int), hipMemcpyDeviceToHost, s));
-    NF_HIP(hipMemcpyAsync(&err_word, d_err.p, sizeof err_word, hipMemcpyDeviceToHost, s));
+    if (ncand > 0) {
+        NF_REQUIRE(ncand / kBlock < (1l << 31), NF_ERR_ARG, "weights: too many (cell, segment) candidates; split the transect set");
+        NF_TRY(reserve_waves(cw));
+        hipLaunchKernelGGL(k_clip_pairs<false>, dim3(cb), dim3(kBlock), 0, s, xy, (const int *)p_node, (const int *)p_img, ncand,
+                           period, (const double *)d_segs, (const int *)d_cc, nshift, periodX, w_mask, w_cnt,
+                           (const long *)nullptr, none, d_err, skip_unsupported);
+        NF_TRY(scan_waves(cw, &nrec));
+    }
+    NF_HIP(hipMemcpyAsync(&err_word, d_err, sizeof err_word, hipMemcpyDeviceToHost, s));
     NF_HIP(hipStreamSynchronize(s));
     if (err_word != ~0ull) return refuse(err_word);
-    NF_REQUIRE(nrec_i >= 0, NF_ERR_ARG, "weights: more than 2^31 (segment, cell) records; split the transect set");
-    const long nrec = nrec_i;
+    NF_REQUIRE(nrec < (1l << 31), NF_ERR_ARG, "weights: more than 2^31 (segment, cell) records; split the transect set");
 
     NF_HIP(hipMalloc((void **)&out->seg_start, sizeof(int) * (size_t)(nseg + 1)));
     if (nrec == 0) {
@@ -737,56 +926,66 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
         return NF_OK;
     }
 
-    DevBuf r_key, r_cell, r_ta, r_tb, r_w, k_out, v_in, v_out, tmp, rstart;
-    NF_HIP(r_key.alloc(sizeof(unsigned long long) * nrec));
-    NF_HIP(r_cell.alloc(sizeof(int) * nrec));
-    NF_HIP(r_ta.alloc(sizeof(double) * nrec));
-    NF_HIP(r_tb.alloc(sizeof(double) * nrec));
-    NF_HIP(r_w.alloc(sizeof(double) * 4 * nrec));
-    Records rec{r_key.as<unsigned long long>(), r_cell.as<int>(), r_ta.as<double>(), r_tb.as<double>(),
-                r_w.as<double>()};
-    hipLaunchKernelGGL(k_clip<true>, dim3(nblocks), dim3(kBlock), 0, s, xy, ncell, d_segs.as<double>(),
-                       d_cc.as<int>(), nseg, nshift, periodX, d_off.as<int>(), (int *)nullptr, rec,
-                       d_err.as<unsigned long long>(), skip_unsupported);
+    Records rec{};
+    NF_HIP(misc.take(&rec.key, (size_t)nrec));
+    NF_HIP(misc.take(&rec.cell, (size_t)nrec));
+    NF_HIP(misc.take(&rec.kshift, (size_t)nrec));
+    NF_HIP(misc.take(&rec.ta, (size_t)nrec));
+    NF_HIP(misc.take(&rec.tb, (size_t)nrec));
+    hipLaunchKernelGGL(k_clip_pairs<true>, dim3(cb), dim3(kBlock), 0, s, xy, (const int *)p_node, (const int *)p_img, ncand, period,
+                       (const double *)d_segs, (const int *)d_cc, nshift, periodX, w_mask, w_cnt, (const long *)w_off, rec, d_err,
+                       skip_unsupported);
     NF_HIP(hipGetLastError());
 
-    // stable sort of record indices by global segment id
-    NF_HIP(k_out.alloc(sizeof(unsigned long long) * nrec));
-    NF_HIP(v_in.alloc(sizeof(unsigned) * nrec));
-    NF_HIP(v_out.alloc(sizeof(unsigned) * nrec));
+    // Stable sort of record indices by (target segment, ta).  (A segmented sort over the 40 bits of ta -- the records leave the
+    // clip stage grouped by segment -- was measured: 3.1 ms against 2.2 ms for these seven device-wide passes at 44 M records.)
+    // The walk's pairs are dead once the fill pass above has run, and everything below is ordered behind it on the same
+    // stream: the sort's buffers re-use the two level arenas.
+    level[0].rewind();
+    level[1].rewind();
+    unsigned long long *k_out = nullptr;
+    unsigned *v_in = nullptr, *v_out = nullptr, *v_tie = nullptr;
+    void *tmp = nullptr;
+    int *rstart = nullptr;
+    NF_HIP(level[0].take(&k_out, (size_t)nrec));
+    NF_HIP(level[1].take(&v_in, (size_t)nrec));
+    NF_HIP(level[1].take(&v_out, (size_t)nrec));
     const unsigned nb_rec = (unsigned)((nrec + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_iota, dim3(nb_rec), dim3(kBlock), 0, s, v_in.as<unsigned>(), nrec);
+    hipLaunchKernelGGL(k_iota, dim3(nb_rec), dim3(kBlock), 0, s, v_in, nrec);
     int bits = 1;
     while ((1l << bits) < (long)nseg + 1 && bits < 24) ++bits;
     const unsigned end_bit = (unsigned)(kTaBits + bits);
     size_t tmp_bytes = 0;
-    NF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned long long *)r_key.p,
-                                     k_out.as<unsigned long long>(), v_in.as<unsigned>(), v_out.as<unsigned>(),
+    NF_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned long long *)rec.key, k_out, (const unsigned *)v_in, v_out,
                                      (size_t)nrec, 0u, end_bit, s));
-    NF_HIP(tmp.alloc(tmp_bytes));
-    NF_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, (const unsigned long long *)r_key.p,
-                                     k_out.as<unsigned long long>(), v_in.as<unsigned>(), v_out.as<unsigned>(),
+    NF_HIP(level[0].take(&tmp, tmp_bytes));
+    NF_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, (const unsigned long long *)rec.key, k_out, (const unsigned *)v_in, v_out,
                                      (size_t)nrec, 0u, end_bit, s));
-    NF_HIP(rstart.alloc(sizeof(int) * (size_t)(nseg + 1)));
+    // runs of equal keys into the engine's historical (tile, image, cell) order: see k_tie_order
+    NF_HIP(level[1].take(&v_tie, (size_t)nrec));
+    hipLaunchKernelGGL(k_tie_order, dim3(nb_rec), dim3(kBlock), 0, s, (const unsigned long long *)k_out, (const unsigned *)v_out, nrec,
+                       rec, v_tie);
+    NF_HIP(misc.take(&rstart, (size_t)(nseg + 1)));
     hipLaunchKernelGGL(k_seg_bounds, dim3((unsigned)((nseg + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       k_out.as<unsigned long long>(), nrec, nseg, rstart.as<int>());
+                       (const unsigned long long *)k_out, nrec, nseg, rstart);
 
     out->nrec = nrec;
     NF_HIP(hipMalloc((void **)&out->cell, sizeof(int) * (size_t)nrec));
     NF_HIP(hipMalloc((void **)&out->w4, sizeof(double) * 4 * (size_t)nrec));
     NF_HIP(hipMalloc((void **)&out->seg, sizeof(int) * (size_t)nrec));
-    DevBuf d_len, d_cov;
-    NF_HIP(d_len.alloc(sizeof(double) * (size_t)nrec));
-    NF_HIP(d_cov.alloc(sizeof(double) * (size_t)(nseg + 1)));
-    hipLaunchKernelGGL(k_expand, dim3(nb_rec), dim3(kBlock), 0, s, k_out.as<unsigned long long>(),
-                       v_out.as<unsigned>(), nrec, rec, out->cell, out->w4, out->seg, d_len.as<double>());
+    double *d_len = nullptr, *d_cov = nullptr;
+    NF_HIP(level[0].take(&d_len, (size_t)nrec));
+    NF_HIP(misc.take(&d_cov, (size_t)(nseg + 1)));
+    hipLaunchKernelGGL(k_expand, dim3(nb_rec), dim3(kBlock), 0, s, (const unsigned long long *)k_out, (const unsigned *)v_tie, nrec,
+                       rec, xy, period, (const double *)d_segs, (const int *)d_cc, nshift, periodX, d_err, out->cell, out->w4,
+                       out->seg, d_len);
     if (nseg > 0) {
         hipLaunchKernelGGL(k_seg_coverage, dim3((unsigned)(((long)nseg * kWave + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                           d_len.as<double>(), rstart.as<int>(), nseg, d_cov.as<double>());
-        NF_HIP(hipMemcpyAsync(out->coverage.data(), d_cov.p, sizeof(double) * (size_t)nseg, hipMemcpyDeviceToHost, s));
+                           (const double *)d_len, (const int *)rstart, nseg, d_cov);
+        NF_HIP(hipMemcpyAsync(out->coverage.data(), d_cov, sizeof(double) * (size_t)nseg, hipMemcpyDeviceToHost, s));
     }
-    NF_HIP(hipMemcpyAsync(out->seg_start, rstart.p, sizeof(int) * (size_t)(nseg + 1), hipMemcpyDeviceToDevice, s));
-    NF_HIP(hipMemcpyAsync(&err_word, d_err.p, sizeof err_word, hipMemcpyDeviceToHost, s));
+    NF_HIP(hipMemcpyAsync(out->seg_start, rstart, sizeof(int) * (size_t)(nseg + 1), hipMemcpyDeviceToDevice, s));
+    NF_HIP(hipMemcpyAsync(&err_word, d_err, sizeof err_word, hipMemcpyDeviceToHost, s));
     NF_HIP(hipGetLastError());
     NF_HIP(hipStreamSynchronize(s));
     if (err_word != ~0ull) return refuse(err_word);   // Newton did not converge somewhere (fill pass)
