@@ -298,9 +298,12 @@ struct SegImage {   // one periodic image of a target segment: q + t d, t in [0,
     double qx, qy, dx, dy;
     int s, k;
 };
+// NSHIFT: 1 or 3 at compile time (the division by 3 becomes a multiplication), 0 = whatever nshift says
+template <int NSHIFT = 0>
 __device__ inline SegImage load_image(const double *__restrict__ segs, int img, int nshift, double periodX)
 {
     SegImage g;
+    if (NSHIFT) nshift = NSHIFT;
     g.s = img / nshift;
     g.k = img - g.s * nshift;
     g.dx = segs[4 * g.s + 2];
@@ -338,6 +341,7 @@ __device__ inline bool line_may_touch(const SegImage &g, const double *p /* 4 (x
 // One level of the walk, count pass: lane t tests child (t % 16) of pair (t / 16) -- the box of a group of the level below or,
 // at the last level, of a cell.  pnode == nullptr: the pairs are (root, image p) for every image.  Writes the ballot mask per
 // wavefront and the number of set bits per workgroup.
+template <int NSHIFT>
 __global__ __launch_bounds__(kBlock) void k_walk_count(const int *__restrict__ pnode, const int *__restrict__ pimg, long np,
                                                        const Box4 *__restrict__ box, long nchild,
                                                        const double *__restrict__ segs, int nshift, double periodX,
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void k_walk_count(const int *__restrict__ p
     if (p < np) {
         const long child = (long)(pnode ? pnode[p] : 0) * kFan + (t & (kFan - 1));
         if (child < nchild) {
-            const SegImage g = load_image(segs, pimg ? pimg[p] : (int)p, nshift, periodX);
+            const SegImage g = load_image<NSHIFT>(segs, pimg ? pimg[p] : (int)p, nshift, periodX);
             if (!(g.dx == 0.0 && g.dy == 0.0)) {
                 const Box4 b = box[child];
                 const double c4[8] = {b.xmin, b.ymin, b.xmax, b.ymin, b.xmax, b.ymax, b.xmin, b.ymax};
@@ -869,8 +873,12 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
         const unsigned nb = (unsigned)(nw / (kBlock / kWave));
         NF_TRY(reserve_waves(nw));
         const int *pn = p_node, *pi = p_img;
-        hipLaunchKernelGGL(k_walk_count, dim3(nb), dim3(kBlock), 0, s, pn, pi, np, (const Box4 *)boxes[(size_t)l - 1],
-                           nlev[(size_t)l - 1], (const double *)d_segs, nshift, periodX, w_mask, w_cnt);
+        if (nshift == 3)
+            hipLaunchKernelGGL(k_walk_count<3>, dim3(nb), dim3(kBlock), 0, s, pn, pi, np, (const Box4 *)boxes[(size_t)l - 1],
+                               nlev[(size_t)l - 1], (const double *)d_segs, nshift, periodX, w_mask, w_cnt);
+        else
+            hipLaunchKernelGGL(k_walk_count<1>, dim3(nb), dim3(kBlock), 0, s, pn, pi, np, (const Box4 *)boxes[(size_t)l - 1],
+                               nlev[(size_t)l - 1], (const double *)d_segs, nshift, periodX, w_mask, w_cnt);
         long nchild = 0;
         NF_TRY(scan_waves(nw, &nchild));
         // the children go to the other arena: what it held (the parents of this level's parents) is dead.  Kernels that read
