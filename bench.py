@@ -33,6 +33,40 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def flux_source_sha16():
+    """Fingerprint of what the flux kernels are compiled from (nf_flux.hip, nf_common.h, the compiler flags of the Makefile):
+    the HBM-traffic figures under profiles/ are counters of ANOTHER run, so they carry this fingerprint and the commit they
+    were taken at, and the bench reports them only while the sources still are what was measured (round-4 verdict W7)."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, 'nemoflux_amd', 'csrc')
+    for name in ('nf_flux.hip', 'nf_common.h'):
+        with open(os.path.join(base, name), 'rb') as f:
+            h.update(f.read())
+    with open(os.path.join(base, 'Makefile')) as f:
+        h.update(''.join(l for l in f if l.startswith('CXXFLAGS')).encode())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(key):
+    """(HBM bytes per launch or None, where the figure comes from) for workload `key` of profiles/pmc_traffic.json."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        d = json.load(f)
+    val = d.get(key, {}).get('hbm_bytes_per_launch')
+    if val is None:
+        return None, None
+    at = d.get('measured_at', {})
+    mine = flux_source_sha16()
+    if at.get('flux_source_sha16') != mine:
+        return None, (f'profiles/pmc_traffic.json holds counters of flux sources {at.get("flux_source_sha16")} (commit '
+                      f'{at.get("commit")}); this build is {mine}: not reported')
+    return val, (f'profiles/pmc_traffic.json: separate rocprofv3 --pmc passes of this command at commit {at.get("commit")} '
+                 f'(flux sources {mine}, unchanged since), not measured in this run')
+
+
 def make_transects(nx, ny, xmin, xmax, ymin, ymax, nbatch, seed=20260401, seam=False):
     """Transect batch of SURVEY 8d C5: `nbatch` seeded polylines of 8-64 vertices snapped to grid nodes, |lat| <= 80, every
     second one closed.
@@ -230,16 +264,13 @@ def run_workload(args, dtype, scaling, rank, world, local, want_totals=False, em
     units_per_launch = own * ny * nx / max(1.0, (nlaunch / args.steps))   # owned slabs / launches per step
     avg_ms = kernel_ms / max(1, nlaunch)
     achieved = bytes_per_unit * units_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    traffic, traffic_source = None, None
     wl_key = f'{nx}x{ny}x{nz}x{args.nt}_{dtype}' + ('_compact' if args.compact else '')
-    if world == 1 and os.path.exists(pmc):   # the PMC pass measured whole time steps (75 levels per launch): N=1 only
-        with open(pmc) as f:
-            traffic = json.load(f).get(wl_key, {}).get('hbm_bytes_per_launch')
+    if world == 1:   # the PMC pass measured whole time steps (75 levels per launch): N=1 only
+        traffic, traffic_source = pmc_traffic(wl_key)
     m['roofline'] = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                     'traffic_source': 'profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command, '
-                                       'not measured in this run)' if traffic is not None else None,
+                     'traffic_source': traffic_source,
                      'kernel': 'nf::k_flux + nf::k_expand_planes (one event pair around both)' if expand_ms > 0 else 'nf::k_flux',
                      'avg_launch_ms': round(avg_ms, 4), 'launches': nlaunch,
                      'avg_ms_by_kernel': {'nf::k_flux': round(flux_ms / max(1, nlaunch), 4),
@@ -440,16 +471,12 @@ def c3_record(steps=20):
         units = float(nz) * ny * nx
         bpu = 2 * es + 64.0 / nz
         k1 = kms / max(1, nl)
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # two separate --pmc passes of `bench.py --only-c3`
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                traffic = json.load(f).get(f'{nx}x{ny}x{nz}x1_{dtype}', {}).get('hbm_bytes_per_launch')
+        traffic, traffic_source = pmc_traffic(f'{nx}x{ny}x{nz}x1_{dtype}')     # two separate --pmc passes of `bench.py --only-c3`
         out[dtype] = {'value': units / wall, 'unit': 'integrals/s', 'ms_per_step': round(wall * 1e3, 4),
                       'k1_ms': round(k1, 4), 'k3_ms': round(k3 / max(1, nl), 4),
                       'frac': round(bpu * units / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                       'wall_frac': round(bpu * units / wall / 1e9 / HBM_PEAK_GBS, 4),
-                      'algorithmic_bytes_per_unit': round(bpu, 3), 'traffic': traffic,
+                      'algorithmic_bytes_per_unit': round(bpu, 3), 'traffic': traffic, 'traffic_source': traffic_source,
                       'kernel': 'nf::k_flux_field' if expand_ms == 0 else 'nf::k_flux + nf::k_expand_planes',
                       'flux': float(rows[0, -1].item())}
         del fld, dg, u, v

@@ -293,7 +293,15 @@ int launch_datagen_uv(void *u, void *v, int dtype, long t0, long t1, long nt, lo
     const double dyy = lat_uses_dx ? dx : dy;
     const double dz = (zmax - zmin) / (double)nz;  // datagen.py:35
     const long ncell = ny * nx, nnode = (ny + 1) * (nx + 1);
-    double *h = nullptr, *ds21 = nullptr, *ds23 = nullptr;
+    double *h = nullptr, *ds21 = nullptr, *ds23 = nullptr, *gtab = nullptr;
+    struct FreeOnExit {       // every return path, the early ones of NF_HIP included (round-4 advisor)
+        double *&a, *&b, *&c, *&d;
+        ~FreeOnExit()
+        {
+            for (double *p : {a, b, c, d})
+                if (p) (void)hipFree(p);
+        }
+    } cleanup{h, ds21, ds23, gtab};
     NF_HIP(hipMalloc((void **)&h, sizeof(double) * nnode));
     NF_HIP(hipMalloc((void **)&ds21, sizeof(double) * ncell));
     NF_HIP(hipMalloc((void **)&ds23, sizeof(double) * ncell));
@@ -309,7 +317,6 @@ int launch_datagen_uv(void *u, void *v, int dtype, long t0, long t1, long nt, lo
         const long t = t0 + sl / nz, k = sl % nz;
         gh[(size_t)sl] = psi_g(psi, zmin + ((double)k + 0.5) * dz, t, nt);   // z: datagen.py:38
     }
-    double *gtab = nullptr;
     NF_HIP(hipMalloc((void **)&gtab, sizeof(double) * gh.size()));
     NF_HIP(hipMemcpyAsync(gtab, gh.data(), sizeof(double) * gh.size(), hipMemcpyHostToDevice, s));
     if (nslab > 0) {
@@ -333,7 +340,7 @@ int launch_datagen_uv(void *u, void *v, int dtype, long t0, long t1, long nt, lo
             }
 #undef NF_UV_ROWS
         } else {
-            dim3 grid(nb, (unsigned)nslab);
+            dim3 grid(nb, (unsigned)nslab);      // nslab < 65536: checked on entry
             if (dtype == NF_F64)
                 hipLaunchKernelGGL(k_uv<double>, grid, dim3(kBlock), 0, s, (double *)u, (double *)v, h, ds21, ds23, gtab,
                                    (unsigned)ny, (unsigned)nx, psi);
@@ -343,11 +350,7 @@ int launch_datagen_uv(void *u, void *v, int dtype, long t0, long t1, long nt, lo
         }
     }
     hipError_t e = hipGetLastError();
-    hipError_t e2 = hipStreamSynchronize(s);
-    (void)hipFree(h);
-    (void)hipFree(ds21);
-    (void)hipFree(ds23);
-    (void)hipFree(gtab);
+    hipError_t e2 = hipStreamSynchronize(s);     // the kernels are done before the tables go (gh, too, is read by a copy)
     NF_HIP(e);
     NF_HIP(e2);
     return NF_OK;

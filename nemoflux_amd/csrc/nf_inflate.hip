@@ -12,6 +12,7 @@
 // then all second bytes, ...): k_place gathers them back, one element per lane, coalesced on both sides, and puts the
 // chunk where it belongs in the (nz, ny, nx) slab (chunks may tile y and x, edge chunks hang over).
 #include <type_traits>
+#include <algorithm>
 #include <vector>
 
 #include "nf_common.h"
@@ -203,6 +204,7 @@ struct Inflater {
     // thread while the other slot decodes); a run is synchronous on its caller's thread, so two inflaters whose runs never
     // overlap in time can share the rest (a file-backed Field then holds one decoded-group scratch, not two).
     Inflater *scratch_owner = nullptr;
+    std::vector<Inflater *> borrowers;   // the inflaters that use THIS one's scratch: detached when this one is deleted
     void release()
     {
         for (void *p : {(void *)d_comp, (void *)d_tmp, (void *)d_jobs, (void *)d_status})
@@ -343,6 +345,12 @@ int inflater_run(Inflater *h, const void *comp_host, size_t comp_bytes, const lo
         NF_HIP(hipMalloc((void **)&so->d_status, sizeof(int) * (size_t)n));
         so->jobs_cap = (size_t)n;
     }
+    // From here on work is queued on `s` that reads `jobs` (pageable host memory) and writes the scratch -- which another
+    // inflater may share and use from ITS stream next: whatever makes this function return early, the stream is drained first
+    struct DrainOnExit {
+        hipStream_t s;
+        ~DrainOnExit() { (void)hipStreamSynchronize(s); }
+    } drain{s};
     if (comp_host) {
         const size_t tail = comp_bytes & ~(size_t)3;                    // zero the last partial word and the padding behind the data
         h->uploaded = 0;
@@ -407,6 +415,24 @@ int nf_inflater_share_scratch(nf_inflater **self, nf_inflater **owner)
     if (o->scratch_owner) {
         set_error("nf_inflater_share_scratch: the owner borrows its scratch itself");
         return NF_ERR_ARG;
+    }
+    if (h->device != o->device) {     // the scratch is device memory: a run on another GPU could not even address it
+        set_error("nf_inflater_share_scratch: the two inflaters were created on different devices");
+        return NF_ERR_ARG;
+    }
+    if (!h->borrowers.empty()) {
+        set_error("nf_inflater_share_scratch: this inflater lends its scratch to others");
+        return NF_ERR_ARG;
+    }
+    try {
+        if (h->scratch_owner != o) o->borrowers.push_back(h);
+    } catch (...) {
+        set_error("out of host memory");
+        return NF_ERR_HOST;
+    }
+    if (h->scratch_owner && h->scratch_owner != o) {     // it borrowed from someone else before
+        auto &b = h->scratch_owner->borrowers;
+        b.erase(std::remove(b.begin(), b.end(), h), b.end());
     }
     for (void *p : {(void *)h->d_tmp, (void *)h->d_jobs, (void *)h->d_status})   // its own scratch is not needed any more
         if (p) (void)hipFree(p);
@@ -495,6 +521,15 @@ int nf_inflater_del(nf_inflater **self)
 {
     if (self && *self) {
         Inflater *h = reinterpret_cast<Inflater *>(*self);
+        // nobody keeps a pointer to a deleted inflater: its borrowers go back to a scratch of their own (allocated at their
+        // next run), and it leaves the list of the one it borrowed from.  Kernels of a borrower may still be reading the
+        // scratch (its runs are synchronous, but an error return can leave work in flight): wait before freeing it
+        if (!h->borrowers.empty()) (void)hipDeviceSynchronize();
+        for (Inflater *b : h->borrowers) b->scratch_owner = nullptr;
+        if (h->scratch_owner) {
+            auto &b = h->scratch_owner->borrowers;
+            b.erase(std::remove(b.begin(), b.end(), h), b.end());
+        }
         h->release();
         delete h;
         *self = nullptr;

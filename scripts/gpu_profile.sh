@@ -6,6 +6,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 R=${1:-r03}
+COMMIT=${2:-unknown}     # git rev-parse --short HEAD of the snapshot, given by the caller (the box has no .git)
 mkdir -p gpurun_out/$R
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu --no-c3 > gpurun_out/$R/bench_trace.json 2> gpurun_out/$R/bench_trace.err
 echo "trace done"
@@ -21,4 +22,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/ingest_tra
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/ingest_fetch -- python3 tools/inflate_rate.py > gpurun_out/$R/ingest_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/$R/ingest_write -- python3 tools/inflate_rate.py > gpurun_out/$R/ingest_write.log 2>&1
 echo "ingest done"
-python3 scripts/summarize_profile.py gpurun_out/$R $R
+python3 scripts/summarize_profile.py gpurun_out/$R $R $COMMIT

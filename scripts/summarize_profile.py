@@ -6,7 +6,11 @@ import os
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
+commit = sys.argv[3] if len(sys.argv) > 3 else None       # the commit the profiled snapshot was taken at (the box has no .git)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import bench  # noqa: E402  (flux_source_sha16: fingerprint of the kernel sources these counters belong to)
+measured_at = {'commit': commit, 'flux_source_sha16': bench.flux_source_sha16(), 'tag': tag}
 out = os.path.join(src, 'summary')
 os.makedirs(out, exist_ok=True)
 
@@ -44,6 +48,7 @@ if st2:
                                         total_ns=int(r['TotalDurationNs']), avg_ns=float(r['AverageNs']),
                                         pct=float(r['Percentage']), min_ns=int(r['MinNs']), max_ns=int(r['MaxNs'])))
 with open(os.path.join(out, f'{tag}_kernel_stats.csv'), 'w') as f:
+    f.write(f'# rocprofv3 --kernel-trace --stats at commit {commit}, flux kernel sources {measured_at["flux_source_sha16"]}\n')
     f.write('kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n')
     for r in rows + ingest_rows:
         f.write('"{kernel}",{calls},{total_ns},{avg_ns:.1f},{pct},{min_ns},{max_ns}\n'.format(**r))
@@ -172,6 +177,7 @@ for k, name in enumerate(CASES):
     ingest[name] = e
 if ingest:
     res['ingest'] = ingest
+res['measured_at'] = measured_at
 with open(os.path.join(out, 'pmc_traffic.json'), 'w') as f:
     json.dump(res, f, indent=1)
 
@@ -183,7 +189,8 @@ def stat(kernel_sub):
     return None
 
 
-lines = [f'# {tag}: numbers quoted in profiles/README.md and DESIGN.md (generated by scripts/summarize_profile.py)', '']
+lines = [f'# {tag}: numbers quoted in profiles/README.md and DESIGN.md (generated by scripts/summarize_profile.py)', '',
+         f'Profiled snapshot: commit `{commit}`, flux kernel sources `{measured_at["flux_source_sha16"]}` (`bench.flux_source_sha16()`).', '']
 lines.append('| kernel (rocprofv3 --kernel-trace --stats of `bench.py --steps 5 --warmup 1 --no-cpu`) | calls | avg ms |')
 lines.append('|---|---|---|')
 for sub in ('k_flux<double', 'k_flux<float', 'k_expand_planes', 'k_gather_segscan', 'k_finalize_seg', 'k_finalize_tr', 'k_geometry',

@@ -179,3 +179,38 @@ def test_far_path_on_the_device():
     assert r.returncode == 0 and 'bit-identical' in r.stdout and 'libnemoflux_amd_w8k.so' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
     cap = int(r.stdout.split('capacity ')[1].split(')')[0])
     assert cap > 2000            # ten streams per CU with the 8 KiB window (the shipped build: 1024)
+
+
+def test_shared_scratch_survives_its_owner():
+    """Round-4 advisor: nf_inflater_share_scratch used to leave the borrower with a dangling pointer when the OWNER was deleted
+    first (a C client has no Python wrapper keeping it alive).  Now the owner detaches its borrowers, which go back to a scratch
+    of their own; lending while borrowing, and borrowing from a borrower, are refused."""
+    import ctypes
+    from nemoflux_amd._lib import lib, check, NemofluxError
+    from nemoflux_amd.ingest import ChunkDecoder
+    data = (numpy.arange(40000, dtype=numpy.uint32) * 2654435761 % 251).astype(numpy.uint8).tobytes()
+    streams = [zlib.compress(data, lvl) for lvl in (1, 6, 9)]
+    want = numpy.frombuffer(data, numpy.uint8)
+    owner, a, b = ChunkDecoder(), ChunkDecoder(), ChunkDecoder()
+    owner.decode_streams(streams, len(data))                     # the owner has a scratch of its own
+    a.share_scratch_of(owner)
+    b.share_scratch_of(owner)
+    assert all(numpy.array_equal(r, want) for r in a.decode_streams(streams, len(data)))
+    with pytest.raises(NemofluxError, match='borrows its scratch itself'):
+        owner_of_a = ChunkDecoder()
+        owner_of_a.share_scratch_of(a)
+    with pytest.raises(NemofluxError, match='lends its scratch'):
+        owner.share_scratch_of(ChunkDecoder())
+    # delete the owner through the C ABI while the borrowers are alive (what a C client might do)
+    a._scratch_owner = b._scratch_owner = None
+    check(lib.nf_inflater_del(ctypes.byref(owner._h)))
+    owner._h = None
+    for d in (a, b, a):
+        assert all(numpy.array_equal(r, want) for r in d.decode_streams(streams, len(data)))
+    # a borrower deleted before its owner leaves the owner usable, and deleting the owner afterwards is clean
+    o2, c = ChunkDecoder(), ChunkDecoder()
+    c.share_scratch_of(o2)
+    c.decode_streams(streams, len(data))
+    del c
+    assert all(numpy.array_equal(r, want) for r in o2.decode_streams(streams, len(data)))
+    del o2
