@@ -420,6 +420,8 @@ __global__ __launch_bounds__(kBlock) void k_clip_pairs(const double *__restrict_
         cell_geometry(xy, c, period, v, cxmin, cxmax, cymin, cymax, slack);   // a candidate is a finite cell
         if (FILL) {
             clip_cell(v, g.qx, g.qy, g.dx, g.dy, ta, tb);
+        } else if (g.dx == 0.0 && g.dy == 0.0) {
+            // a zero-length piece (a repeated vertex) crosses nothing; the walk never lets one through, a one-cell grid has no walk
         } else if (quad_is_nonconvex(v)) {   // not a cell the weights are defined on: refuse if the line really crosses it
             // (skip policy: the cell contributes nothing and the segment's coverage says so)
             if (!skip_unsupported && segment_overlaps_quad(v, g.qx, g.qy, g.dx, g.dy)) flag_cell(err, c, 1, g.s);
