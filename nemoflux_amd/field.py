@@ -309,7 +309,9 @@ class Field(object):
         # arrow seed points along the target lines (field.py:71-87)
         vectorPoints = []
         uVectors = []
-        for lonlatpts in self._polylines:
+        # (batch drivers -- readback=False -- never look at the arrows: a batch of 4 096 transects on the ORCA12-like grid would
+        # seed 2 x 10^8 of them)
+        for lonlatpts in (self._polylines if self._readback else []):
             for i in range(len(lonlatpts) - 1):
                 begPoint = numpy.array(lonlatpts[i])
                 endPoint = numpy.array(lonlatpts[i + 1])
