@@ -51,6 +51,7 @@ _sig('nf_memcpy_h2d', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t])
 _sig('nf_memcpy_d2h', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t])
 _sig('nf_memset', [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t])
 _sig('nf_synchronize', [])
+_sig('nf_release_scratch', [])
 _sig('nf_host_unshuffle', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int])
 _sig('nf_host_gather', [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int])
 _sig('nf_tuning_set', [ctypes.c_char_p, ctypes.c_int])

@@ -277,6 +277,12 @@ try {
     return NF_OK;
 }
 NF_API_CATCH
+int nf_release_scratch(void)
+try {
+    weights_trim_scratch();
+    return NF_OK;
+}
+NF_API_CATCH
 int nf_synchronize(void)
 try {
     NF_NEED_DEVICE();
@@ -294,6 +300,7 @@ struct Grid_t {
     double *d_xy = nullptr;         // corner table (ncell,4,2)
     bool owns_xy = true;
     long version = 0;               // bumped by every build: weights / located points of an older build are refused
+    LocatorBoxes boxes;             // the locator of this grid (filled by the first computeWeights, dropped when the points change)
 };
 
 struct PolylineIntegral_t {
@@ -349,6 +356,7 @@ try {
     NF_REQUIRE(g->host_points, NF_ERR_STATE, "mnt_grid_build: setPointsPtr first");
     NF_REQUIRE(ncells > 0 && ncells < (1ll << 31), NF_ERR_ARG, "mnt_grid_build: bad cell count");
     NF_NEED_DEVICE();
+    g->boxes.release();             // they describe the old points
     if (g->owns_xy) dev_free(g->d_xy);
     g->owns_xy = true;
     g->ncell = (long)ncells;
@@ -496,7 +504,7 @@ try {
     p->stage.release();
     p->h_cell.clear();
     NF_TRY(build_weights(p->grid->d_xy, p->grid->ncell, segs.data(), cc.data(), p->nseg, p->periodX, &p->ws, nullptr,
-                         p->skip_unsupported, p->overlap_warn));
+                         p->skip_unsupported, p->overlap_warn, &p->grid->boxes));
     NF_TRY(dev_alloc(&p->d_tr_off, 2));
     NF_TRY(dev_alloc(&p->d_scratch, (size_t)p->ws.nrec));
     const int off[2] = {0, p->nseg};
@@ -1198,6 +1206,7 @@ try {
     for (int k = 0; k < 4; ++k) f->box[k] = box_key_to_double(keys[k]);
     f->grid_view.ncell = f->ncell;
     f->grid_view.d_xy = f->d_xy;
+    f->grid_view.boxes.release();     // a locator built on the old corner table says nothing about the new one
     ++f->grid_view.version;
     f->grid_view.owns_xy = false;
     f->weights_built = false;

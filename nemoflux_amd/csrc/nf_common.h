@@ -214,10 +214,27 @@ int weights_to_host(const WeightSet &ws, int64_t *cell_edge, double *weight, int
 // segs_host: (nseg,4) = x0,y0,dx,dy ; seg_cc_host: counterclock flag per segment
 // skip_unsupported: 0 = a target segment that overlaps a non-convex / pole-vertex cell is an error (default); 1 = such
 // cells contribute nothing and the segment's coverage is < 1
+// The locator of a grid (nf_weights.hip: bounding boxes of the cells and of groups of 16, 256, ... consecutive cells) for one
+// period, kept by whoever owns the corner table -- mint's buildLocator builds it once per PolylineIntegral; here a Grid_t keeps
+// it for all the PolylineIntegral objects made on it (fluxviz / fluxplot make one per transect).  build_weights fills it when
+// it does not match the grid it is called with.
+struct LocatorBoxes {
+    std::vector<void *> level;   // level[l]: HBM array of the boxes of level l (0 = cells)
+    std::vector<long> count;
+    const double *xy = nullptr;  // the corner table the boxes were built from
+    long ncell = 0;
+    double period = -1.0;
+    void release();
+    ~LocatorBoxes() { release(); }
+};
 // overlap_warn: 0 = a target segment covered more than once (over_covered) is an error (default); 1 = the build goes through,
 // out->over_seg names the first such segment and the coverage says how much (the caller warns)
+// boxes: nullptr = the locator lives for this build only (the batched build of a Field)
 int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
-                  double periodX, WeightSet *out, hipStream_t s, int skip_unsupported = 0, int overlap_warn = 0);
+                  double periodX, WeightSet *out, hipStream_t s, int skip_unsupported = 0, int overlap_warn = 0,
+                  LocatorBoxes *boxes = nullptr);
+// gives the scratch memory that weight builds keep between calls (at most 512 MiB per host thread) back to the system
+void weights_trim_scratch();
 
 // K3: gather + wavefront segmented reduction -> per-segment sums, then per-transect sums.
 // row: (nseg + ntransect) doubles in HBM; tr_offsets_dev: (ntransect+1) segment offsets.

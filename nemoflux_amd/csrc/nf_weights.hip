@@ -708,6 +708,75 @@ struct Arena {
     template <typename T> hipError_t take(T **out, size_t count) { return take((void **)out, sizeof(T) * count); }
 };
 
+// The arenas of a build, kept between builds of the same host thread while they are small (a viewer makes one
+// PolylineIntegral per transect: without this every one of them paid ten hipMalloc / hipFree pairs, more than its kernels).
+struct BuildScratch {
+    Arena misc, level[2];
+    int device = -1;
+    size_t capacity() const
+    {
+        size_t n = 0;
+        for (const Arena *a : {&misc, &level[0], &level[1]})
+            for (const Arena::Block &b : a->blocks) n += b.size;
+        return n;
+    }
+};
+constexpr size_t kScratchKeep = 512ull << 20;
+static thread_local BuildScratch *t_scratch = nullptr;   // never freed at thread exit (the HIP runtime may be gone by then)
+
+struct ScratchLease {   // takes the cached scratch (or a new one) for one build; gives it back only if told the stream is drained
+    BuildScratch *sc = nullptr;
+    bool drained = false;
+    ScratchLease()
+    {
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        sc = t_scratch;
+        t_scratch = nullptr;
+        if (sc && sc->device != dev) {
+            delete sc;
+            sc = nullptr;
+        }
+        if (!sc) {
+            sc = new BuildScratch();
+            sc->device = dev;
+        }
+    }
+    ScratchLease(const ScratchLease &) = delete;
+    ScratchLease &operator=(const ScratchLease &) = delete;
+    ~ScratchLease()
+    {
+        if (drained && !t_scratch && sc->capacity() <= kScratchKeep) {
+            sc->misc.rewind();
+            sc->level[0].rewind();
+            sc->level[1].rewind();
+            t_scratch = sc;
+        } else {
+            delete sc;      // hipFree waits for whatever is still running
+        }
+    }
+};
+
+}  // namespace
+
+void weights_trim_scratch()
+{
+    delete t_scratch;
+    t_scratch = nullptr;
+}
+
+void LocatorBoxes::release()
+{
+    for (void *p : level)
+        if (p) (void)hipFree(p);
+    level.clear();
+    count.clear();
+    xy = nullptr;
+    ncell = 0;
+    period = -1.0;
+}
+
+namespace {
 struct DevBuf {  // frees on scope exit
     void *p = nullptr;
     DevBuf() = default;
@@ -774,7 +843,7 @@ int fold_weights(WeightSet *ws, long ncell, long nx, hipStream_t s)
 }
 
 int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
-                  double periodX, WeightSet *out, hipStream_t s, int skip_unsupported, int overlap_warn)
+                  double periodX, WeightSet *out, hipStream_t s, int skip_unsupported, int overlap_warn, LocatorBoxes *keep)
 {
     out->release();
     out->nseg = nseg;
@@ -784,7 +853,9 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     const int nshift = periodX > 0.0 ? 3 : 1;
     const double period = nshift == 3 ? periodX : 0.0;
 
-    Arena misc, level[2];    // freed when the build returns, on every path
+    ScratchLease lease;      // the arenas: rewound and kept for the next build when this one ends drained, freed otherwise
+    Arena &misc = lease.sc->misc;
+    Arena(&level)[2] = lease.sc->level;
     double *d_segs = nullptr;
     int *d_cc = nullptr;
     unsigned long long *d_err = nullptr;
@@ -817,18 +888,38 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     while (nlev.back() > 1) nlev.push_back((nlev.back() + kFan - 1) / kFan);
     const int top = (int)nlev.size() - 1;            // the root: one box (top == 0: a one-cell grid)
     std::vector<Box4 *> boxes(nlev.size(), nullptr);
-    NF_HIP(misc.take(&boxes[0], (size_t)ncell));
-    for (int l = 1; l <= top; ++l) {
-        NF_HIP(misc.take(&boxes[(size_t)l], (size_t)nlev[(size_t)l]));
-        const long n_in = nlev[(size_t)l - 1];
-        const unsigned nb = (unsigned)((n_in + kBlock - 1) / kBlock);
-        if (l == 1)
-            hipLaunchKernelGGL(k_boxes_cells, dim3(nb), dim3(kBlock), 0, s, xy, ncell, period, boxes[0], boxes[1]);
-        else
-            hipLaunchKernelGGL(k_boxes_up, dim3(nb), dim3(kBlock), 0, s, (const Box4 *)boxes[(size_t)l - 1], n_in,
-                               boxes[(size_t)l]);
+    const bool cached = keep && keep->xy == xy && keep->ncell == ncell && keep->period == period &&
+                        keep->level.size() == nlev.size();
+    if (cached) {
+        for (size_t l = 0; l < nlev.size(); ++l) boxes[l] = static_cast<Box4 *>(keep->level[l]);
+    } else {
+        if (keep) {      // the grid's own copy: plain allocations that outlive this build
+            keep->release();
+            keep->level.assign(nlev.size(), nullptr);
+            keep->count = nlev;
+            for (size_t l = 0; l < nlev.size(); ++l) {
+                NF_HIP(hipMalloc(&keep->level[l], sizeof(Box4) * (size_t)nlev[l]));
+                boxes[l] = static_cast<Box4 *>(keep->level[l]);
+            }
+        } else {
+            for (size_t l = 0; l < nlev.size(); ++l) NF_HIP(misc.take(&boxes[l], (size_t)nlev[l]));
+        }
+        for (int l = 1; l <= top; ++l) {
+            const long n_in = nlev[(size_t)l - 1];
+            const unsigned nb = (unsigned)((n_in + kBlock - 1) / kBlock);
+            if (l == 1)
+                hipLaunchKernelGGL(k_boxes_cells, dim3(nb), dim3(kBlock), 0, s, xy, ncell, period, boxes[0], boxes[1]);
+            else
+                hipLaunchKernelGGL(k_boxes_up, dim3(nb), dim3(kBlock), 0, s, (const Box4 *)boxes[(size_t)l - 1], n_in,
+                                   boxes[(size_t)l]);
+        }
+        NF_HIP(hipGetLastError());
+        if (keep) {
+            keep->xy = xy;
+            keep->ncell = ncell;
+            keep->period = period;
+        }
     }
-    NF_HIP(hipGetLastError());
 
     // per-wavefront masks and per-workgroup counts / offsets of one count-scan-fill step over n lanes; *total = the set bits
     unsigned long long *w_mask = nullptr;
@@ -924,13 +1015,17 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     }
     NF_HIP(hipMemcpyAsync(&err_word, d_err, sizeof err_word, hipMemcpyDeviceToHost, s));
     NF_HIP(hipStreamSynchronize(s));
-    if (err_word != ~0ull) return refuse(err_word);
+    if (err_word != ~0ull) {
+        lease.drained = true;      // nothing of this build is running any more: the scratch may serve the next one
+        return refuse(err_word);
+    }
     NF_REQUIRE(nrec < (1l << 31), NF_ERR_ARG, "weights: more than 2^31 (segment, cell) records; split the transect set");
 
     NF_HIP(hipMalloc((void **)&out->seg_start, sizeof(int) * (size_t)(nseg + 1)));
     if (nrec == 0) {
         NF_HIP(hipMemsetAsync(out->seg_start, 0, sizeof(int) * (size_t)(nseg + 1), s));
         NF_HIP(hipStreamSynchronize(s));
+        lease.drained = true;
         for (int q = 0; q < nseg; ++q)
             if (segs_host[4 * q + 2] == 0.0 && segs_host[4 * q + 3] == 0.0) out->coverage[(size_t)q] = 1.0;
         return NF_OK;
@@ -998,6 +1093,7 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     NF_HIP(hipMemcpyAsync(&err_word, d_err, sizeof err_word, hipMemcpyDeviceToHost, s));
     NF_HIP(hipGetLastError());
     NF_HIP(hipStreamSynchronize(s));
+    lease.drained = true;      // the last kernel of the build has finished; nothing below launches anything
     if (err_word != ~0ull) return refuse(err_word);   // Newton did not converge somewhere (fill pass)
     for (int q = 0; q < nseg; ++q)                     // a zero-length segment has nothing to cover
         if (segs_host[4 * q + 2] == 0.0 && segs_host[4 * q + 3] == 0.0) out->coverage[(size_t)q] = 1.0;

@@ -1490,6 +1490,12 @@ def test_locator_hierarchy_on_small_and_ragged_grids(nx, ny, oracle):
             if k in (2, 3):     # every point of a line along shared edges is counted once
                 inside = pli.getCoverage()
                 assert numpy.all(inside <= 1.0 + 1e-12)
+    # the grid keeps its locator and the library its scratch between builds: a second object on the same grid, after the
+    # scratch was given back, gives the same weights; new points on the same Grid object drop the old locator
+    from nemoflux_amd._lib import lib, check
+    check(lib.nf_release_scratch())
+    again = _gpu_weights(pts, lines[0])[2]
+    assert again == _gpu_weights(pts, lines[0])[2]
     # the batched build (nf_field_build_weights) on the same grid: all five lines at once == one by one
     from nemoflux_amd import mint
     grid = mint.Grid()
@@ -1787,3 +1793,27 @@ def test_rebuilt_grid_invalidates_weights_and_located_points(oracle):
     data = numpy.random.default_rng(0).standard_normal((small.shape[0], 4))
     assert abs(pli.getIntegral(data) - oracle.get_integral(ow, data)) <= 1e-13
     assert vi.getFaceVectors(data, placement=mint.CELL_BY_CELL_DATA).shape == (1, 3)
+
+
+def test_grid_locator_follows_the_points(oracle):
+    """The Grid keeps its locator (the box hierarchy of the weight build) for all PolylineIntegral objects made on it (round 5).
+    New points of the SAME shape -- possibly at the same HBM address -- must not find the old boxes: a grid moved by 7.5 degrees
+    gives the weights of the moved grid; a second period (periodX 0 after 360) rebuilds the boxes too."""
+    from nemoflux_amd import mint
+    o = oracle.DataGen(72, 36, 1, 1)
+    a = oracle.assemble_points(o.bounds_lon, o.bounds_lat)
+    b = oracle.assemble_points(o.bounds_lon + 7.5, o.bounds_lat * 0.9)
+    xyz = transect_xyz("(-100,-50),(20,10),(100,50)")
+    grid = mint.Grid()
+    for pts, periodX in ((a, 360.), (b, 360.), (b, 0.), (a, 0.), (a, 360.)):
+        grid.setPoints(pts) if pts is not getattr(grid, 'points', None) else None
+        pli = mint.PolylineIntegral()
+        pli.setGrid(grid)
+        pli.buildLocator(numCellsPerBucket=128, periodX=periodX, enableFolding=False)
+        pli.computeWeights(xyz, counterclock=False)
+        ce, w, sg = pli.getWeights()
+        d = {}
+        for x, y, z in zip(sg.tolist(), ce.tolist(), w.tolist()):
+            d[(x, y)] = d.get((x, y), 0.0) + z
+        od = oracle.polyline_weights(pts, xyz, periodX=periodX).as_dict()
+        assert set(d) == set(od) and max(abs(d[k] - od[k]) for k in od) <= 1e-13, periodX
