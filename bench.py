@@ -34,15 +34,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def flux_source_sha16():
-    """Fingerprint of what the flux kernels are compiled from (nf_flux.hip, nf_common.h, the compiler flags of the Makefile):
+    """Fingerprint of what the flux kernels are compiled from (nf_flux.hip, the marked parts of nf_common.h -- constants, XCD
+    tile map, launch arguments --, the compiler flags of the Makefile):
     the HBM-traffic figures under profiles/ are counters of ANOTHER run, so they carry this fingerprint and the commit they
     were taken at, and the bench reports them only while the sources still are what was measured (round-4 verdict W7)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     base = os.path.join(ROOT, 'nemoflux_amd', 'csrc')
-    for name in ('nf_flux.hip', 'nf_common.h'):
-        with open(os.path.join(base, name), 'rb') as f:
-            h.update(f.read())
+    with open(os.path.join(base, 'nf_flux.hip'), 'rb') as f:
+        h.update(f.read())
+    with open(os.path.join(base, 'nf_common.h')) as f:      # only what K1 uses of the shared header (marked there)
+        for part in re.findall(r'\[flux-fingerprint-begin\](.*?)\[flux-fingerprint-end\]', f.read(), re.S):
+            h.update(part.encode())
     with open(os.path.join(base, 'Makefile')) as f:
         h.update(''.join(l for l in f if l.startswith('CXXFLAGS')).encode())
     return h.hexdigest()[:16]

@@ -13,11 +13,13 @@
 
 namespace nf {
 
+// [flux-fingerprint-begin]  (bench.flux_source_sha16 hashes nf_flux.hip and the marked parts of this header: what K1 is built from)
 constexpr int kWave = 64;        // CDNA wavefront
 constexpr int kBlock = 256;      // 4 waves per workgroup
 constexpr int kXcds = 8;         // MI355X: 8 XCDs, workgroups are dealt round-robin over them
 constexpr double kDeg2Rad = 3.14159265358979323846 / 180.0;  // geo.py:4
 constexpr double kEarthRadiusSv = 6371000.0;                 // field.py:12
+// [flux-fingerprint-end]
 
 void set_error(const std::string &msg);
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
@@ -42,6 +44,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         if (rc_ != NF_OK) return rc_; \
     } while (0)
 
+// [flux-fingerprint-begin]
 // ---- XCD-aware tile mapping -------------------------------------------------------------------------
 // Workgroup b lands on XCD b % 8.  Give every XCD one CONTIGUOUS band of logical tiles so that (a) the
 // neighbour-slot stores of the edge-flux kernel (row j -> row j+1, column i -> i+1) meet the owning row's
@@ -49,6 +52,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 // Grid must be launched with xcd_grid(ntiles) workgroups; tiles >= ntiles exit.
 __host__ __device__ inline unsigned xcd_grid(unsigned ntiles) { return ((ntiles + kXcds - 1) / kXcds) * kXcds; }
 __device__ inline unsigned xcd_tile(unsigned b, unsigned grid) { return (b % kXcds) * (grid / kXcds) + b / kXcds; }
+// [flux-fingerprint-end]
 
 // ---- cells the weights / the point location are not defined on --------------------------------
 // v = (x0,y0,...,x3,y3) of a quad in the (lon,lat) plane
@@ -144,6 +148,7 @@ int launch_corner_table_from_points(const double *points, long ncell, double *xy
 int launch_points_from_corner_table(const double *xy, long ncell, double *points, hipStream_t s);
 double box_key_to_double(unsigned long long k);
 
+// [flux-fingerprint-begin]
 // several time steps in one launch (launch-bound small grids): step tb reads u,v + tb*in_stride, integrates levels
 // [zr[2tb], zr[2tb+1]) and writes planes iV + tb*4*ncell, abs + tb*2*ncell.  zr == nullptr: one step (z0, z1).
 struct StepBatch {
@@ -179,6 +184,7 @@ int launch_expand_planes(double *iV, double *absUV, long ncell, long ny, long nx
 int tuning_set(const char *name, int value);
 long tuning_version();
 int launch_planes_to_aos(const double *planes, long ncell, double *aos, hipStream_t s);
+// [flux-fingerprint-end]
 
 // K2: batched polyline weights.
 struct WeightSet {  // device-resident result: one record per (target segment, crossed cell), sorted by segment, ta
