@@ -1340,7 +1340,7 @@ try {
     }
     f->weights_built = false;
     const int bw = build_weights(f->d_xy, f->ncell, segs.data(), cc.data(), (int)cc.size(), periodX, &f->ws, f->stream,
-                                 f->skip_unsupported, f->overlap_warn);
+                                 f->skip_unsupported, f->overlap_warn, nullptr, f->nx);
     if (bw != NF_OK) {
         // over-covered segment (overlapping cells): name the transect and its own segment index, not the batch's
         for (size_t q = 0; q < f->ws.coverage.size(); ++q)

@@ -236,9 +236,10 @@ struct LocatorBoxes {
 // overlap_warn: 0 = a target segment covered more than once (over_covered) is an error (default); 1 = the build goes through,
 // out->over_seg names the first such segment and the coverage says how much (the caller warns)
 // boxes: nullptr = the locator lives for this build only (the batched build of a Field)
+// row_length: the cells are rows of this many (a Field's (ny, nx) grid: the locator groups them in 4 x 4 blocks); 0 = unknown
 int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
                   double periodX, WeightSet *out, hipStream_t s, int skip_unsupported = 0, int overlap_warn = 0,
-                  LocatorBoxes *boxes = nullptr);
+                  LocatorBoxes *boxes = nullptr, long row_length = 0);
 // gives the scratch memory that weight builds keep between calls (at most 512 MiB per host thread) back to the system
 void weights_trim_scratch();
 

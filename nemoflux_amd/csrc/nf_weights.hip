@@ -13,11 +13,12 @@
 // (a sub-segment running along a shared edge is counted once).
 //
 // Mapping to the hardware (round 5; until round 4 one wavefront owned 64 cells and walked ALL segment images, two lanes of 64
-// busy in the clip -- 16 / 95 / 723 ms for 65 / 512 / 4096 transects on the ORCA12-like grid, now 4.3 / 15 / 90 ms with the
+// busy in the clip -- 16 / 95 / 723 ms for 65 / 512 / 4096 transects on the ORCA12-like grid, now 4.5 / 12 / 68 ms with the
 // same bits: profiles/r05_weights_scaling.txt).  Everything is one lane per unit of work, compacted with ballot / popcount
 // and a scan between a count pass and a fill pass, so every list has a fixed order and the result is bitwise reproducible:
-//   1. locator (buildLocator): bounding boxes of the cells and of groups of 16, 256, 4096 ... consecutive cells, 16 bytes
-//      each, from one pass over the corner table;
+//   1. locator (buildLocator): bounding boxes of the cells and of groups of 16, 256, 4096 ... of them, 16 bytes each, from
+//      one pass over the corner table: 4 x 4 blocks of cells (then of blocks) when the cells are known to be rows of nx -- a
+//      Field's grid --, 16 consecutive cells for a flat mint.Grid;
 //   2. walk: (group, segment image) pairs from the root down, one lane per (pair, child): boxes apart? box corners on one
 //      side of the target line? -- no divisions; the last level leaves (cell, image) candidates;
 //   3. clip: one lane per candidate (Cyrus-Beck against the cell's four edges); hits become records (key, cell, image, ta,
@@ -188,9 +189,10 @@ constexpr unsigned long long kTaWindow = 112;  // > kTolT * 2^40 + 1
 
 // ---- the locator: a box hierarchy over the cells, walked breadth-first by all segment images at once ----------------------
 // mint's buildLocator bins the cells into buckets (field.py:47: numCellsPerBucket = 128) and computeWeights asks the buckets a
-// target segment passes through.  Here: the cells in their storage order are grouped 16 by 16 by 16 ... (16 cells, 256, 4096,
-// ... up to one root), every group with the bounding box of its cells (a row-major grid makes these strips of a grid row,
-// then bundles of rows; nothing is assumed about that -- any order gives valid boxes, a coherent one gives small boxes).
+// target segment passes through.  Here: the cells are grouped 16 by 16 by 16 ... (16 cells, 256, 4096, ... up to one root),
+// every group with the bounding box of its cells: 4 x 4 blocks when the row length of the grid is known (struct Layout), 16
+// consecutive cells otherwise (on a row-major grid: strips of a grid row, then bundles of rows; any order gives valid boxes, a
+// coherent one gives small boxes).
 // All (group, segment image) pairs whose box the segment may touch are expanded level by level, ONE LANE PER (pair, child):
 // bounding boxes first, then -- no divisions -- on which side of the target line the box's corners lie.  Every level is a count
 // pass (ballot masks per wavefront), a scan and a fill pass, so the pairs of a level come out in (image, group) order, run to
@@ -245,27 +247,47 @@ __device__ inline Box4 fan_union(double xmin, double xmax, double ymin, double y
     return outward(xmin, xmax, ymin, ymax);
 }
 
-// levels 0 and 1: the box of every cell and of every 16 consecutive cells, from the corner table
-__global__ __launch_bounds__(kBlock) void k_boxes_cells(const double *__restrict__ xy, long ncell, double period,
-                                                        Box4 *__restrict__ box0, Box4 *__restrict__ box1)
+// How the nodes of one level are laid out and which 16 nodes of the level below a node holds.  The cells of a Field are a
+// (ny, nx) array: its groups are 4 x 4 blocks of cells, then 4 x 4 blocks of blocks ... -- compact boxes, so that the number
+// of (group, line) pairs falls by four from one level to the next coarser one.  A mint.Grid is a flat list of cells whose row
+// length nobody told us: one row of nodes, 16 consecutive ones per group (on a row-major grid: strips of a grid row).
+struct Layout {
+    int ty, tx;     // the level below: ty rows of tx nodes (cells at the last level)
+    int fy, fx;     // a node holds fy x fx of them (fy * fx = 16)
+    int px;         // nodes per row of THIS level
+};
+// child j (0 .. 15) of node p, or -1 when it lies beyond the edge of the level below
+__device__ inline long child_of(const Layout &g, long p, int j)
 {
-    const long c = (long)blockIdx.x * kBlock + threadIdx.x;
-    double v[8], cxmin = 1e300, cxmax = -1e300, cymin = 1e300, cymax = -1e300, slack = 0.0;
-    if (c < ncell) cell_geometry(xy, c, period, v, cxmin, cxmax, cymin, cymax, slack);
-    // an absent or non-finite cell has an empty box and no slack: it adds nothing to its group
-    if (c < ncell) box0[c] = outward(cxmin - slack, cxmax + slack, cymin - slack, cymax + slack);
-    const Box4 b = fan_union(cxmin - slack, cxmax + slack, cymin - slack, cymax + slack);
-    if ((threadIdx.x & (kFan - 1)) == 0 && c < ncell) box1[c / kFan] = b;
+    const long py = p / g.px, pxx = p - py * g.px;
+    const long cy = py * g.fy + j / g.fx, cx = pxx * g.fx + j % g.fx;
+    return (cy < g.ty && cx < g.tx) ? cy * g.tx + cx : -1;
 }
 
-// level l + 1 from level l
-__global__ __launch_bounds__(kBlock) void k_boxes_up(const Box4 *__restrict__ in, long n_in, Box4 *__restrict__ out)
+// level 0: the box of every cell, from the corner table
+__global__ __launch_bounds__(kBlock) void k_boxes_cells(const double *__restrict__ xy, long ncell, double period,
+                                                        Box4 *__restrict__ box0)
 {
-    const long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long c = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= ncell) return;
+    double v[8], cxmin, cxmax, cymin, cymax, slack;
+    cell_geometry(xy, c, period, v, cxmin, cxmax, cymin, cymax, slack);
+    // a non-finite cell has an empty box and no slack: it adds nothing to its group
+    box0[c] = outward(cxmin - slack, cxmax + slack, cymin - slack, cymax + slack);
+}
+
+// level l + 1 from level l: lane j of every 16 loads child j of its node
+__global__ __launch_bounds__(kBlock) void k_boxes_up(const Box4 *__restrict__ in, Layout g, long n_out, Box4 *__restrict__ out)
+{
+    const long t = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long p = t / kFan;
     Box4 b = outward(1e300, -1e300, 1e300, -1e300);
-    if (i < n_in) b = in[i];
+    if (p < n_out) {
+        const long c = child_of(g, p, (int)(t & (kFan - 1)));
+        if (c >= 0) b = in[c];
+    }
     b = fan_union(b.xmin, b.xmax, b.ymin, b.ymax);     // floats are doubles: nothing moves
-    if ((threadIdx.x & (kFan - 1)) == 0 && i < n_in) out[i / kFan] = b;
+    if ((threadIdx.x & (kFan - 1)) == 0 && p < n_out) out[p] = b;
 }
 
 // count pass of a count / scan / fill step: every wavefront leaves its ballot mask, every workgroup the number of set bits
@@ -343,7 +365,7 @@ __device__ inline bool line_may_touch(const SegImage &g, const double *p /* 4 (x
 // wavefront and the number of set bits per workgroup.
 template <int NSHIFT>
 __global__ __launch_bounds__(kBlock) void k_walk_count(const int *__restrict__ pnode, const int *__restrict__ pimg, long np,
-                                                       const Box4 *__restrict__ box, long nchild,
+                                                       const Box4 *__restrict__ box, Layout lay,
                                                        const double *__restrict__ segs, int nshift, double periodX,
                                                        unsigned long long *__restrict__ wmask, int *__restrict__ bcnt)
 {
@@ -351,8 +373,8 @@ __global__ __launch_bounds__(kBlock) void k_walk_count(const int *__restrict__ p
     const long p = t / kFan;
     bool pass = false;
     if (p < np) {
-        const long child = (long)(pnode ? pnode[p] : 0) * kFan + (t & (kFan - 1));
-        if (child < nchild) {
+        const long child = child_of(lay, pnode ? pnode[p] : 0, (int)(t & (kFan - 1)));
+        if (child >= 0) {
             const SegImage g = load_image<NSHIFT>(segs, pimg ? pimg[p] : (int)p, nshift, periodX);
             if (!(g.dx == 0.0 && g.dy == 0.0)) {
                 const Box4 b = box[child];
@@ -364,9 +386,9 @@ __global__ __launch_bounds__(kBlock) void k_walk_count(const int *__restrict__ p
     block_count(__ballot(pass), wmask, bcnt);
 }
 
-// fill pass: the children that passed, in (pair, child) order = (image, group) order
+// fill pass: the children that passed, in (pair, child) order
 __global__ __launch_bounds__(kBlock) void k_walk_fill(const int *__restrict__ pnode, const int *__restrict__ pimg, long np,
-                                                      const unsigned long long *__restrict__ wmask,
+                                                      Layout lay, const unsigned long long *__restrict__ wmask,
                                                       const long *__restrict__ boff, int *__restrict__ cnode,
                                                       int *__restrict__ cimg)
 {
@@ -380,12 +402,12 @@ __global__ __launch_bounds__(kBlock) void k_walk_fill(const int *__restrict__ pn
     unsigned bits = (unsigned)(mask >> (kFan * sub)) & ((1u << kFan) - 1u);
     if (!bits) return;
     long pos = wave_offset(wmask, boff, cblock, w) + __popcll(mask & ((1ull << (kFan * sub)) - 1ull));
-    const long first = (long)(pnode ? pnode[p] : 0) * kFan;
+    const long node = pnode ? pnode[p] : 0;
     const int img = pimg ? pimg[p] : (int)p;
     while (bits) {
         const int j = __ffs(bits) - 1;
         bits &= bits - 1;
-        cnode[pos] = (int)(first + j);
+        cnode[pos] = (int)child_of(lay, node, j);
         cimg[pos] = img;
         ++pos;
     }
@@ -843,7 +865,8 @@ int fold_weights(WeightSet *ws, long ncell, long nx, hipStream_t s)
 }
 
 int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
-                  double periodX, WeightSet *out, hipStream_t s, int skip_unsupported, int overlap_warn, LocatorBoxes *keep)
+                  double periodX, WeightSet *out, hipStream_t s, int skip_unsupported, int overlap_warn, LocatorBoxes *keep,
+                  long row_length)
 {
     out->release();
     out->nseg = nseg;
@@ -883,12 +906,25 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
         NF_HIP(hipMemcpyAsync(d_cc, seg_cc_host, sizeof(int) * (size_t)nseg, hipMemcpyHostToDevice, s));
     }
 
-    // ---- the locator: box hierarchy over the cells (level 0 = the cells themselves, level l = groups of 16^l)
-    std::vector<long> nlev{ncell};
-    while (nlev.back() > 1) nlev.push_back((nlev.back() + kFan - 1) / kFan);
+    // ---- the locator: box hierarchy over the cells (level 0 = the cells themselves, a node of level l + 1 = 16 nodes of level l:
+    // 4 x 4 blocks when the cells are known to be rows of row_length, 16 consecutive ones otherwise)
+    const bool tiled = row_length > 1 && ncell % row_length == 0 && ncell / row_length > 1;
+    struct Shape {
+        long ty, tx;
+    };
+    std::vector<Shape> shape{tiled ? Shape{ncell / row_length, row_length} : Shape{1, ncell}};
+    const int fy = tiled ? 4 : 1, fx = tiled ? 4 : kFan;
+    while (shape.back().ty * shape.back().tx > 1)
+        shape.push_back(Shape{(shape.back().ty + fy - 1) / fy, (shape.back().tx + fx - 1) / fx});
+    std::vector<long> nlev;
+    for (const Shape &q : shape) nlev.push_back(q.ty * q.tx);
     const int top = (int)nlev.size() - 1;            // the root: one box (top == 0: a one-cell grid)
+    // layout[l]: how a node of level l finds its children in level l - 1
+    auto layout = [&](int l) {
+        return Layout{(int)shape[(size_t)l - 1].ty, (int)shape[(size_t)l - 1].tx, fy, fx, (int)shape[(size_t)l].tx};
+    };
     std::vector<Box4 *> boxes(nlev.size(), nullptr);
-    const bool cached = keep && keep->xy == xy && keep->ncell == ncell && keep->period == period &&
+    const bool cached = keep && keep->xy == xy && keep->ncell == ncell && keep->period == period && keep->count == nlev &&
                         keep->level.size() == nlev.size();
     if (cached) {
         for (size_t l = 0; l < nlev.size(); ++l) boxes[l] = static_cast<Box4 *>(keep->level[l]);
@@ -904,15 +940,12 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
         } else {
             for (size_t l = 0; l < nlev.size(); ++l) NF_HIP(misc.take(&boxes[l], (size_t)nlev[l]));
         }
-        for (int l = 1; l <= top; ++l) {
-            const long n_in = nlev[(size_t)l - 1];
-            const unsigned nb = (unsigned)((n_in + kBlock - 1) / kBlock);
-            if (l == 1)
-                hipLaunchKernelGGL(k_boxes_cells, dim3(nb), dim3(kBlock), 0, s, xy, ncell, period, boxes[0], boxes[1]);
-            else
-                hipLaunchKernelGGL(k_boxes_up, dim3(nb), dim3(kBlock), 0, s, (const Box4 *)boxes[(size_t)l - 1], n_in,
-                                   boxes[(size_t)l]);
-        }
+        if (top >= 1)
+            hipLaunchKernelGGL(k_boxes_cells, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, xy, ncell, period,
+                               boxes[0]);
+        for (int l = 1; l <= top; ++l)
+            hipLaunchKernelGGL(k_boxes_up, dim3((unsigned)((nlev[(size_t)l] * kFan + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                               (const Box4 *)boxes[(size_t)l - 1], layout(l), nlev[(size_t)l], boxes[(size_t)l]);
         NF_HIP(hipGetLastError());
         if (keep) {
             keep->xy = xy;
@@ -968,10 +1001,10 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
         const int *pn = p_node, *pi = p_img;
         if (nshift == 3)
             hipLaunchKernelGGL(k_walk_count<3>, dim3(nb), dim3(kBlock), 0, s, pn, pi, np, (const Box4 *)boxes[(size_t)l - 1],
-                               nlev[(size_t)l - 1], (const double *)d_segs, nshift, periodX, w_mask, w_cnt);
+                               layout(l), (const double *)d_segs, nshift, periodX, w_mask, w_cnt);
         else
             hipLaunchKernelGGL(k_walk_count<1>, dim3(nb), dim3(kBlock), 0, s, pn, pi, np, (const Box4 *)boxes[(size_t)l - 1],
-                               nlev[(size_t)l - 1], (const double *)d_segs, nshift, periodX, w_mask, w_cnt);
+                               layout(l), (const double *)d_segs, nshift, periodX, w_mask, w_cnt);
         long nchild = 0;
         NF_TRY(scan_waves(nw, &nchild));
         // the children go to the other arena: what it held (the parents of this level's parents) is dead.  Kernels that read
@@ -982,7 +1015,7 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
         NF_HIP(dst.take(&c_node, (size_t)nchild));
         NF_HIP(dst.take(&c_img, (size_t)nchild));
         if (nchild > 0)
-            hipLaunchKernelGGL(k_walk_fill, dim3((unsigned)((np + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, pn, pi, np,
+            hipLaunchKernelGGL(k_walk_fill, dim3((unsigned)((np + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, pn, pi, np, layout(l),
                                (const unsigned long long *)w_mask, (const long *)w_off, c_node, c_img);
         NF_HIP(hipGetLastError());
         p_node = c_node;
