@@ -92,6 +92,10 @@ int mnt_grid_del(Grid_t **self);
  * must outlive the grid, as in mint; the corner (lon,lat) pairs are uploaded to HBM by mnt_grid_build. */
 int mnt_grid_setPointsPtr(Grid_t **self, double *points);
 int mnt_grid_build(Grid_t **self, int nVertsPerCell, long long ncells);
+/* extension (not in mint): the cells handed to setPoints are the rows of a (ny, nx) grid, nx = rowLength -- what
+ * horizgrid.py:17-22 flattens.  Only a hint: the weights do not depend on it, the locator groups the cells in 4 x 4 blocks
+ * instead of 16 consecutive ones and long target lines are located several times faster.  0 = unknown (default). */
+int mnt_grid_setRowLength(Grid_t **self, long long rowLength);
 /* mint.Grid.getNumberOfCells()                  horizgrid.py:30 */
 int mnt_grid_getNumberOfCells(Grid_t **self, size_t *numCells);
 /* mint.Grid.dump(fileName): legacy-VTK unstructured grid  horizgrid.py:43 */

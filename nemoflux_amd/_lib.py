@@ -62,6 +62,7 @@ _sig('mnt_grid_del', [_pp])
 _sig('mnt_grid_setPointsPtr', [_pp, c_double_p])
 _sig('mnt_grid_build', [_pp, ctypes.c_int, ctypes.c_longlong])
 _sig('mnt_grid_getNumberOfCells', [_pp, ctypes.POINTER(ctypes.c_size_t)])
+_sig('mnt_grid_setRowLength', [_pp, ctypes.c_longlong])
 _sig('mnt_grid_dump', [_pp, ctypes.c_char_p])
 _sig('mnt_polylineintegral_new', [_pp])
 _sig('mnt_polylineintegral_del', [_pp])

@@ -301,6 +301,7 @@ struct Grid_t {
     bool owns_xy = true;
     long version = 0;               // bumped by every build: weights / located points of an older build are refused
     LocatorBoxes boxes;             // the locator of this grid (filled by the first computeWeights, dropped when the points change)
+    long row_length = 0;            // mnt_grid_setRowLength: the cells are rows of this many (0 = a flat list, like mint's)
 };
 
 struct PolylineIntegral_t {
@@ -367,6 +368,15 @@ try {
     NF_TRY(launch_corner_table_from_points(points.as<double>(), g->ncell, g->d_xy, nullptr));
     NF_HIP(hipDeviceSynchronize());
     ++g->version;
+    return NF_OK;
+}
+NF_API_CATCH
+int mnt_grid_setRowLength(Grid_t **self, long long rowLength)
+try {
+    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_grid_setRowLength: null grid");
+    NF_REQUIRE(rowLength >= 0, NF_ERR_ARG, "mnt_grid_setRowLength: negative row length");
+    if ((*self)->row_length != (long)rowLength) (*self)->boxes.release();    // the groups of the locator follow the layout
+    (*self)->row_length = (long)rowLength;
     return NF_OK;
 }
 NF_API_CATCH
@@ -504,7 +514,7 @@ try {
     p->stage.release();
     p->h_cell.clear();
     NF_TRY(build_weights(p->grid->d_xy, p->grid->ncell, segs.data(), cc.data(), p->nseg, p->periodX, &p->ws, nullptr,
-                         p->skip_unsupported, p->overlap_warn, &p->grid->boxes));
+                         p->skip_unsupported, p->overlap_warn, &p->grid->boxes, p->grid->row_length));
     NF_TRY(dev_alloc(&p->d_tr_off, 2));
     NF_TRY(dev_alloc(&p->d_scratch, (size_t)p->ws.nrec));
     const int off[2] = {0, p->nseg};
@@ -1207,6 +1217,7 @@ try {
     f->grid_view.ncell = f->ncell;
     f->grid_view.d_xy = f->d_xy;
     f->grid_view.boxes.release();     // a locator built on the old corner table says nothing about the new one
+    f->grid_view.row_length = f->nx;
     ++f->grid_view.version;
     f->grid_view.owns_xy = false;
     f->weights_built = false;

@@ -36,6 +36,7 @@ class HorizGrid(object):
         self._points = _geometry_only(bounds_lon, bounds_lat)['points']
         self.grid = mint.Grid()
         self.grid.setPoints(self._points)  # horizgrid.py:23-24
+        self.grid.setRowLength(nx)         # hint for the locator (the reference's mint.Grid has no such call; optional)
 
     @property
     def points(self):

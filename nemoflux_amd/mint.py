@@ -57,6 +57,11 @@ class Grid(object):
         check(lib.mnt_grid_setPointsPtr(ctypes.byref(self.obj), _lib.dptr(pts)))
         check(lib.mnt_grid_build(ctypes.byref(self.obj), 4, pts.shape[0]))
 
+    def setRowLength(self, nx):
+        """Extension (not in mint): the cells are the rows of a (ny, nx) grid.  A hint for the locator only -- long target
+        lines are located faster; the weights do not change."""
+        check(lib.mnt_grid_setRowLength(ctypes.byref(self.obj), int(nx)))
+
     def getNumberOfCells(self):
         n = ctypes.c_size_t()
         check(lib.mnt_grid_getNumberOfCells(ctypes.byref(self.obj), ctypes.byref(n)))

@@ -1440,10 +1440,12 @@ def test_gpu_weight_entries_against_an_independent_sampling_algorithm(geometry, 
 
 
 # ------------------------------------------------------------------------------------------ date-line-wrapped bounds (round 4)
-def _gpu_weights(pts, xyz, periodX=360.):
+def _gpu_weights(pts, xyz, periodX=360., row_length=0):
     from nemoflux_amd import mint
     grid = mint.Grid()
     grid.setPoints(pts)
+    if row_length:
+        grid.setRowLength(row_length)      # locator hint: 4 x 4 blocks of cells instead of 16 consecutive ones
     pli = mint.PolylineIntegral()
     pli.setGrid(grid)
     pli.buildLocator(numCellsPerBucket=128, periodX=periodX, enableFolding=False)
@@ -1485,6 +1487,9 @@ def test_locator_hierarchy_on_small_and_ragged_grids(nx, ny, oracle):
             assert set(d) == set(od), (nx, ny, periodX, k)
             assert not od or max(abs(d[q] - od[q]) for q in od) <= 1e-13
             assert numpy.allclose(pli.getCoverage(), ow.coverage, rtol=0, atol=1e-12)
+            # the same with the row length known to the locator (4 x 4 blocks): the same records in the same order
+            pli2, _, d2 = _gpu_weights(pts, xyz, periodX=periodX, row_length=nx)
+            assert d2 == d and all(numpy.array_equal(a, b) for a, b in zip(pli.getWeights(), pli2.getWeights()))
             if k == 4:
                 assert not d and numpy.all(pli.getCoverage() == 0.)
             if k in (2, 3):     # every point of a line along shared edges is counted once
