@@ -62,7 +62,7 @@ int nf_memcpy_h2d(void *dev, const void *host, size_t bytes);
 int nf_memcpy_d2h(void *host, const void *dev, size_t bytes);
 int nf_memset(void *dev, int value, size_t bytes);
 int nf_synchronize(void);
-/* Weight builds keep their scratch memory between calls while it is small (at most 512 MiB of HBM per host thread: a viewer
+/* Weight builds keep their scratch memory between calls while it is small (at most 1 GiB of HBM per host thread: a viewer
  * makes one PolylineIntegral per transect and each build would otherwise pay a dozen hipMalloc / hipFree pairs).  This gives
  * the calling thread's share back to the system. */
 int nf_release_scratch(void);

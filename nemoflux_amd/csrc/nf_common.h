@@ -240,7 +240,7 @@ struct LocatorBoxes {
 int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
                   double periodX, WeightSet *out, hipStream_t s, int skip_unsupported = 0, int overlap_warn = 0,
                   LocatorBoxes *boxes = nullptr, long row_length = 0);
-// gives the scratch memory that weight builds keep between calls (at most 512 MiB per host thread) back to the system
+// gives the scratch memory that weight builds keep between calls (at most 1 GiB per host thread) back to the system
 void weights_trim_scratch();
 
 // K3: gather + wavefront segmented reduction -> per-segment sums, then per-transect sums.

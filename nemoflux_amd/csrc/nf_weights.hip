@@ -13,7 +13,7 @@
 // (a sub-segment running along a shared edge is counted once).
 //
 // Mapping to the hardware (round 5; until round 4 one wavefront owned 64 cells and walked ALL segment images, two lanes of 64
-// busy in the clip -- 16 / 95 / 723 ms for 65 / 512 / 4096 transects on the ORCA12-like grid, now 4.5 / 12 / 68 ms with the
+// busy in the clip -- 16 / 95 / 723 ms for 65 / 512 / 4096 transects on the ORCA12-like grid, now 2.9 / 12 / 68 ms with the
 // same bits: profiles/r05_weights_scaling.txt).  Everything is one lane per unit of work, compacted with ballot / popcount
 // and a scan between a count pass and a fill pass, so every list has a fixed order and the result is bitwise reproducible:
 //   1. locator (buildLocator): bounding boxes of the cells and of groups of 16, 256, 4096 ... of them, 16 bytes each, from
@@ -743,7 +743,7 @@ struct BuildScratch {
         return n;
     }
 };
-constexpr size_t kScratchKeep = 512ull << 20;
+constexpr size_t kScratchKeep = 1024ull << 20;   // the 65-transect batch of the ORCA12-like grid needs 0.9 GiB
 static thread_local BuildScratch *t_scratch = nullptr;   // never freed at thread exit (the HIP runtime may be gone by then)
 
 struct ScratchLease {   // takes the cached scratch (or a new one) for one build; gives it back only if told the stream is drained
