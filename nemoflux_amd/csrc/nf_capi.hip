@@ -704,24 +704,8 @@ try {
     NF_TRY(dev_alloc(&v->d_cell, numPoints));
     NF_TRY(dev_alloc(&v->d_best, numPoints));
     NF_HIP(hipMemcpy(v->d_targets, targetPoints, sizeof(double) * 3 * numPoints, hipMemcpyHostToDevice));
-    {   // order the points by y for the locator's range search (index bookkeeping only)
-        std::vector<long> order(numPoints);
-        for (size_t i = 0; i < numPoints; ++i) order[i] = (long)i;
-        std::stable_sort(order.begin(), order.end(),
-                         [&](long a, long b) { return targetPoints[3 * a + 1] < targetPoints[3 * b + 1]; });
-        std::vector<double> sorted(3 * numPoints);
-        for (size_t q = 0; q < numPoints; ++q)
-            for (int k = 0; k < 3; ++k) sorted[3 * q + k] = targetPoints[3 * order[q] + k];
-        DevTmp d_sorted, d_order;
-        NF_TRY(d_sorted.alloc(sizeof(double) * 3 * numPoints));
-        NF_TRY(d_order.alloc(sizeof(long) * numPoints));
-        NF_HIP(hipMemcpy(d_sorted.p, sorted.data(), sizeof(double) * 3 * numPoints, hipMemcpyHostToDevice));
-        NF_HIP(hipMemcpy(d_order.p, order.data(), sizeof(long) * numPoints, hipMemcpyHostToDevice));
-        NF_TRY(launch_find_points(v->grid->d_xy, v->grid->ncell, v->d_targets, d_sorted.as<double>(),
-                                  d_order.as<long>(), v->npts, v->periodX, tol2, v->d_best, v->d_cell, v->d_pcoords,
-                                  nullptr));
-        NF_HIP(hipDeviceSynchronize());
-    }
+    NF_TRY(launch_find_points(v->grid->d_xy, v->grid->ncell, v->grid->row_length, &v->grid->boxes, v->d_targets, v->npts,
+                              v->periodX, tol2, v->d_best, v->d_cell, v->d_pcoords, nullptr));
     v->h_cell.resize(numPoints);      // the located cells stay on the host too: they address the caller's host arrays
     NF_HIP(hipMemcpy(v->h_cell.data(), v->d_cell, sizeof(long) * numPoints, hipMemcpyDeviceToHost));
     NF_TRY(v->stage.resize((long)numPoints));

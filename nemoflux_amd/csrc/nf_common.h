@@ -258,9 +258,9 @@ int launch_integral(const WeightSet &ws, const double *data, long ncell, int pla
 
 // VectorInterp (field.py:90-95,119-120)
 // targets_dev: caller order (n,3); sorted_dev: the same points sorted by y; order_dev: caller index of sorted point q
-int launch_find_points(const double *xy, long ncell, const double *targets_dev, const double *sorted_dev,
-                       const long *order_dev, long npts, double periodX, double tol2, unsigned long long *best_dev,
-                       long *cell_dev, double *pcoords_dev, hipStream_t s);
+int launch_find_points(const double *xy, long ncell, long row_length, LocatorBoxes *keep, const double *targets_dev, long npts,
+                       double periodX, double tol2, unsigned long long *best_dev, long *cell_dev, double *pcoords_dev,
+                       hipStream_t s);
 int launch_face_vectors(const double *xy, const long *cell_dev, const double *pcoords_dev, long npts, const double *data,
                         long ncell, int planes, double periodX, double *vectors_dev, hipStream_t s);
 

@@ -5,14 +5,17 @@
 //           not vendored: "parity unpinned" beyond README.md:36 (psi = x -> the arrows point down in y).
 //
 //   findPoints:  every target point (tried at x - periodX, x, x + periodX) is located in the cell with the lowest id
-//                whose bilinear parameters (xi, eta) lie in [-tol, 1+tol]^2, tol = sqrt(tol2).  One wavefront owns 64
-//                consecutive cells (corner rows staged through LDS, as in K2); the point list is wave-uniform; a wave
-//                bounding box rejects almost every (tile, point) pair; winners are resolved with a 64-bit atomicMin
-//                on the key cell*4 + shift, which is order-independent, so the result is deterministic.
+//                whose bilinear parameters (xi, eta) lie in [-tol, 1+tol]^2, tol = sqrt(tol2).  The candidates come from
+//                the grid's locator (nf_locator.h: the box hierarchy of the weight build, walked by all point images at
+//                once, one lane per (group, point, child)); one lane per (cell, point image) candidate then applies the
+//                exact test; winners are resolved with a 64-bit atomicMin on the key cell*4 + shift, which is
+//                order-independent, so the result is deterministic.  (Until round 5 every 64-cell tile scanned the points
+//                of its latitude range: 746 ms for 2 M points on the ORCA12-like grid; tools/findpoints_timing.py.)
 //   getFaceVectors: one lane per located point,
 //                V = [ (d3 (1-xi) + d1 xi) r_xi - (d0 (1-eta) + d2 eta) r_eta ] / J,  J = r_xi x r_eta
 //                with d0..d3 = the cell's S,E,N,W edge data ((ncell,4) AoS or the engine's [4][ncell] planes).
 #include "nf_common.h"
+#include "nf_locator.h"
 
 namespace nf {
 
@@ -54,70 +57,68 @@ __device__ inline double vmax64(double x)
     return x;
 }
 
-// targets are sorted by y (order[] gives the caller's index), so a wave only visits the points whose y falls in
-// its tile's bounding box: two wave-uniform binary searches instead of a scan of all points
-__global__ __launch_bounds__(kBlock) void k_find_points(const double *__restrict__ xy, long ncell,
-                                                        const double *__restrict__ targets,
-                                                        const long *__restrict__ order, long npts, int nshift,
-                                                        double periodX, double tol, unsigned long long *best)
+// the walk's test for points: lane t = child (t % 16) of pair (t / 16).  An image is point img / nshift moved by one of the
+// nshift periods.  A point within the per-cell slack of the exact test below (1e-6 x the cell's coordinates) of a cell is
+// within this margin of every box that holds the cell.
+__global__ __launch_bounds__(kBlock) void k_walk_count_points(const int *__restrict__ pnode, const int *__restrict__ pimg, long np,
+                                                              const Box4 *__restrict__ box, Layout lay,
+                                                              const double *__restrict__ targets, int nshift, double periodX,
+                                                              unsigned long long *__restrict__ wmask, int *__restrict__ bcnt)
 {
-    __shared__ double s_xy[kBlock * 8];
-    const int tid = threadIdx.x;
-    const long c0 = (long)blockIdx.x * kBlock;
-    const long nval = ncell * 8;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        long g = c0 * 8 + tid + r * kBlock;
-        if (g < nval) s_xy[tid + r * kBlock] = xy[g];
+    const long t = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long p = t / kFan;
+    bool pass = false;
+    if (p < np) {
+        const long child = child_of(lay, pnode ? pnode[p] : 0, (int)(t & (kFan - 1)));
+        if (child >= 0) {
+            const int img = pimg ? pimg[p] : (int)p;
+            const int q = img / nshift, k = img - q * nshift;
+            const double px = targets[3 * (long)q] + (nshift == 3 ? k - 1 : 0) * periodX, py = targets[3 * (long)q + 1];
+            const Box4 b = box[child];
+            const double m = 1.e-6 * (2.0 * fmax(fabs((double)b.xmin), fabs((double)b.xmax)) +
+                                      2.0 * fmax(fabs((double)b.ymin), fabs((double)b.ymax)) + 1.0);
+            pass = px >= b.xmin - m && px <= b.xmax + m && py >= b.ymin - m && py <= b.ymax + m;
+        }
     }
-    __syncthreads();
-    const long c = c0 + tid;
-    bool valid = c < ncell;
+    block_count(__ballot(pass), wmask, bcnt);
+}
+
+// the exact test, one lane per (cell, point image) candidate
+__global__ __launch_bounds__(kBlock) void k_locate_pairs(const double *__restrict__ xy, const int *__restrict__ ccell,
+                                                         const int *__restrict__ cimg, long nc,
+                                                         const double *__restrict__ targets, int nshift, double periodX,
+                                                         double tol, unsigned long long *best)
+{
+    const long t = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= nc) return;
+    const long c = ccell[t];
+    const int img = cimg[t];
+    const int q = img / nshift, k = img - q * nshift;
+    const double px = targets[3 * (long)q] + (nshift == 3 ? k - 1 : 0) * periodX, ty = targets[3 * (long)q + 1];
     double v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = xy[c * 8 + i];
+    if (!quad_is_finite(v)) return;                // NaN / infinite corners: not a cell
+    unwrap_quad(v, nshift == 3 ? periodX : 0.0);   // date-line cells, as in K2 (nf_common.h)
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = valid ? s_xy[tid * 8 + k] : 0.0;
-    valid = valid && quad_is_finite(v);            // NaN / infinite corners: not a cell
-    unwrap_quad(v, nshift == 3 ? periodX : 0.0);   // date-line cells, as in K2 (nf_common.h)
-    if (valid) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            xmin = fmin(xmin, v[2 * i]);
-            xmax = fmax(xmax, v[2 * i]);
-            ymin = fmin(ymin, v[2 * i + 1]);
-            ymax = fmax(ymax, v[2 * i + 1]);
-        }
+    for (int i = 0; i < 4; ++i) {
+        xmin = fmin(xmin, v[2 * i]);
+        xmax = fmax(xmax, v[2 * i]);
+        ymin = fmin(ymin, v[2 * i + 1]);
+        ymax = fmax(ymax, v[2 * i + 1]);
     }
-    const double slack = valid ? 1.e-6 * (fabs(xmin) + fabs(xmax) + fabs(ymin) + fabs(ymax) + 1.0) : 0.0;
-    const bool unusable = valid && quad_is_nonconvex(v);
-    const double wslack = vmax64(slack);
-    const double wxmin = vmin64(xmin) - wslack, wxmax = vmax64(xmax) + wslack;
-    const double wymin = vmin64(ymin) - wslack, wymax = vmax64(ymax) + wslack;
-    long lo = 0, hi = npts;  // first point with y >= wymin
-    while (lo < hi) {
-        const long mid = (lo + hi) >> 1;
-        if (targets[3 * mid + 1] < wymin) lo = mid + 1;
-        else hi = mid;
-    }
-    for (long q = lo; q < npts; ++q) {
-        const double tx = targets[3 * q], ty = targets[3 * q + 1];
-        if (ty > wymax) break;  // wave-uniform
-        const long p = order[q];
-        for (int k = 0; k < nshift; ++k) {
-            const double px = tx + (nshift == 3 ? k - 1 : 0) * periodX;
-            if (px < wxmin || px > wxmax) continue;  // wave-uniform
-            if (!valid || px < xmin - slack || px > xmax + slack || ty < ymin - slack || ty > ymax + slack) continue;
-            if (unusable) continue;   // no inverse bilinear map in a non-convex / pole-vertex cell: the point is "not found" there
-            double xi, eta;
-            inv_bilinear_v(v, px, ty, xi, eta);
-            if (xi >= -tol && xi <= 1.0 + tol && eta >= -tol && eta <= 1.0 + tol) {
-                // Newton must have converged onto the point
-                const double mx = ((v[0] + xi * (v[2] - v[0])) + eta * (v[6] - v[0])) + (xi * eta) * ((v[0] - v[2]) + (v[4] - v[6])) - px;
-                const double my = ((v[1] + xi * (v[3] - v[1])) + eta * (v[7] - v[1])) + (xi * eta) * ((v[1] - v[3]) + (v[5] - v[7])) - ty;
-                if (fabs(mx) + fabs(my) <= 1.e-9 * ((xmax - xmin) + (ymax - ymin)))
-                    atomicMin(&best[p], (unsigned long long)c * 4 + (unsigned long long)k);
-            }
-        }
+    const double slack = 1.e-6 * (fabs(xmin) + fabs(xmax) + fabs(ymin) + fabs(ymax) + 1.0);
+    if (px < xmin - slack || px > xmax + slack || ty < ymin - slack || ty > ymax + slack) return;
+    if (quad_is_nonconvex(v)) return;   // no inverse bilinear map in a non-convex / pole-vertex cell: the point is "not found" there
+    double xi, eta;
+    inv_bilinear_v(v, px, ty, xi, eta);
+    if (xi >= -tol && xi <= 1.0 + tol && eta >= -tol && eta <= 1.0 + tol) {
+        // Newton must have converged onto the point
+        const double mx = ((v[0] + xi * (v[2] - v[0])) + eta * (v[6] - v[0])) + (xi * eta) * ((v[0] - v[2]) + (v[4] - v[6])) - px;
+        const double my = ((v[1] + xi * (v[3] - v[1])) + eta * (v[7] - v[1])) + (xi * eta) * ((v[1] - v[3]) + (v[5] - v[7])) - ty;
+        if (fabs(mx) + fabs(my) <= 1.e-9 * ((xmax - xmin) + (ymax - ymin)))
+            atomicMin(&best[q], (unsigned long long)c * 4 + (unsigned long long)k);
     }
 }
 
@@ -194,18 +195,34 @@ __global__ __launch_bounds__(kBlock) void k_face_vectors(const double *__restric
     vectors[3 * p + 2] = 0.0;
 }
 
-int launch_find_points(const double *xy, long ncell, const double *targets_dev, const double *sorted_dev,
-                       const long *order_dev, long npts, double periodX, double tol2, unsigned long long *best_dev,
-                       long *cell_dev, double *pcoords_dev, hipStream_t s)
+int launch_find_points(const double *xy, long ncell, long row_length, LocatorBoxes *keep, const double *targets_dev, long npts,
+                       double periodX, double tol2, unsigned long long *best_dev, long *cell_dev, double *pcoords_dev,
+                       hipStream_t s)
 {
     if (npts == 0) return NF_OK;
     const int nshift = periodX > 0.0 ? 3 : 1;
+    NF_REQUIRE(npts * nshift < (1l << 31), NF_ERR_ARG, "findPoints: too many target points for one call (2^31 / 3)");
     NF_HIP(hipMemsetAsync(best_dev, 0xff, sizeof(unsigned long long) * npts, s));
-    hipLaunchKernelGGL(k_find_points, dim3((unsigned)((ncell + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, xy, ncell,
-                       sorted_dev, order_dev, npts, nshift, periodX, sqrt(tol2), best_dev);
+    ScratchLease lease;
+    Walker wk(*lease.sc, s);
+    NF_TRY(wk.prepare(xy, ncell, nshift == 3 ? periodX : 0.0, row_length, keep));
+    int *c_cell = nullptr, *c_img = nullptr;
+    long nc = 0;
+    NF_TRY(wk.walk(npts * nshift,
+                   [&](int, const int *pn, const int *pi, long npairs, const Box4 *child_boxes, Layout lay, unsigned nb,
+                       unsigned long long *mask, int *cnt) {
+                       hipLaunchKernelGGL(k_walk_count_points, dim3(nb), dim3(kBlock), 0, s, pn, pi, npairs, child_boxes, lay,
+                                          targets_dev, nshift, periodX, mask, cnt);
+                   },
+                   &c_cell, &c_img, &nc));
+    if (nc > 0)
+        hipLaunchKernelGGL(k_locate_pairs, dim3((unsigned)((nc + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, xy, (const int *)c_cell,
+                           (const int *)c_img, nc, targets_dev, nshift, periodX, sqrt(tol2), best_dev);
     hipLaunchKernelGGL(k_locate_finish, dim3((unsigned)((npts + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, xy,
                        targets_dev, npts, nshift, periodX, best_dev, cell_dev, pcoords_dev);
     NF_HIP(hipGetLastError());
+    NF_HIP(hipStreamSynchronize(s));
+    lease.drained = true;
     return NF_OK;
 }
 
