@@ -46,17 +46,6 @@ __device__ inline void inv_bilinear_v(const double *v, double px, double py, dou
     xi1 = t;
 }
 
-__device__ inline double vmin64(double x)
-{
-    for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o, kWave));
-    return x;
-}
-__device__ inline double vmax64(double x)
-{
-    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, kWave));
-    return x;
-}
-
 // the walk's test for points: lane t = child (t % 16) of pair (t / 16).  An image is point img / nshift moved by one of the
 // nshift periods.  A point within the per-cell slack of the exact test below (1e-6 x the cell's coordinates) of a cell is
 // within this margin of every box that holds the cell.
