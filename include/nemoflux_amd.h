@@ -107,7 +107,8 @@ int mnt_polylineintegral_del(PolylineIntegral_t **self);
 /* .setGrid(grid)                                field.py:46 */
 int mnt_polylineintegral_setGrid(PolylineIntegral_t **self, Grid_t *grid);
 /* .buildLocator(numCellsPerBucket=128, periodX=360., enableFolding=False)   field.py:47
- * numCellsPerBucket sets the cull-tile size (rounded to the 64-cell wavefront tile); enableFolding != 0
+ * The locator is a 16-fold hierarchy of bounding boxes over the cells, built at the first computeWeights / findPoints on the
+ * grid and kept by the grid (nf_locator.h); numCellsPerBucket must be positive and has nothing to tune; enableFolding != 0
  * is rejected (nemoflux never enables it).  periodX > 0: target lines are also tried one period to the west and to the east,
  * and every cell's corners are brought to within periodX/2 of its corner 0 before the cell is used (a global file stores
  * bounds_lon wrapped into one period, so the cells on the cut have corners ~355 degrees apart: datagen.py:161-166 is the

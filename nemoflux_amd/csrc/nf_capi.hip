@@ -458,7 +458,7 @@ try {
     NF_REQUIRE(periodX >= 0.0, NF_ERR_ARG, "mnt_polylineintegral_buildLocator: negative periodX");
     NF_REQUIRE(!enableFolding, NF_ERR_ARG, "mnt_polylineintegral_buildLocator: enableFolding is not supported");
     (*self)->periodX = periodX;
-    (*self)->locator = true;  // the cull tile is the 64-cell wavefront tile, rebuilt inside computeWeights
+    (*self)->locator = true;  // the box hierarchy itself is built (and kept by the grid) at the first computeWeights
     return NF_OK;
 }
 NF_API_CATCH
