@@ -171,3 +171,19 @@ def test_c4_size_land_block_is_filled_with_zero(real):
     del dg, u, v
     gc.collect()
     torch.cuda.empty_cache()
+
+
+def test_weight_build_at_scale_1024_transects():
+    """The weight build (K2, rebuilt in round 5 around a box hierarchy walked by all segment images) far beyond the 65-polyline
+    batch of config C5: 1 024 seeded node-snapped polylines (36 000 target segments, ~85 M weight records) on the ORCA12-like
+    grid, x-periodic psi, polylines that cross the +-180 seam and column 0 -- every target segment inside the grid exactly
+    once (coverage 1), every per-segment sum equal to the stream-function difference, closed loops zero.  One time step: the
+    geometry is what is under test."""
+    from nemoflux_amd.datagen import STREAM_FUNCTIONS
+    psi = STREAM_FUNCTIONS[3]
+    polys = bench.make_transects(NX, NY, *BOX, 1021, seed=20260405, seam=True)
+    assert len(polys) == 1024
+    tot, segs, off, nrec = _run_case(psi, polys, 'float64', nt=1)
+    assert nrec > 60_000_000
+    worst_seg, worst_tot = _check(psi, polys, 'float64', tot, segs, off, NT=1)
+    assert worst_seg <= 2e-12 and worst_tot <= 2e-12 * 8
