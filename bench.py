@@ -150,6 +150,13 @@ def run_workload(args, dtype, scaling, rank, world, local, want_totals=False, em
         fld = Field.fromArrays(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, ug, vg, xyzs, slab_range=srange,
                                readback=False, stream=stream, compact=args.compact)
     setup_s = time.time() - t0
+    # the weight build (K2) of this transect batch on its own: a second build of the same weights, timed (the first one above
+    # also paid the first-use costs of the process)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    check(lib.nf_field_build_weights(ctypes.byref(fld._h), 128, ctypes.c_double(360.)))
+    torch.cuda.synchronize()
+    weights_build_ms = (time.perf_counter() - t0) * 1e3
     rows = torch.zeros((nt_global, fld._rowlen), dtype=torch.float64, device='cuda')
 
     def step():
@@ -190,7 +197,7 @@ def run_workload(args, dtype, scaling, rank, world, local, want_totals=False, em
     if emulate:     # the rank's own share: what it integrates per pass
         units_total = float(srange[1] - srange[0]) * ny * nx
     m = {'value': units_total * args.steps / elapsed, 'ms_per_step': elapsed / args.steps * 1e3,
-         'nt_global': nt_global, 'setup_s': setup_s, 'psi': psi, 'polys': polys, 'nseg': fld._nseg,
+         'nt_global': nt_global, 'setup_s': setup_s, 'weights_build_ms': weights_build_ms, 'psi': psi, 'polys': polys, 'nseg': fld._nseg,
          'weight_entries': int(fld.getWeights()[0].size), 'dg': dg, 'u': u, 'v': v, 'xyz0': xyzs[0]}
 
     # ---- the one collective of the N>1 path, timed on its own after the timed region (message = the rows)
@@ -371,7 +378,7 @@ def main():
                    'parallelism': f'(t,z)-slab sharding x{world}, 1 all-reduce',
                    'resident_outputs': 'eU,eV only (compact, non-headline)' if args.compact else
                                        'integratedVelocity [4][ncell] + |eU|,|eV| every step',
-                   'setup_s': round(m['setup_s'], 3)},
+                   'setup_s': round(m['setup_s'], 3), 'weights_build_ms': round(m['weights_build_ms'], 3)},
         'roofline': m['roofline'],
         'accuracy': m['accuracy'],
     }
