@@ -664,8 +664,6 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     // candidates, in (image, then walk) order -- nf_locator.h; the test of a pair is k_walk_count's
     Walker wk(*lease.sc, s);
     NF_TRY(wk.prepare(xy, ncell, period, row_length, keep));
-    const int top = wk.top;
-    (void)top;
     int *p_node = nullptr, *p_img = nullptr;
     long np = 0;
     NF_TRY(wk.walk((long)nseg * nshift,
