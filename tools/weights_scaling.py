@@ -3,7 +3,7 @@
 mint-shaped weights (cell*4+edge, weight, segment) up to 512 transects, of the per-segment / per-transect rows of one time
 step always -- so that two builds of the library can be compared bit for bit.
 
-usage: python tools/weights_scaling.py [label] [counts, default 65,512,4096]
+usage: python tools/weights_scaling.py [label] [counts, default 65,512,4096] [rot: the grid with its pole moved by (20, 30) degrees]
 """
 import contextlib, ctypes, hashlib, io, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,16 +16,22 @@ from nemoflux_amd.field import Field
 label = sys.argv[1] if len(sys.argv) > 1 else ''
 counts = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else '65,512,4096').split(',')]
 nx, ny = 3600, 1800
+rot = len(sys.argv) > 3 and sys.argv[3] == 'rot'
 dg = DataGen(); dg.setSizes(nx, ny, 2, 1); dg.setBoundingBox(-180., 180., -90., 90., 0., 1.); dg.build()
+if rot:     # curvilinear: the cells' boxes are no longer the cells, the ones around the moved pole are large and unusable
+    dg.rotatePole((20., 30.))
 dg.applyStreamFunction(STREAM_FUNCTIONS[3]); u, v = dg.computeUVFromPotential()
-print(f'weight build vs number of transects {label}: {nx} x {ny} cells, periodX = 360 (3 images per target segment)')
+print(f'weight build vs number of transects {label}: {nx} x {ny} cells{" (rotated pole)" if rot else ""}, periodX = 360 (3 images per target segment)')
+import warnings
+warnings.simplefilter('ignore')
 for n in counts:
     polys = bench.make_transects(nx, ny, -180., 180., -90., 90., n - 3, seed=20260402, seam=True)
     xyzs = [numpy.array([(x, y, 0.) for x, y in p]) for p in polys]
     nseg = sum(len(p) - 1 for p in polys)
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
-        f = Field.fromArrays(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, u, v, xyzs, readback=False)
+        f = Field.fromArrays(dg.bounds_lon, dg.bounds_lat, dg.deptht_bounds, u, v, xyzs, readback=False,
+                             unsupportedCells='skip' if rot else 'refuse')
     t_field = time.perf_counter() - t0
     best = 1e30
     for rep in range(2):
