@@ -54,7 +54,7 @@ __host__ __device__ inline unsigned xcd_grid(unsigned ntiles) { return ((ntiles 
 __device__ inline unsigned xcd_tile(unsigned b, unsigned grid) { return (b % kXcds) * (grid / kXcds) + b / kXcds; }
 // [flux-fingerprint-end]
 
-// ---- cells the weights / the point location are not defined on --------------------------------
+// ---- cells the weights / the point location are not defined on (docs/PARITY.md) --------------------------------
 // v = (x0,y0,...,x3,y3) of a quad in the (lon,lat) plane
 __device__ inline bool quad_is_nonconvex(const double *v)
 {
