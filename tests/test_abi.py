@@ -108,6 +108,20 @@ def test_null_arguments_are_errors_not_crashes():
     assert lib.nf_field_del(ctypes.byref(h)) == 0
     assert lib.nf_field_del(ctypes.byref(h)) == 0          # deleting twice is harmless (handle was nulled)
     assert lib.nf_tuning_set(None, 0) == 1 and lib.nf_tuning_set(b'no_such_knob', 0) == 1
+    assert lib.nf_tuning_set(b'batch_cellsteps_m', -1) == 1 and lib.nf_tuning_set(b'batch_cellsteps_m', 32) == 0
+    # round-5 entry points: policy switches and hints check their arguments, the scratch release needs no GPU
+    g, pl, f = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.mnt_grid_new(ctypes.byref(g)) == 0 and lib.mnt_polylineintegral_new(ctypes.byref(pl)) == 0
+    assert lib.nf_field_new(ctypes.byref(f)) == 0
+    assert lib.mnt_grid_setRowLength(None, 4) == 1 and lib.mnt_grid_setRowLength(ctypes.byref(g), -1) == 1
+    assert lib.mnt_grid_setRowLength(ctypes.byref(g), 3600) == 0 and lib.mnt_grid_setRowLength(ctypes.byref(g), 0) == 0
+    assert lib.mnt_polylineintegral_setOverlappingCells(None, 0) == 1
+    assert lib.mnt_polylineintegral_setOverlappingCells(ctypes.byref(pl), 2) == 1 and b'0 (refuse) or 1 (warn)' in lib.nf_last_error()
+    assert lib.mnt_polylineintegral_setOverlappingCells(ctypes.byref(pl), 1) == 0
+    assert lib.nf_field_set_overlapping_cells(ctypes.byref(f), 3) == 1 and lib.nf_field_set_overlapping_cells(ctypes.byref(f), 0) == 0
+    assert lib.nf_release_scratch() == 0
+    assert lib.mnt_grid_del(ctypes.byref(g)) == 0 and lib.mnt_polylineintegral_del(ctypes.byref(pl)) == 0
+    assert lib.nf_field_del(ctypes.byref(f)) == 0
     assert lib.nf_inflater_new(None) == 1 and lib.nf_inflater_capacity(None) == 1
     assert lib.nf_inflater_run(None, None, 0, None, None, 0, 0, 4, 0, None, None, None, None, None, None) == 1
 
