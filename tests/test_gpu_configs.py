@@ -1822,3 +1822,55 @@ def test_grid_locator_follows_the_points(oracle):
             d[(x, y)] = d.get((x, y), 0.0) + z
         od = oracle.polyline_weights(pts, xyz, periodX=periodX).as_dict()
         assert set(d) == set(od) and max(abs(d[k] - od[k]) for k in od) <= 1e-13, periodX
+
+
+@pytest.mark.parametrize('hint', [False, True])
+def test_find_points_at_scale_on_the_locator(hint, oracle):
+    """mint.VectorInterp.findPoints through the grid's locator (round 5) far beyond a viewer's few thousand arrow seeds: 300 000
+    random points on the ORCA025-size regular grid land in exactly the cell their coordinates say (points strictly inside
+    cells), with the parametric coordinates of the position inside it; points outside the grid are not found; a period away
+    they are found again; and on a small rotated grid every point gets the oracle's cell."""
+    from nemoflux_amd import mint
+    nx, ny = 1440, 1021
+    o = oracle.DataGen(nx, ny, 1, 1, lat_uses_dx=False)
+    grid = mint.Grid()
+    grid.setPoints(oracle.assemble_points(o.bounds_lon, o.bounds_lat))
+    if hint:
+        grid.setRowLength(nx)
+    rng = numpy.random.default_rng(17)
+    n = 300_000
+    i, j = rng.integers(0, nx, n), rng.integers(0, ny, n)
+    fx, fy = rng.uniform(0.05, 0.95, n), rng.uniform(0.05, 0.95, n)
+    dx, dy = 360. / nx, 180. / ny
+    tp = numpy.zeros((n, 3))
+    tp[:, 0] = -180. + (i + fx) * dx
+    tp[:, 1] = -90. + (j + fy) * dy
+    tp[::7, 0] += 360.                              # a period away: found through the periodic images
+    tp[5::1000, 1] = 95.                            # outside the grid
+    vi = mint.VectorInterp()
+    vi.setGrid(grid)
+    vi.buildLocator(numCellsPerBucket=128, periodX=360.)
+    nf = vi.findPoints(tp, tol2=1.e-12)
+    ids, pc = vi.getCells()
+    out = numpy.zeros(n, bool)
+    out[5::1000] = True
+    assert nf == out.sum() and numpy.all(ids[out] == -1)
+    assert numpy.array_equal(ids[~out], (j * nx + i)[~out])
+    assert numpy.abs(pc[~out, 0] - fx[~out]).max() <= 1e-9 and numpy.abs(pc[~out, 1] - fy[~out]).max() <= 1e-9
+    # rotated grid: the oracle's cells
+    r = oracle.DataGen(36, 18, 1, 1)
+    r.rotatePole((20., 30.))
+    rp = oracle.assemble_points(r.bounds_lon, r.bounds_lat)
+    g2 = mint.Grid()
+    g2.setPoints(rp)
+    if hint:
+        g2.setRowLength(36)
+    q = numpy.zeros((4000, 3))
+    q[:, 0], q[:, 1] = rng.uniform(-180., 180., 4000), rng.uniform(-60., 60., 4000)
+    v2 = mint.VectorInterp()
+    v2.setGrid(g2)
+    v2.buildLocator(numCellsPerBucket=128, periodX=360.)
+    v2.findPoints(q, tol2=1.e-12)
+    data = rng.standard_normal((rp.shape[0], 4))
+    _, oids = oracle.vector_interp(rp, q, data)
+    assert numpy.array_equal(v2.getCells()[0], oids)
