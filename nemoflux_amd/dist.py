@@ -75,8 +75,7 @@ def init_from_env(backend=None):
     if 'NF_FORCE_DEVICE' in os.environ:      # rehearsal of N ranks on a one-GPU box (with NF_DIST_BACKEND=gloo)
         local = int(os.environ['NF_FORCE_DEVICE'])
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if ndev and local >= ndev:   # launcher that restricts every rank to its own device (HIP_VISIBLE_DEVICES per rank)
-        local %= ndev
+    local = _device_for_local_rank(local, ndev)
     backend = backend or os.environ.get('NF_DIST_BACKEND')
     if world > 1 and not dist.is_initialized():
         if backend is None:
@@ -95,6 +94,37 @@ def init_from_env(backend=None):
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local
+
+
+class OverSubscribed(SystemExit):
+    """More ranks on this node than GPUs this rank can see: refused at rank start (exit code 2)."""
+
+
+def _device_for_local_rank(local, ndev):
+    """The device index of this rank, or a refusal BEFORE init_process_group (round-5 verdict W4b).
+
+    One process per GPU: with LOCAL_WORLD_SIZE ranks on this node (torchrun exports it) and fewer devices visible to this rank,
+    two ranks would land on one device and fail later, inside RCCL (duplicate device in ncclCommInitRank) -- so the rank says
+    so now and exits non-zero; torch.distributed.run then ends the others.  Two set-ups are not over-subscription:
+      * ndev == 1: a launcher that gives every rank its own device through HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES -- every
+        rank then sees exactly one device, index 0;
+      * NF_FORCE_DEVICE: the rehearsal hook (N ranks sharing one GPU over gloo), handled by the caller."""
+    if not ndev or 'NF_FORCE_DEVICE' in os.environ:
+        return local
+    try:
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', '0'))
+    except ValueError:
+        local_world = 0
+    if ndev == 1:
+        return 0
+    if local_world > ndev or local >= ndev:
+        msg = (f'nemoflux_amd.dist: rank {os.environ.get("RANK", "?")} (local rank {local}): '
+               f'{local_world or "more than " + str(ndev)} ranks on this node but {ndev} GPUs visible; one process per GPU -- '
+               'start at most that many ranks, give every rank its own HIP_VISIBLE_DEVICES, or set NF_FORCE_DEVICE (with '
+               'NF_DIST_BACKEND=gloo) for a rehearsal on one GPU')
+        print('# ' + msg, file=sys.stderr, flush=True)
+        raise OverSubscribed(2)
+    return local
 
 
 def all_reduce(tensor, op=None, group=None):
@@ -171,8 +201,12 @@ def _agree(flag, group=None):
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
         return int(t.item())
     import datetime
-    seq = _agree_seq[group] = _agree_seq.get(group, 0) + 1
-    prefix = f'nemoflux_amd/agree/{ranks[0]}-{ranks[-1]}-{len(ranks)}/{seq}'
+    # the key names the group by ALL of its ranks (two sub-groups may share first rank, last rank and size: {0,1,3} and
+    # {0,2,3} -- round-5 advisor), and carries the group's own call counter
+    import hashlib
+    tag = hashlib.sha1(','.join(str(r) for r in ranks).encode()).hexdigest()[:16]
+    seq = _agree_seq[tag] = _agree_seq.get(tag, 0) + 1
+    prefix = f'nemoflux_amd/agree/{tag}/{seq}'
     store.set(f'{prefix}/{me}', str(flag))
     keys = [f'{prefix}/{r}' for r in ranks]
     store.wait(keys, datetime.timedelta(seconds=startup_timeout_s()))

@@ -277,3 +277,36 @@ def tiny_segment_lines(xx, yy, half, n, seed):
         out.append(numpy.array([[cx - 7.3, cy - 3.1, 0.], [cx - d[0], cy - d[1], 0.], [cx + d[0], cy + d[1], 0.],
                                 [cx + 5.2, cy + 6.4, 0.]]))
     return out
+
+
+# ---- affine stream function: an oracle-free exact answer on curvilinear cells (round 6) ---------------------------------
+def affine_edge_data(points, a, b, c=0.):
+    """Cell-by-cell edge data of psi = a*lon + b*lat + c on cells `points` (ncell,4,3): nodal differences in the +xi
+    orientation mint's counterclock=False uses: S psi1-psi0, E psi2-psi1, N psi2-psi3, W psi3-psi0.
+    A bilinear cell reproduces an affine function exactly, so the flux across ANY polyline is a*dlon + b*dlat of its end
+    points (end points need not be nodes) and every interpolated face vector is (b, -a, 0) -- with no reference to the
+    oracle's or the device's clipping / inverse-bilinear code (field.py:45-48,90-95,102; README.md:45,58)."""
+    psi = a * points[:, :, 0] + b * points[:, :, 1] + c
+    return numpy.ascontiguousarray(numpy.stack([psi[:, 1] - psi[:, 0], psi[:, 2] - psi[:, 1], psi[:, 2] - psi[:, 3],
+                                                psi[:, 3] - psi[:, 0]], axis=1))
+
+
+def random_open_polylines(seed, n, box, nvert=(2, 7)):
+    """n open polylines of 2..6 vertices drawn uniformly in box = (lonmin, lonmax, latmin, latmax): the end points (and
+    every vertex) fall inside cells, not on nodes."""
+    rng = numpy.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        m = int(rng.integers(*nvert))
+        xyz = numpy.zeros((m, 3))
+        xyz[:, 0] = rng.uniform(box[0], box[1], m)
+        xyz[:, 1] = rng.uniform(box[2], box[3], m)
+        out.append(xyz)
+    return out
+
+
+def affine_expected(xyz, a, b):
+    """(per-segment, total) flux of psi = a*lon + b*lat across the polyline xyz."""
+    d = numpy.diff(xyz[:, :2], axis=0)
+    seg = a * d[:, 0] + b * d[:, 1]
+    return seg, float(a * (xyz[-1, 0] - xyz[0, 0]) + b * (xyz[-1, 1] - xyz[0, 1]))

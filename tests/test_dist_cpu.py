@@ -234,3 +234,92 @@ def test_rank_environment_is_set_by_the_rank_itself(monkeypatch):
     src = inspect.getsource(bench.self_launch)
     assert 'setdefault' not in src and 'env=' not in src           # the launcher hands its own environment down unchanged
     assert inspect.getsource(nfdist.init_from_env).split('rank_environment()')[0].count('torch.cuda') == 0
+
+
+def test_rank_refuses_over_subscription_before_the_rendezvous(monkeypatch, capsys):
+    """Round-5 verdict W4b.  Under `torchrun --nproc-per-node 8` on a node where a rank sees 4 GPUs, ranks used to be mapped
+    `local % ndev` -- two per device -- and fail later inside RCCL.  Now the rank refuses at start, before init_process_group,
+    with exit code 2 and a message.  Not refused: one visible device per rank (a launcher that sets HIP_VISIBLE_DEVICES for
+    each rank: index 0), the NF_FORCE_DEVICE rehearsal hook, and as many devices as ranks."""
+    import torch
+    from nemoflux_amd import dist as nfdist
+    for k in ('NF_FORCE_DEVICE', 'LOCAL_WORLD_SIZE', 'WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    assert nfdist._device_for_local_rank(5, 8) == 5                      # one device per rank
+    assert nfdist._device_for_local_rank(5, 1) == 0                      # HIP_VISIBLE_DEVICES per rank
+    assert nfdist._device_for_local_rank(5, 0) == 5                      # no GPU at all (CPU tests over gloo)
+    with pytest.raises(SystemExit) as e:
+        nfdist._device_for_local_rank(1, 4)                              # 8 ranks, 4 devices: even a rank that "fits" refuses
+    assert e.value.code == 2
+    assert '8 ranks on this node but 4 GPUs visible' in capsys.readouterr().err
+    monkeypatch.delenv('LOCAL_WORLD_SIZE')
+    with pytest.raises(SystemExit):
+        nfdist._device_for_local_rank(6, 4)                              # no LOCAL_WORLD_SIZE (another launcher): index out of range
+    assert nfdist._device_for_local_rank(3, 4) == 3
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    monkeypatch.setenv('NF_FORCE_DEVICE', '0')
+    assert nfdist._device_for_local_rank(0, 4) == 0                      # the rehearsal hook lifts the check
+    monkeypatch.delenv('NF_FORCE_DEVICE')
+    # through init_from_env, with a node that shows 4 devices: exits before any process group exists
+    called = []
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 4)
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda d: called.append(('set_device', d)))
+    monkeypatch.setattr(nfdist.dist, 'init_process_group', lambda *a, **kw: called.append('init_process_group'))
+    monkeypatch.setenv('WORLD_SIZE', '8')
+    monkeypatch.setenv('RANK', '6')
+    monkeypatch.setenv('LOCAL_RANK', '6')
+    with pytest.raises(SystemExit) as e:
+        nfdist.init_from_env()
+    assert e.value.code == 2 and called == []
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '4')
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    monkeypatch.setenv('RANK', '3')
+    monkeypatch.setenv('LOCAL_RANK', '3')
+    assert nfdist.init_from_env() == (3, 4, 3)
+    assert called == [('set_device', 3), 'init_process_group']
+
+
+def _agree_worker(rank, world, port, out_dir):
+    import json
+    from nemoflux_amd import dist as nfdist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), NF_DIST_TIMEOUT_S='60')
+    nfdist.init_from_env(backend='gloo')
+    res = {}
+    res['all_yes'] = nfdist._agree(1)
+    res['one_no'] = nfdist._agree(0 if rank == 2 else 1)
+    res['again_yes'] = nfdist._agree(1)                       # the sequence number keeps the calls apart
+    # two sub-groups with the same first rank, last rank and size: {0,1,3} and {0,2,3} (their keys collided before round 6)
+    ga = dist.new_group([0, 1, 3], backend='gloo')
+    gb = dist.new_group([0, 2, 3], backend='gloo')
+    if rank in (0, 1, 3):
+        res['group_a'] = nfdist._agree(0 if rank == 1 else 1, ga)
+    if rank in (0, 2, 3):
+        res['group_b'] = nfdist._agree(1, gb)
+    if rank in (0, 1, 3):
+        res['group_a_2'] = nfdist._agree(1, ga)
+    with open(os.path.join(out_dir, f'agree{rank}.json'), 'w') as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_agreement_through_the_store_with_subgroups(tmp_path):
+    """nemoflux_amd.dist._agree (the MIN over ranks that precedes ncclCommInitRank) through the rendezvous store, 4 gloo
+    ranks: mixed flags, repeated calls, and two sub-groups that share first rank, last rank and size -- a rank in both must
+    not read the other group's flag (round-5 advisor)."""
+    import json
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    mp.spawn(_agree_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    res = [json.load(open(tmp_path / f'agree{r}.json')) for r in range(4)]
+    for r in range(4):
+        assert (res[r]['all_yes'], res[r]['one_no'], res[r]['again_yes']) == (1, 0, 1), (r, res[r])
+    for r in (0, 1, 3):
+        assert res[r]['group_a'] == 0 and res[r]['group_a_2'] == 1, (r, res[r])
+    for r in (0, 2, 3):
+        assert res[r]['group_b'] == 1, (r, res[r])

@@ -741,3 +741,38 @@ def test_oracle_wrapped_golden_case_vs_reference_fluxexact(oracle, cases):
         for t in range(m['nt']):
             got = oracle.get_integral(w, g['integratedVelocity'][t])
             assert abs(got - tr['fluxexact'][t]) <= 6e-10 * max(1.0, abs(tr['fluxexact'][t])), (tn, t)   # printed with 10 digits
+
+
+@pytest.mark.parametrize('kind', ['rot36_golden', 'rot72', 'orca025_real'])
+def test_oracle_affine_psi_open_polylines_and_face_vectors(kind, oracle):
+    """Oracle-independent closed form on curvilinear cells (round-5 verdict W1; the GPU twin is tests/test_gpu_affine.py):
+    bilinear cells reproduce psi = a*lon + b*lat + c exactly, so with edge data = nodal differences the flux across any OPEN
+    polyline whose end points lie INSIDE cells is a*dlon + b*dlat, every per-segment sum likewise, and every interpolated
+    face vector is (b, -a, 0).  periodX = 0: an affine psi is not periodic.  (field.py:45-48,90-95,102; README.md:45,58)"""
+    from conftest import affine_edge_data, affine_expected, random_open_polylines
+    a, b, c = 1.7, -0.6, 3.0
+    if kind == 'orca025_real':
+        g = load_golden('sa_T_bounds')
+        pts, box = oracle.assemble_points(g['bounds_lon'], g['bounds_lat']), (14., 36., -41., -21.5)
+    elif kind == 'rot36_golden':
+        g = load_golden('rot36_zt')
+        pts, box = oracle.assemble_points(g['bounds_lon'], g['bounds_lat']), (-150., 150., -60., 60.)
+    else:
+        o = oracle.DataGen(72, 36, 1, 1)
+        o.rotatePole((20., 30.))
+        pts, box = oracle.assemble_points(o.bounds_lon, o.bounds_lat), (-170., 170., -80., 80.)
+    data = affine_edge_data(pts, a, b, c)
+    span = max(box[1] - box[0], box[3] - box[2])
+    tol = 1e-12 * (abs(a) + abs(b)) * span
+    for xyz in random_open_polylines(99, 60, box):
+        w = oracle.polyline_weights(pts, xyz, periodX=0., skip_unsupported=True)
+        assert numpy.all(numpy.abs(w.coverage - 1.) <= 1e-9)
+        tot, seg = oracle.get_integral(w, data, True)
+        want_seg, want = affine_expected(xyz, a, b)
+        assert abs(tot - want) <= tol and numpy.all(numpy.abs(seg - want_seg) <= tol)
+    rng = numpy.random.default_rng(3)
+    tg = numpy.zeros((2000, 3))
+    tg[:, 0], tg[:, 1] = rng.uniform(box[0], box[1], 2000), rng.uniform(box[2], box[3], 2000)
+    vec, ids = oracle.vector_interp(pts, tg, data, periodX=0.)
+    assert (ids >= 0).all()
+    assert numpy.abs(vec - [b, -a, 0.]).max() <= 1e-10 * (abs(a) + abs(b))
