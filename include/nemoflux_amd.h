@@ -62,9 +62,11 @@ int nf_memcpy_h2d(void *dev, const void *host, size_t bytes);
 int nf_memcpy_d2h(void *host, const void *dev, size_t bytes);
 int nf_memset(void *dev, int value, size_t bytes);
 int nf_synchronize(void);
-/* Weight builds keep their scratch memory between calls while it is small (at most 1 GiB of HBM per host thread: a viewer
- * makes one PolylineIntegral per transect and each build would otherwise pay a dozen hipMalloc / hipFree pairs).  This gives
- * the calling thread's share back to the system. */
+/* Weight builds and point searches keep their scratch memory between calls while it is small (a process-wide pool of at most
+ * 4 idle scratches of at most 1 GiB of HBM each: a viewer makes one PolylineIntegral per transect and each build would
+ * otherwise pay a dozen hipMalloc / hipFree pairs).  A build checks a scratch out of the pool and hands it back, whichever
+ * host thread runs it, so threads that end leave nothing behind.  This call frees every idle scratch of the process
+ * (the Python package calls it at interpreter exit). */
 int nf_release_scratch(void);
 /* host-side file decoding helper: undo HDF5's shuffle filter (es byte planes of n elements -> n elements) */
 int nf_host_unshuffle(const void *src, void *dst, size_t n, int es);
@@ -78,7 +80,10 @@ int nf_host_gather(const unsigned long long *src_addr, const unsigned long long 
  * (0 = the generator's one-cell-per-lane kernel with plain division, the reference of its row kernel), "west_shift" (0 = the
  * west slots of integratedVelocity as 8-byte stores, the form before round 5), "batch_cellsteps_m" (all-steps-in-one-launch
  * limit in Mi cell-steps, 32), "partial_step_planes" (1 = six-plane epilogue on a rank's partial time steps), "graph" (0 =
- * no graph replay of a pass).  The library reads NO environment variable: these calls are the only switches. */
+ * no graph replay of a pass).  The library reads NO environment variable: these calls are the only switches.
+ * NOT thread-safe: the knobs are plain process-wide variables read by every later launch of every thread; set them before the
+ * objects they affect are used and from one thread only (the reference drives mint from a single thread; A/B tools
+ * and the bench's --knob do the same).  A product run never needs to call this. */
 int nf_tuning_set(const char *name, int value);
 
 /* ------------------------------------------------------------------ Level 1: mint-shaped API */
@@ -116,9 +121,13 @@ int mnt_polylineintegral_setGrid(PolylineIntegral_t **self, Grid_t *grid);
 int mnt_polylineintegral_buildLocator(PolylineIntegral_t **self, int numCellsPerBucket, double periodX,
                                       int enableFolding);
 /* .computeWeights(xyz (npoints,3), counterclock=False)   field.py:48
- * NF_ERR_ARG (with the cell id in nf_last_error) when a target segment overlaps, over a positive length, a cell the
- * weights are not defined on: a quad that is not convex in the (lon,lat) plane, one with a corner AT a geographic
- * pole (the cells around the pole of a rotated grid) or one that CONTAINS a pole -- never a silent number.  NF_ERR_ARG naming
+ * A cell the weights are not defined on -- a quad that is not convex in the (lon,lat) plane, one with a corner AT a
+ * geographic pole (the cells around the pole of a rotated grid) or one that CONTAINS a pole -- that a target segment
+ * overlaps over a positive length is left out (policy 'skip', the default of this mint-shaped level since round 6: mint's
+ * computeWeights has no error path there, field.py:44-49): the rest of the line is integrated,
+ * mnt_polylineintegral_getCoverage reports < 1 for the segment and mnt_polylineintegral_getNumberOfDroppedCrossings says
+ * how many such crossings were left out -- never a silent number.  With mnt_polylineintegral_setUnsupportedCells(0) the
+ * call returns NF_ERR_ARG (with the cell id in nf_last_error) instead.  NF_ERR_ARG naming
  * the segment, too, when some stretch of a target segment lies in two cells that do not hold the same sub-segment (coverage
  * > 1 + 1e-8 AND the excess, as a length, > 1e-9 max(1, |coordinates|) degrees: overlapping cells, e.g. a date-line-wrapped
  * grid with periodX = 0): that stretch would be counted twice.  (The length condition keeps rounding noise on target
@@ -127,11 +136,14 @@ int mnt_polylineintegral_buildLocator(PolylineIntegral_t **self, int numCellsPer
  * part in nothing. */
 int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, const double xyz[],
                                         int counterclock);
-/* extension (not in mint): what computeWeights does with such a cell.  skip = 0 (default): the error above.  skip = 1:
- * the cell contributes nothing -- the rest of the line is integrated and mnt_polylineintegral_getCoverage reports
- * the fraction of every target segment that was (real ORCA grids with a few distorted polar cells far from the
- * transect's physics; mint itself returns a number there, pinned by nothing in the reference). */
+/* extension (not in mint): what computeWeights does with such a cell.  skip = 1 (default): the cell contributes nothing --
+ * the rest of the line is integrated and mnt_polylineintegral_getCoverage reports the fraction of every target segment
+ * that was (real ORCA grids with a few distorted polar cells far from the transect's physics; mint itself returns a number
+ * there, pinned by nothing in the reference).  skip = 0: NF_ERR_ARG naming the cell. */
 int mnt_polylineintegral_setUnsupportedCells(PolylineIntegral_t **self, int skip);
+/* extension: (cell, target-segment image) crossings of unsupported cells the last computeWeights left out (0 unless the
+ * policy is 'skip' and the line meets such cells) */
+int mnt_polylineintegral_getNumberOfDroppedCrossings(PolylineIntegral_t **self, size_t *n);
 /* extension (not in mint): what computeWeights does with a target segment that is covered more than once (see above).
  * warn = 0 (default): NF_ERR_ARG.  warn = 1: the weights are built as mint would build them -- the stretch counts twice --
  * and mnt_polylineintegral_getCoverage reports > 1 for the segment (the Python wrapper warns). */
@@ -208,8 +220,11 @@ int nf_field_set_slab_range(nf_field **self, long s_begin, long s_end);
 /* Transects (field.py:43-49): add polylines, then build all weights in one batched pass.
  * xyz: (npts,3) host.  *transect_id receives the index. */
 int nf_field_add_transect(nf_field **self, const double *xyz, int npts, int counterclock, int *transect_id);
-/* same policy switch as mnt_polylineintegral_setUnsupportedCells, for the batched build below; call before build_weights */
+/* same policy switch as mnt_polylineintegral_setUnsupportedCells, for the batched build below; call before build_weights.
+ * The default of THIS level is 0 (refuse): a batch driver should hear about a transect it cannot integrate in full. */
 int nf_field_set_unsupported_cells(nf_field **self, int skip);
+/* crossings of unsupported cells the last nf_field_build_weights left out (policy 'skip'), over all transects */
+int nf_field_num_dropped_crossings(nf_field **self, size_t *n);
 /* same policy switch as mnt_polylineintegral_setOverlappingCells, for the batched build below; call before build_weights */
 int nf_field_set_overlapping_cells(nf_field **self, int warn);
 int nf_field_build_weights(nf_field **self, int numCellsPerBucket, double periodX);

@@ -1,151 +1,7 @@
-// nf_capi.hip -- the C ABI of libnemoflux_amd.so (declared in include/nemoflux_amd.h).
-//
-// Level 1 mirrors the entry points nemoflux reaches in the mint C library through python-mint's ctypes
-// wrapper (horizgrid.py:23-24,30,43; field.py:45-48,102); Level 2 is the Field-shaped engine
-// (field.py:15-234).  Host-side orchestration only: every number is produced by the HIP kernels of
-// nf_geom.hip / nf_flux.hip / nf_weights.hip / nf_integral.hip / nf_datagen.hip.  There is no CPU path.
-#include <algorithm>
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-#include <limits>
-#include <new>
-#include <thread>
-#include <vector>
-
-#include "nf_common.h"
-
-namespace nf {
-
-static thread_local std::string g_err;
-void set_error(const std::string &msg) { g_err = msg; }
-int hip_fail(hipError_t e, const char *what, const char *file, int line)
-{
-    char buf[512];
-    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
-    g_err = buf;
-    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? NF_ERR_NO_DEVICE : NF_ERR_HIP;
-}
-
-static int require_device()
-{
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
-        set_error("no usable AMD GPU (hipGetDeviceCount); nemoflux_amd has no CPU fallback");
-        return NF_ERR_NO_DEVICE;
-    }
-    return NF_OK;
-}
-#define NF_NEED_DEVICE()                      \
-    do {                                      \
-        int rc_ = nf::require_device();       \
-        if (rc_ != NF_OK) return rc_;         \
-    } while (0)
-// Exception barrier of the C ABI: every entry point is a function-try-block ending in NF_API_CATCH, so a
-// std::bad_alloc (or any other C++ exception) raised by the host-side containers becomes NF_ERR_HOST.
-static int trap_exception() noexcept
-{
-    try {
-        throw;
-    } catch (const std::bad_alloc &) {
-        try { g_err = "out of host memory"; } catch (...) {}
-    } catch (const std::exception &e) {
-        try { g_err = std::string("internal error: ") + e.what(); } catch (...) {}
-    } catch (...) {
-        try { g_err = "internal error: unknown C++ exception"; } catch (...) {}
-    }
-    return NF_ERR_HOST;
-}
-#define NF_API_CATCH catch (...) { return nf::trap_exception(); }
-
-// device scratch that lives for one call: freed on every return path
-struct DevTmp {
-    void *p = nullptr;
-    DevTmp() = default;
-    DevTmp(const DevTmp &) = delete;
-    DevTmp &operator=(const DevTmp &) = delete;
-    ~DevTmp() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes)
-    {
-        NF_HIP(hipMalloc(&p, bytes ? bytes : 16));
-        return NF_OK;
-    }
-    template <typename T> T *as() const { return static_cast<T *>(p); }
-};
-
-template <typename T>
-static int dev_alloc(T **p, size_t count)
-{
-    NF_HIP(hipMalloc((void **)p, sizeof(T) * (count ? count : 1)));
-    return NF_OK;
-}
-template <typename T>
-static void dev_free(T *&p)
-{
-    if (p) (void)hipFree((void *)p);
-    p = nullptr;
-}
-
-// Sparse staging of a caller's HOST (ncell,4) array for the Level-1 entry points: the 32 bytes of every cell an object
-// touches (the records of a PolylineIntegral, the located cells of a VectorInterp) are gathered into a pinned buffer in
-// record / point order, so that what crosses PCIe is n x 32 B instead of the whole array (207 MB at ORCA12 size) -- mint's
-// own getIntegral is a sparse dot over the same entries (field.py:102).  Native threads from 32 Ki rows on; ids < 0 (a
-// point outside the grid) give a row of zeros.
-template <typename I>
-static void host_gather_rows4(const double *data, const I *ids, long n, double *out)
-{
-    auto work = [=](long lo, long hi) {
-        for (long k = lo; k < hi; ++k) {
-            if (k + 16 < hi && ids[k + 16] >= 0) __builtin_prefetch(data + 4 * (long)ids[k + 16]);
-            if (ids[k] >= 0) memcpy(out + 4 * k, data + 4 * (long)ids[k], 32);
-            else memset(out + 4 * k, 0, 32);
-        }
-    };
-    const long per = 1l << 15;
-    long nthr = std::min<long>(std::min<long>(8, (long)std::thread::hardware_concurrency()), n / per);
-    if (nthr <= 1) {
-        work(0, n);
-        return;
-    }
-    std::vector<std::thread> pool;
-    const long chunk = (n + nthr - 1) / nthr;
-    for (long t = 1; t < nthr; ++t) pool.emplace_back(work, t * chunk, std::min(n, (t + 1) * chunk));
-    work(0, std::min(n, chunk));
-    for (auto &th : pool) th.join();
-}
-
-// pinned host buffer + its HBM twin, sized once per weight build / point search
-struct GatherStage {
-    double *h = nullptr, *d = nullptr;
-    long rows = 0;
-    void release()
-    {
-        if (h) (void)hipHostFree(h);
-        if (d) (void)hipFree(d);
-        h = d = nullptr;
-        rows = 0;
-    }
-    int resize(long n)
-    {
-        release();
-        if (n <= 0) return NF_OK;
-        NF_HIP(hipHostMalloc((void **)&h, sizeof(double) * 4 * (size_t)n, hipHostMallocDefault));
-        NF_HIP(hipMalloc((void **)&d, sizeof(double) * 4 * (size_t)n));
-        rows = n;
-        return NF_OK;
-    }
-    template <typename I>
-    int upload(const double *data, const I *ids)   // gather on the host, one copy of rows x 32 B; complete at return
-    {
-        if (rows == 0) return NF_OK;
-        host_gather_rows4(data, ids, rows, h);
-        NF_HIP(hipMemcpy(d, h, sizeof(double) * 4 * (size_t)rows, hipMemcpyHostToDevice));
-        return NF_OK;
-    }
-};
-
-}  // namespace nf
+// nf_capi_field.hip -- the C ABI of libnemoflux_amd.so, part 3 of 3: Level 2, the Field-shaped engine (field.py:15-234;
+// BASELINE north_star's computeFlux(tIndex)): nf_field_*.  Host-side orchestration only: every number is produced by the HIP
+// kernels of nf_geom.hip / nf_flux.hip / nf_weights.hip / nf_integral.hip.  There is no CPU path.
+#include "nf_capi.h"
 
 using namespace nf;
 
@@ -160,103 +16,15 @@ static long g_batch_cellsteps = 32l << 20;
 static int g_partial_full = 0;
 static int g_use_graph = 1;
 
-// =============================================================================================== plumbing
-extern "C" {
-
-const char *nf_last_error(void) { return g_err.c_str(); }
-int nf_version(void) { return 100; }
-
-int nf_device_count(int *count)
-try {
-    NF_REQUIRE(count, NF_ERR_ARG, "nf_device_count: null argument");
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    *count = (e == hipSuccess) ? n : 0;
-    return NF_OK;
-}
-NF_API_CATCH
-int nf_set_device(int device)
-try {
-    NF_NEED_DEVICE();
-    NF_HIP(hipSetDevice(device));
-    return NF_OK;
-}
-NF_API_CATCH
-int nf_device_name(char *buf, int buflen)
-try {
-    NF_REQUIRE(buf && buflen > 0, NF_ERR_ARG, "nf_device_name: null or empty buffer");
-    NF_NEED_DEVICE();
-    int dev = 0;
-    NF_HIP(hipGetDevice(&dev));
-    hipDeviceProp_t p;
-    NF_HIP(hipGetDeviceProperties(&p, dev));
-    snprintf(buf, buflen, "%s:%s:%dCU", p.gcnArchName, p.name, p.multiProcessorCount);
-    return NF_OK;
-}
-NF_API_CATCH
-int nf_malloc(void **dev, size_t bytes)
-try {
-    NF_REQUIRE(dev, NF_ERR_ARG, "nf_malloc: null argument");
-    NF_NEED_DEVICE();
-    NF_HIP(hipMalloc(dev, bytes ? bytes : 16));
-    return NF_OK;
-}
-NF_API_CATCH
-int nf_free(void *dev)
-try {
-    if (dev) NF_HIP(hipFree(dev));
-    return NF_OK;
-}
-NF_API_CATCH
-int nf_host_alloc(void **host, size_t bytes)
-try {
-    NF_REQUIRE(host, NF_ERR_ARG, "nf_host_alloc: null argument");
-    NF_NEED_DEVICE();
-    NF_HIP(hipHostMalloc(host, bytes ? bytes : 16, hipHostMallocDefault));
-    return NF_OK;
-}
-NF_API_CATCH
-int nf_host_free(void *host)
-try {
-    if (host) NF_HIP(hipHostFree(host));
-    return NF_OK;
-}
-NF_API_CATCH
-int nf_memcpy_h2d(void *dev, const void *host, size_t bytes)
-try {
-    NF_NEED_DEVICE();
-    NF_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
-    return NF_OK;
-}
-NF_API_CATCH
-int nf_memcpy_d2h(void *host, const void *dev, size_t bytes)
-try {
-    NF_NEED_DEVICE();
-    NF_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
-    return NF_OK;
-}
-NF_API_CATCH
-int nf_memset(void *dev, int value, size_t bytes)
-try {
-    NF_NEED_DEVICE();
-    NF_HIP(hipMemset(dev, value, bytes));
-    return NF_OK;
-}
-NF_API_CATCH
-int nf_tuning_set(const char *name, int value)
-try {
-    NF_REQUIRE(name, NF_ERR_ARG, "nf_tuning_set: null name");
+namespace nf {
+int field_tuning_set(const char *name, int value)
+{
     if (!strcmp(name, "batch_steps")) {
         g_batch_steps = value;
         return NF_OK;
     }
-    if (!strcmp(name, "edge_weights")) {   // K3 on the engine's planes: 1 = unique-edge entries (built by the next
-                                           // nf_field_build_weights), 0 = (cell, 4 weights) records (default)
-        integral_use_edges(value);
-        return NF_OK;
-    }
     if (!strcmp(name, "batch_cellsteps_m")) {
-        NF_REQUIRE(value >= 0 && value <= 2047, NF_ERR_ARG, "nf_tuning_set: batch_cellsteps_m must be in [0, 2047]");
+        if (!(value >= 0 && value <= 2047)) return -1;   // nf_tuning_set then reports the knob as unknown / out of range
         g_batch_cellsteps = (long)value << 20;
         return NF_OK;
     }
@@ -268,506 +36,9 @@ try {
         g_use_graph = value != 0;
         return NF_OK;
     }
-    if (!strcmp(name, "datagen_rows")) {   // generator: 1 = the row kernel (default), 0 = one cell per lane with plain division
-        datagen_use_rows(value);
-        return NF_OK;
-    }
-    int rc = tuning_set(name, value);
-    NF_REQUIRE(rc == NF_OK, NF_ERR_ARG, std::string("nf_tuning_set: unknown knob ") + name);
-    return NF_OK;
+    return -1;
 }
-NF_API_CATCH
-int nf_release_scratch(void)
-try {
-    weights_trim_scratch();
-    return NF_OK;
-}
-NF_API_CATCH
-int nf_synchronize(void)
-try {
-    NF_NEED_DEVICE();
-    NF_HIP(hipDeviceSynchronize());
-    return NF_OK;
-}
-NF_API_CATCH
-
-}  // extern "C"
-
-// =============================================================================================== Level 1
-struct Grid_t {
-    long ncell = 0;
-    double *host_points = nullptr;  // borrowed (ncell,4,3)
-    double *d_xy = nullptr;         // corner table (ncell,4,2)
-    bool owns_xy = true;
-    long version = 0;               // bumped by every build: weights / located points of an older build are refused
-    LocatorBoxes boxes;             // the locator of this grid (filled by the first computeWeights, dropped when the points change)
-    long row_length = 0;            // mnt_grid_setRowLength: the cells are rows of this many (0 = a flat list, like mint's)
-};
-
-struct PolylineIntegral_t {
-    Grid_t *grid = nullptr;
-    bool locator = false;
-    double periodX = 0.0;
-    WeightSet ws;
-    int *d_tr_off = nullptr;
-    double *d_scratch = nullptr;
-    double *d_row = nullptr;
-    // getIntegral on a HOST array stages only the cells the weights touch (GatherStage): the record cell ids stay on the
-    // host after computeWeights, the gathered (nrec,4) rows are indexed by RECORD NUMBER on the device (d_iota = 0..nrec-1)
-    std::vector<int> h_cell;
-    GatherStage stage;
-    int *d_iota = nullptr;
-    long grid_version = -1;     // the grid build the weights belong to
-    int nseg = 0;
-    int skip_unsupported = 0;   // mnt_polylineintegral_setUnsupportedCells
-    int overlap_warn = 0;       // mnt_polylineintegral_setOverlappingCells
-};
-
-extern "C" {
-
-int mnt_grid_new(Grid_t **self)
-try {
-    NF_REQUIRE(self, NF_ERR_ARG, "mnt_grid_new: null argument");
-    *self = new Grid_t();
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_grid_del(Grid_t **self)
-try {
-    if (self && *self) {
-        if ((*self)->owns_xy) dev_free((*self)->d_xy);
-        delete *self;
-        *self = nullptr;
-    }
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_grid_setPointsPtr(Grid_t **self, double *points)
-try {
-    NF_REQUIRE(self && *self && points, NF_ERR_ARG, "mnt_grid_setPointsPtr: null argument");
-    (*self)->host_points = points;
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_grid_build(Grid_t **self, int nVertsPerCell, long long ncells)
-try {
-    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_grid_build: null grid");
-    Grid_t *g = *self;
-    NF_REQUIRE(nVertsPerCell == 4, NF_ERR_ARG, "mnt_grid_build: only quad cells (4 vertices) are supported");
-    NF_REQUIRE(g->host_points, NF_ERR_STATE, "mnt_grid_build: setPointsPtr first");
-    NF_REQUIRE(ncells > 0 && ncells < (1ll << 31), NF_ERR_ARG, "mnt_grid_build: bad cell count");
-    NF_NEED_DEVICE();
-    g->boxes.release();             // they describe the old points
-    if (g->owns_xy) dev_free(g->d_xy);
-    g->owns_xy = true;
-    g->ncell = (long)ncells;
-    DevTmp points;
-    NF_TRY(points.alloc(sizeof(double) * 12 * (size_t)ncells));
-    NF_TRY(dev_alloc(&g->d_xy, (size_t)ncells * 8));
-    NF_HIP(hipMemcpy(points.p, g->host_points, sizeof(double) * 12 * (size_t)ncells, hipMemcpyHostToDevice));
-    NF_TRY(launch_corner_table_from_points(points.as<double>(), g->ncell, g->d_xy, nullptr));
-    NF_HIP(hipDeviceSynchronize());
-    ++g->version;
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_grid_setRowLength(Grid_t **self, long long rowLength)
-try {
-    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_grid_setRowLength: null grid");
-    NF_REQUIRE(rowLength >= 0, NF_ERR_ARG, "mnt_grid_setRowLength: negative row length");
-    if ((*self)->row_length != (long)rowLength) (*self)->boxes.release();    // the groups of the locator follow the layout
-    (*self)->row_length = (long)rowLength;
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_grid_getNumberOfCells(Grid_t **self, size_t *numCells)
-try {
-    NF_REQUIRE(self && *self && numCells, NF_ERR_ARG, "mnt_grid_getNumberOfCells: null argument");
-    *numCells = (size_t)(*self)->ncell;
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_grid_dump(Grid_t **self, const char *fileName)
-try {
-    NF_REQUIRE(self && *self && fileName, NF_ERR_ARG, "mnt_grid_dump: null argument");
-    Grid_t *g = *self;
-    NF_REQUIRE(g->ncell > 0, NF_ERR_STATE, "mnt_grid_dump: grid not built");
-    std::vector<double> pts;
-    const double *p = g->host_points;
-    if (!p) {  // grid view of a Field: rebuild (lon,lat,0) from the corner table
-        NF_NEED_DEVICE();
-        DevTmp points;
-        NF_TRY(points.alloc(sizeof(double) * 12 * (size_t)g->ncell));
-        NF_TRY(launch_points_from_corner_table(g->d_xy, g->ncell, points.as<double>(), nullptr));
-        pts.resize((size_t)g->ncell * 12);
-        NF_HIP(hipMemcpy(pts.data(), points.p, sizeof(double) * pts.size(), hipMemcpyDeviceToHost));
-        p = pts.data();
-    }
-    FILE *f = fopen(fileName, "w");
-    NF_REQUIRE(f, NF_ERR_ARG, std::string("mnt_grid_dump: cannot open ") + fileName);
-    fprintf(f, "# vtk DataFile Version 3.0\nnemoflux_amd grid\nASCII\nDATASET UNSTRUCTURED_GRID\n");
-    fprintf(f, "POINTS %ld double\n", g->ncell * 4);
-    for (long k = 0; k < g->ncell * 4; ++k) fprintf(f, "%.17g %.17g %.17g\n", p[3 * k], p[3 * k + 1], p[3 * k + 2]);
-    fprintf(f, "CELLS %ld %ld\n", g->ncell, g->ncell * 5);
-    for (long c = 0; c < g->ncell; ++c) fprintf(f, "4 %ld %ld %ld %ld\n", 4 * c, 4 * c + 1, 4 * c + 2, 4 * c + 3);
-    fprintf(f, "CELL_TYPES %ld\n", g->ncell);
-    for (long c = 0; c < g->ncell; ++c) fprintf(f, "9\n");  // VTK_QUAD
-    const bool bad = ferror(f) != 0;
-    NF_REQUIRE(fclose(f) == 0 && !bad, NF_ERR_HOST, std::string("mnt_grid_dump: error writing ") + fileName);
-    return NF_OK;
-}
-NF_API_CATCH
-
-int mnt_polylineintegral_new(PolylineIntegral_t **self)
-try {
-    NF_REQUIRE(self, NF_ERR_ARG, "mnt_polylineintegral_new: null argument");
-    *self = new PolylineIntegral_t();
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_polylineintegral_del(PolylineIntegral_t **self)
-try {
-    if (self && *self) {
-        PolylineIntegral_t *p = *self;
-        p->ws.release();
-        dev_free(p->d_tr_off);
-        dev_free(p->d_scratch);
-        dev_free(p->d_row);
-        dev_free(p->d_iota);
-        p->stage.release();
-        delete p;
-        *self = nullptr;
-    }
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_polylineintegral_setGrid(PolylineIntegral_t **self, Grid_t *grid)
-try {
-    NF_REQUIRE(self && *self && grid, NF_ERR_ARG, "mnt_polylineintegral_setGrid: null argument");
-    NF_REQUIRE(grid->ncell > 0 && grid->d_xy, NF_ERR_STATE, "mnt_polylineintegral_setGrid: grid not built");
-    (*self)->grid = grid;
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_polylineintegral_buildLocator(PolylineIntegral_t **self, int numCellsPerBucket, double periodX,
-                                      int enableFolding)
-try {
-    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_polylineintegral_buildLocator: null argument");
-    NF_REQUIRE((*self)->grid, NF_ERR_STATE, "mnt_polylineintegral_buildLocator: setGrid first");
-    NF_REQUIRE(numCellsPerBucket > 0, NF_ERR_ARG, "mnt_polylineintegral_buildLocator: numCellsPerBucket <= 0");
-    NF_REQUIRE(periodX >= 0.0, NF_ERR_ARG, "mnt_polylineintegral_buildLocator: negative periodX");
-    NF_REQUIRE(!enableFolding, NF_ERR_ARG, "mnt_polylineintegral_buildLocator: enableFolding is not supported");
-    (*self)->periodX = periodX;
-    (*self)->locator = true;  // the box hierarchy itself is built (and kept by the grid) at the first computeWeights
-    return NF_OK;
-}
-NF_API_CATCH
-
-int mnt_polylineintegral_setUnsupportedCells(PolylineIntegral_t **self, int skip)
-try {
-    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_polylineintegral_setUnsupportedCells: null argument");
-    NF_REQUIRE(skip == 0 || skip == 1, NF_ERR_ARG, "mnt_polylineintegral_setUnsupportedCells: policy must be 0 (refuse) or 1 (skip)");
-    (*self)->skip_unsupported = skip;
-    return NF_OK;
-}
-NF_API_CATCH
-
-int mnt_polylineintegral_setOverlappingCells(PolylineIntegral_t **self, int warn)
-try {
-    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_polylineintegral_setOverlappingCells: null argument");
-    NF_REQUIRE(warn == 0 || warn == 1, NF_ERR_ARG, "mnt_polylineintegral_setOverlappingCells: policy must be 0 (refuse) or 1 (warn)");
-    (*self)->overlap_warn = warn;
-    return NF_OK;
-}
-NF_API_CATCH
-
-static int polyline_segments(const double *xyz, int npoints, int counterclock, std::vector<double> &segs,
-                             std::vector<int> &cc)
-{
-    for (int s = 0; s + 1 < npoints; ++s) {
-        segs.push_back(xyz[3 * s]);
-        segs.push_back(xyz[3 * s + 1]);
-        segs.push_back(xyz[3 * (s + 1)] - xyz[3 * s]);
-        segs.push_back(xyz[3 * (s + 1) + 1] - xyz[3 * s + 1]);
-        cc.push_back(counterclock ? 1 : 0);
-    }
-    return npoints > 1 ? npoints - 1 : 0;
-}
-
-int mnt_polylineintegral_computeWeights(PolylineIntegral_t **self, int npoints, const double xyz[],
-                                        int counterclock)
-try {
-    NF_REQUIRE(self && *self && xyz, NF_ERR_ARG, "mnt_polylineintegral_computeWeights: null argument");
-    PolylineIntegral_t *p = *self;
-    NF_REQUIRE(p->grid && p->locator, NF_ERR_STATE, "mnt_polylineintegral_computeWeights: setGrid/buildLocator first");
-    NF_REQUIRE(npoints >= 2, NF_ERR_ARG, "mnt_polylineintegral_computeWeights: need at least 2 points");
-    NF_NEED_DEVICE();
-    std::vector<double> segs;
-    std::vector<int> cc;
-    p->nseg = polyline_segments(xyz, npoints, counterclock, segs, cc);
-    // whatever a previous computeWeights left is gone first: after a refused build getIntegral must say "computeWeights
-    // first", not launch on buffers sized for another polyline
-    dev_free(p->d_tr_off);
-    dev_free(p->d_scratch);
-    dev_free(p->d_row);
-    dev_free(p->d_iota);
-    p->stage.release();
-    p->h_cell.clear();
-    NF_TRY(build_weights(p->grid->d_xy, p->grid->ncell, segs.data(), cc.data(), p->nseg, p->periodX, &p->ws, nullptr,
-                         p->skip_unsupported, p->overlap_warn, &p->grid->boxes, p->grid->row_length));
-    NF_TRY(dev_alloc(&p->d_tr_off, 2));
-    NF_TRY(dev_alloc(&p->d_scratch, (size_t)p->ws.nrec));
-    const int off[2] = {0, p->nseg};
-    NF_HIP(hipMemcpy(p->d_tr_off, off, sizeof off, hipMemcpyHostToDevice));
-    // what getIntegral needs to stage a host array sparsely: the cells of the records, here; their row numbers, there
-    p->h_cell.resize((size_t)p->ws.nrec);
-    NF_TRY(dev_alloc(&p->d_iota, (size_t)p->ws.nrec));
-    if (p->ws.nrec > 0) {
-        NF_HIP(hipMemcpy(p->h_cell.data(), p->ws.cell, sizeof(int) * (size_t)p->ws.nrec, hipMemcpyDeviceToHost));
-        std::vector<int> iota((size_t)p->ws.nrec);
-        for (long k = 0; k < p->ws.nrec; ++k) iota[(size_t)k] = (int)k;
-        NF_HIP(hipMemcpy(p->d_iota, iota.data(), sizeof(int) * iota.size(), hipMemcpyHostToDevice));
-    }
-    NF_TRY(p->stage.resize(p->ws.nrec));
-    NF_TRY(dev_alloc(&p->d_row, (size_t)p->nseg + 1));   // last: its presence means "weights are ready"
-    p->grid_version = p->grid->version;
-    return NF_OK;
-}
-NF_API_CATCH
-
-// the reduction of one object: gather + wavefront segmented scan + the two finalize kernels, then the row comes back
-static int pli_reduce(PolylineIntegral_t *p, const WeightSet &ws, const double *data_dev, long nrows, double *result,
-                      double *seg_totals_host)
-{
-    NF_TRY(launch_integral(ws, data_dev, nrows, 0, 0, p->d_tr_off, 1, p->d_scratch, p->d_row, nullptr));
-    std::vector<double> row((size_t)p->nseg + 1);
-    NF_HIP(hipMemcpy(row.data(), p->d_row, sizeof(double) * row.size(), hipMemcpyDeviceToHost));
-    *result = row[p->nseg];
-    if (seg_totals_host) memcpy(seg_totals_host, row.data(), sizeof(double) * p->nseg);
-    return NF_OK;
-}
-
-static int pli_ready(PolylineIntegral_t *p, int placement)
-{
-    NF_REQUIRE(p->d_row, NF_ERR_STATE, "mnt_polylineintegral_getIntegral: computeWeights first");
-    NF_REQUIRE(p->grid && p->grid_version == p->grid->version, NF_ERR_STATE,
-               "mnt_polylineintegral_getIntegral: the grid was rebuilt after computeWeights (the weights index the old cells): computeWeights again");
-    NF_REQUIRE(placement == MNT_CELL_BY_CELL_DATA, NF_ERR_ARG,
-               "mnt_polylineintegral_getIntegral: only CELL_BY_CELL_DATA is supported (field.py:102)");
-    return NF_OK;
-}
-
-int mnt_polylineintegral_getIntegralDev(PolylineIntegral_t **self, const double *data_dev, int placement,
-                                        double *result, double *seg_totals_host)
-try {
-    NF_REQUIRE(self && *self && data_dev && result, NF_ERR_ARG, "mnt_polylineintegral_getIntegral: null argument");
-    PolylineIntegral_t *p = *self;
-    NF_TRY(pli_ready(p, placement));
-    NF_NEED_DEVICE();
-    return pli_reduce(p, p->ws, data_dev, p->grid->ncell, result, seg_totals_host);
-}
-NF_API_CATCH
-
-// Host data: mint's getIntegral is a sparse dot over the K = 4 x (cells crossed) entries (field.py:102; fluxplot.py:55-58
-// calls it once per transect per time step), so the cost here must not depend on the size of the grid either: the 32
-// bytes of every record's cell are gathered on the host into a pinned buffer, nrec x 32 B go to HBM and the SAME kernels
-// run on them with the record number as the cell index -- the same products summed in the same tree, hence the bits of
-// mnt_polylineintegral_getIntegralDev on the whole array (tests/test_gpu_parity.py::test_level1_host_data_is_staged_sparsely).
-int mnt_polylineintegral_getIntegral(PolylineIntegral_t **self, const double data[], int placement, double *result)
-try {
-    NF_REQUIRE(self && *self && data && result, NF_ERR_ARG, "mnt_polylineintegral_getIntegral: null argument");
-    PolylineIntegral_t *p = *self;
-    NF_REQUIRE(p->grid, NF_ERR_STATE, "mnt_polylineintegral_getIntegral: setGrid first");
-    NF_TRY(pli_ready(p, placement));
-    NF_NEED_DEVICE();
-    NF_TRY(p->stage.upload(data, p->h_cell.data()));
-    WeightSet rows;              // a view of the object's records whose cell index is the record number
-    rows.nrec = p->ws.nrec;
-    rows.cell = p->d_iota;
-    rows.w4 = p->ws.w4;
-    rows.seg = p->ws.seg;
-    rows.nseg = p->ws.nseg;
-    rows.seg_start = p->ws.seg_start;
-    return pli_reduce(p, rows, p->stage.d, p->ws.nrec, result, nullptr);
-}
-NF_API_CATCH
-
-int mnt_polylineintegral_getCoverage(PolylineIntegral_t **self, double *coverage)
-try {
-    NF_REQUIRE(self && *self && coverage, NF_ERR_ARG, "mnt_polylineintegral_getCoverage: null argument");
-    // also readable after a build that was refused for over-coverage (the message names one segment; this has them all)
-    NF_REQUIRE((*self)->d_row || !(*self)->ws.coverage.empty(), NF_ERR_STATE,
-               "mnt_polylineintegral_getCoverage: computeWeights first");
-    const std::vector<double> &c = (*self)->ws.coverage;
-    if (!c.empty()) memcpy(coverage, c.data(), sizeof(double) * c.size());
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_polylineintegral_getNumberOfWeights(PolylineIntegral_t **self, size_t *n)
-try {
-    NF_REQUIRE(self && *self && n, NF_ERR_ARG, "mnt_polylineintegral_getNumberOfWeights: null argument");
-    *n = (size_t)(*self)->ws.entries();
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_polylineintegral_getWeights(PolylineIntegral_t **self, int64_t *cell_edge, double *weight, int *seg)
-try {
-    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_polylineintegral_getWeights: null argument");
-    if ((*self)->ws.nrec == 0) return NF_OK;
-    NF_NEED_DEVICE();
-    return weights_to_host((*self)->ws, cell_edge, weight, seg);
-}
-NF_API_CATCH
-
-}  // extern "C"
-
-// ----------------------------------------------------------------------------------------------- VectorInterp
-struct VectorInterp_t {
-    Grid_t *grid = nullptr;
-    bool locator = false;
-    double periodX = 0.0;
-    long npts = 0;
-    double *d_targets = nullptr, *d_pcoords = nullptr, *d_vectors = nullptr;
-    long *d_cell = nullptr;
-    unsigned long long *d_best = nullptr;
-    // getFaceVectors on a HOST array stages only the located cells, one (4) row per target point (GatherStage)
-    std::vector<long> h_cell;
-    GatherStage stage;
-    long grid_version = -1;     // the grid build the located cells belong to
-};
-
-static void vi_free_points(VectorInterp_t *v)
-{
-    dev_free(v->d_targets);
-    dev_free(v->d_pcoords);
-    dev_free(v->d_vectors);
-    dev_free(v->d_cell);
-    dev_free(v->d_best);
-    v->stage.release();
-    v->h_cell.clear();
-    v->npts = 0;
-}
-
-extern "C" {
-
-int mnt_vectorinterp_new(VectorInterp_t **self)
-try {
-    NF_REQUIRE(self, NF_ERR_ARG, "mnt_vectorinterp_new: null argument");
-    *self = new VectorInterp_t();
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_vectorinterp_del(VectorInterp_t **self)
-try {
-    if (self && *self) {
-        vi_free_points(*self);
-        delete *self;
-        *self = nullptr;
-    }
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_vectorinterp_setGrid(VectorInterp_t **self, Grid_t *grid)
-try {
-    NF_REQUIRE(self && *self && grid, NF_ERR_ARG, "mnt_vectorinterp_setGrid: null argument");
-    NF_REQUIRE(grid->ncell > 0 && grid->d_xy, NF_ERR_STATE, "mnt_vectorinterp_setGrid: grid not built");
-    (*self)->grid = grid;
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_vectorinterp_buildLocator(VectorInterp_t **self, int numCellsPerBucket, double periodX, int enableFolding)
-try {
-    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_vectorinterp_buildLocator: null argument");
-    NF_REQUIRE((*self)->grid, NF_ERR_STATE, "mnt_vectorinterp_buildLocator: setGrid first");
-    NF_REQUIRE(numCellsPerBucket > 0 && periodX >= 0.0, NF_ERR_ARG, "mnt_vectorinterp_buildLocator: bad arguments");
-    NF_REQUIRE(!enableFolding, NF_ERR_ARG, "mnt_vectorinterp_buildLocator: enableFolding is not supported");
-    (*self)->periodX = periodX;
-    (*self)->locator = true;
-    return NF_OK;
-}
-NF_API_CATCH
-int mnt_vectorinterp_findPoints(VectorInterp_t **self, size_t numPoints, const double targetPoints[], double tol2,
-                                size_t *numNotFound)
-try {
-    NF_REQUIRE(self && *self && (targetPoints || numPoints == 0), NF_ERR_ARG, "mnt_vectorinterp_findPoints: null argument");
-    VectorInterp_t *v = *self;
-    NF_REQUIRE(v->grid && v->locator, NF_ERR_STATE, "mnt_vectorinterp_findPoints: setGrid/buildLocator first");
-    NF_REQUIRE(tol2 >= 0.0, NF_ERR_ARG, "mnt_vectorinterp_findPoints: negative tolerance");
-    NF_NEED_DEVICE();
-    vi_free_points(v);
-    v->npts = (long)numPoints;
-    if (numNotFound) *numNotFound = 0;
-    if (numPoints == 0) return NF_OK;
-    NF_TRY(dev_alloc(&v->d_targets, numPoints * 3));
-    NF_TRY(dev_alloc(&v->d_pcoords, numPoints * 2));
-    NF_TRY(dev_alloc(&v->d_vectors, numPoints * 3));
-    NF_TRY(dev_alloc(&v->d_cell, numPoints));
-    NF_TRY(dev_alloc(&v->d_best, numPoints));
-    NF_HIP(hipMemcpy(v->d_targets, targetPoints, sizeof(double) * 3 * numPoints, hipMemcpyHostToDevice));
-    NF_TRY(launch_find_points(v->grid->d_xy, v->grid->ncell, v->grid->row_length, &v->grid->boxes, v->d_targets, v->npts,
-                              v->periodX, tol2, v->d_best, v->d_cell, v->d_pcoords, nullptr));
-    v->h_cell.resize(numPoints);      // the located cells stay on the host too: they address the caller's host arrays
-    NF_HIP(hipMemcpy(v->h_cell.data(), v->d_cell, sizeof(long) * numPoints, hipMemcpyDeviceToHost));
-    NF_TRY(v->stage.resize((long)numPoints));
-    if (numNotFound) {
-        size_t n = 0;
-        for (long c : v->h_cell) n += (c < 0);
-        *numNotFound = n;
-    }
-    v->grid_version = v->grid->version;
-    return NF_OK;
-}
-NF_API_CATCH
-/* layout: 0 = (ncell,4) AoS, 1 = [4][ncell] planes (the engine's resident layout), 2 = (npts,4) rows gathered per point */
-static int vi_vectors(VectorInterp_t *v, const double *data_dev, int layout, double vectors[])
-{
-    NF_REQUIRE(vectors, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null output");
-    NF_REQUIRE(v->grid_version == v->grid->version, NF_ERR_STATE,
-               "mnt_vectorinterp_getFaceVectors: the grid was rebuilt after findPoints (the located cells are the old grid's): findPoints again");
-    NF_NEED_DEVICE();
-    NF_TRY(launch_face_vectors(v->grid->d_xy, v->d_cell, v->d_pcoords, v->npts, data_dev, v->grid->ncell, layout,
-                               v->periodX, v->d_vectors, nullptr));
-    NF_HIP(hipMemcpy(vectors, v->d_vectors, sizeof(double) * 3 * v->npts, hipMemcpyDeviceToHost));
-    return NF_OK;
-}
-int mnt_vectorinterp_getFaceVectorsDev(VectorInterp_t **self, const double *data_dev, int layout, double vectors[])
-try {
-    NF_REQUIRE(self && *self && data_dev, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null argument");
-    VectorInterp_t *v = *self;
-    NF_REQUIRE(v->grid, NF_ERR_STATE, "mnt_vectorinterp_getFaceVectors: setGrid first");
-    NF_REQUIRE(layout == 0 || layout == 1, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectorsDev: layout must be 0 ((ncell,4)) or 1 ([4][ncell] planes)");
-    if (v->npts == 0) return NF_OK;
-    return vi_vectors(v, data_dev, layout, vectors);
-}
-NF_API_CATCH
-// Host data: only the rows of the located cells travel (npts x 32 B, not ncell x 32 B): field.py:119 calls this at every
-// update() of the viewer.  Same arithmetic on the same values as the resident-data call: same bits.
-int mnt_vectorinterp_getFaceVectors(VectorInterp_t **self, const double data[], int placement, double vectors[])
-try {
-    NF_REQUIRE(self && *self && data, NF_ERR_ARG, "mnt_vectorinterp_getFaceVectors: null argument");
-    VectorInterp_t *v = *self;
-    NF_REQUIRE(v->grid, NF_ERR_STATE, "mnt_vectorinterp_getFaceVectors: setGrid first");
-    NF_REQUIRE(placement == MNT_CELL_BY_CELL_DATA, NF_ERR_ARG,
-               "mnt_vectorinterp_getFaceVectors: only CELL_BY_CELL_DATA (placement=0) is supported (field.py:94-95)");
-    if (v->npts == 0) return NF_OK;
-    NF_NEED_DEVICE();
-    NF_TRY(v->stage.upload(data, v->h_cell.data()));
-    return vi_vectors(v, v->stage.d, 2, vectors);
-}
-NF_API_CATCH
-int mnt_vectorinterp_getCells(VectorInterp_t **self, long long *cell_ids, double *pcoords)
-try {
-    NF_REQUIRE(self && *self, NF_ERR_ARG, "mnt_vectorinterp_getCells: null argument");
-    VectorInterp_t *v = *self;
-    if (v->npts == 0) return NF_OK;
-    NF_NEED_DEVICE();
-    if (cell_ids) NF_HIP(hipMemcpy(cell_ids, v->d_cell, sizeof(long) * v->npts, hipMemcpyDeviceToHost));
-    if (pcoords) NF_HIP(hipMemcpy(pcoords, v->d_pcoords, sizeof(double) * 2 * v->npts, hipMemcpyDeviceToHost));
-    return NF_OK;
-}
-NF_API_CATCH
-
-}  // extern "C"
+}  // namespace nf
 
 // =============================================================================================== Level 2
 struct nf_field {
@@ -851,6 +122,17 @@ static int field_free_geometry(nf_field *f)
     f->batch_steps = 0;
     f->batch_version = -1;
     dev_free(f->d_maxbits);
+    // the locator cache and the lent grid describe the corner table that was just freed: gone with it, on EVERY path out of
+    // set_bounds (an early return used to leave boxes keyed on the freed pointer, which hipMalloc often hands out again:
+    // round-5 advisor)
+    {
+        std::lock_guard<std::mutex> lock(f->grid_view.boxes.mtx);
+        f->grid_view.boxes.release();
+    }
+    f->grid_view.d_xy = nullptr;
+    f->grid_view.ncell = 0;
+    ++f->grid_view.version;
+    f->weights_built = false;
     return NF_OK;
 }
 
@@ -1200,8 +482,7 @@ try {
     for (int k = 0; k < 4; ++k) f->box[k] = box_key_to_double(keys[k]);
     f->grid_view.ncell = f->ncell;
     f->grid_view.d_xy = f->d_xy;
-    f->grid_view.boxes.release();     // a locator built on the old corner table says nothing about the new one
-    f->grid_view.row_length = f->nx;
+    f->grid_view.row_length = f->nx;  // (field_free_geometry above dropped the locator of the old corner table)
     ++f->grid_view.version;
     f->grid_view.owns_xy = false;
     f->weights_built = false;
@@ -1310,6 +591,13 @@ try {
 }
 NF_API_CATCH
 
+int nf_field_num_dropped_crossings(nf_field **self, size_t *n)
+try {
+    NF_REQUIRE(self && *self && n, NF_ERR_ARG, "nf_field_num_dropped_crossings: null argument");
+    *n = (size_t)(*self)->ws.dropped;
+    return NF_OK;
+}
+NF_API_CATCH
 int nf_field_set_overlapping_cells(nf_field **self, int warn)
 try {
     NF_REQUIRE(self && *self, NF_ERR_ARG, "nf_field_set_overlapping_cells: null field");
@@ -1657,102 +945,6 @@ try {
     NF_REQUIRE(self && *self && k3_ms, NF_ERR_ARG, "nf_field_timing_k3: null argument");
     *k3_ms = (*self)->last_k3_ms;
     return NF_OK;
-}
-NF_API_CATCH
-
-// ------------------------------------------------------------------------------------------- file decode helper
-// Inverse of HDF5's shuffle filter on the HOST (file decoding, like zlib's inflate next to it -- not a compute path):
-// src holds the es byte planes of n elements one after the other, dst receives the n elements.  Called by
-// nemoflux_amd/hdf5min.py from its inflate threads (ctypes releases the GIL); ten times faster than numpy's strided copies.
-int nf_host_unshuffle(const void *src, void *dst, size_t n, int es)
-try {
-    NF_REQUIRE(src && dst && es > 0 && es <= 16, NF_ERR_ARG, "nf_host_unshuffle: bad arguments");
-    const unsigned char *s = (const unsigned char *)src;
-    unsigned char *d = (unsigned char *)dst;
-    if (es == 4) {
-        const unsigned char *p0 = s, *p1 = s + n, *p2 = s + 2 * n, *p3 = s + 3 * n;
-        uint32_t *o = (uint32_t *)d;
-        if (((uintptr_t)d & 3) == 0) {
-            for (size_t i = 0; i < n; ++i)
-                o[i] = (uint32_t)p0[i] | ((uint32_t)p1[i] << 8) | ((uint32_t)p2[i] << 16) | ((uint32_t)p3[i] << 24);
-            return NF_OK;
-        }
-    }
-    for (int j = 0; j < es; ++j) {
-        const unsigned char *pj = s + (size_t)j * n;
-        for (size_t i = 0; i < n; ++i) d[i * es + j] = pj[i];
-    }
-    return NF_OK;
-}
-NF_API_CATCH
-
-// Gather n byte ranges into a staging buffer with `nthreads` native threads (file ingest: the compressed chunks of a group
-// of time steps, copied out of the mapped file into pinned memory).  One call, no interpreter lock between the copies: the
-// Python thread pool this replaces took the GIL twice per chunk and stalled for hundreds of milliseconds whenever the
-// caller's thread was busy in the interpreter.  Ranges are dealt to the threads in contiguous runs of about equal bytes.
-int nf_host_gather(const unsigned long long *src_addr, const unsigned long long *dst_addr, const long long *len, long long n,
-                   int nthreads)
-try {
-    NF_REQUIRE(n == 0 || (src_addr && dst_addr && len), NF_ERR_ARG, "nf_host_gather: null argument");
-    NF_REQUIRE(n >= 0 && nthreads >= 1 && nthreads <= 256, NF_ERR_ARG, "nf_host_gather: bad counts");
-    long long total = 0;
-    for (long long i = 0; i < n; ++i) {
-        NF_REQUIRE(len[i] >= 0, NF_ERR_ARG, "nf_host_gather: negative length");
-        total += len[i];
-    }
-    if (total == 0) return NF_OK;
-    const int nt = (int)std::min<long long>(nthreads, n);
-    auto work = [&](long long lo, long long hi) {
-        for (long long i = lo; i < hi; ++i)
-            if (len[i]) memcpy((void *)(uintptr_t)dst_addr[i], (const void *)(uintptr_t)src_addr[i], (size_t)len[i]);
-    };
-    if (nt <= 1) {
-        work(0, n);
-        return NF_OK;
-    }
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)nt);
-    const long long share = (total + nt - 1) / nt;
-    long long lo = 0;
-    try {
-        for (int t = 0; t < nt && lo < n; ++t) {
-            long long hi = lo, acc = 0;
-            while (hi < n && (acc < share || t == nt - 1)) acc += len[hi++];
-            pool.emplace_back(work, lo, hi);
-            lo = hi;
-        }
-    } catch (...) {   // a thread could not be started: the caller's thread finishes the rest, the started ones are joined
-        for (auto &th : pool) th.join();   // (destroying a joinable std::thread would call std::terminate)
-        work(lo, n);
-        return NF_OK;
-    }
-    for (auto &th : pool) th.join();
-    return NF_OK;
-}
-NF_API_CATCH
-
-// ------------------------------------------------------------------------------------------- datagen
-int nf_datagen_bounds(double *bounds_lon_dev, double *bounds_lat_dev, long ny, long nx, double xmin, double xmax,
-                      double ymin, double ymax, double delta_lon_deg, double delta_lat_deg, int lat_uses_dx,
-                      void *hip_stream)
-try {
-    NF_REQUIRE(bounds_lon_dev && bounds_lat_dev, NF_ERR_ARG, "nf_datagen_bounds: null argument");
-    NF_NEED_DEVICE();
-    NF_TRY(launch_datagen_bounds(bounds_lon_dev, bounds_lat_dev, ny, nx, xmin, xmax, ymin, ymax, delta_lon_deg,
-                                 delta_lat_deg, lat_uses_dx, (hipStream_t)hip_stream));
-    NF_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
-    return NF_OK;
-}
-NF_API_CATCH
-int nf_datagen_uv(void *u_dev, void *v_dev, int dtype, long t_begin, long t_end, long nt, long nz, long ny, long nx,
-                  double xmin, double xmax, double ymin, double ymax, double zmin, double zmax, int lat_uses_dx,
-                  int psi, void *hip_stream)
-try {
-    NF_REQUIRE(u_dev && v_dev, NF_ERR_ARG, "nf_datagen_uv: null argument");
-    NF_REQUIRE(dtype == NF_F64 || dtype == NF_F32, NF_ERR_ARG, "nf_datagen_uv: dtype must be NF_F64/NF_F32");
-    NF_NEED_DEVICE();
-    return launch_datagen_uv(u_dev, v_dev, dtype, t_begin, t_end, nt, nz, ny, nx, xmin, xmax, ymin, ymax, zmin, zmax,
-                             lat_uses_dx, psi, (hipStream_t)hip_stream);
 }
 NF_API_CATCH
 

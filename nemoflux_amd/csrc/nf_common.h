@@ -7,6 +7,7 @@
 #include <string>
 #include <cmath>
 #include <initializer_list>
+#include <mutex>
 #include <vector>
 
 #include "../../include/nemoflux_amd.h"
@@ -198,6 +199,7 @@ struct WeightSet {  // device-resident result: one record per (target segment, c
     // 1 = inside the grid, each point counted once; < 1 = part of the segment is outside (contributes 0, like mint)
     std::vector<double> coverage;
     int over_seg = -1;         // first target segment build_weights found covered more than once (over_covered), or -1
+    long dropped = 0;          // skip policy: (cell, segment image) crossings of unsupported cells that were left out
     // Unique-edge form for the engine's own planes (fold_weights): the south / west slots of integratedVelocity are copies
     // of the neighbours' north / east values (field.py:219-223), so every (cell, edge) weight is folded onto the element
     // of the two signed planes that really carries it and duplicates are merged per target segment (adjacent cells
@@ -230,6 +232,11 @@ struct LocatorBoxes {
     const double *xy = nullptr;  // the corner table the boxes were built from
     long ncell = 0;
     double period = -1.0;
+    // Objects that share a Grid share this cache.  Whoever may (re)build it or walks it holds `mtx` for the whole call
+    // (computeWeights / findPoints are synchronous: the kernels that read the boxes have finished when the call returns), and
+    // so does whoever releases it (new points, new row length, grid deletion): two host threads driving their own
+    // PolylineIntegral objects on one Grid are serialised here instead of racing on release() (round-5 advisor).
+    std::mutex mtx;
     void release();
     ~LocatorBoxes() { release(); }
 };
@@ -240,7 +247,8 @@ struct LocatorBoxes {
 int build_weights(const double *xy, long ncell, const double *segs_host, const int *seg_cc_host, int nseg,
                   double periodX, WeightSet *out, hipStream_t s, int skip_unsupported = 0, int overlap_warn = 0,
                   LocatorBoxes *boxes = nullptr, long row_length = 0);
-// gives the scratch memory that weight builds keep between calls (at most 1 GiB per host thread) back to the system
+// gives the idle scratch memory that weight builds / point searches keep between calls (a process-wide pool of at most 4
+// scratches of at most 1 GiB each) back to the system
 void weights_trim_scratch();
 
 // K3: gather + wavefront segmented reduction -> per-segment sums, then per-transect sums.

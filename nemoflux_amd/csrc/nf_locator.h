@@ -226,22 +226,21 @@ struct BuildScratch {
     }
 };
 constexpr size_t kScratchKeep = 1024ull << 20;   // the 65-transect batch of the ORCA12-like grid needs 0.9 GiB
-BuildScratch *&scratch_slot();   // the calling thread's cached scratch (nf_weights.hip); never freed at thread exit: the HIP
-                                 // runtime may be gone by then
+constexpr size_t kScratchPool = 4;               // idle scratches kept at most (one per concurrently building host thread)
+// The idle scratches of the PROCESS (nf_weights.hip), under a mutex: a build checks one out and hands it back, so a host
+// thread that ends leaves nothing behind (round-5 advisor: the per-thread slot leaked up to 1 GiB of HBM per exited thread)
+// and nf_release_scratch frees every one of them, whichever thread built with it.
+BuildScratch *scratch_checkout(int device);        // an idle scratch of this device, or nullptr
+bool scratch_checkin(BuildScratch *sc);            // false: the pool is full, the caller deletes it
 
-struct ScratchLease {   // takes the cached scratch (or a new one) for one build; gives it back only if told the stream is drained
+struct ScratchLease {   // takes a pooled scratch (or a new one) for one build; gives it back only if told the stream is drained
     BuildScratch *sc = nullptr;
     bool drained = false;
     ScratchLease()
     {
         int dev = -1;
         (void)hipGetDevice(&dev);
-        sc = scratch_slot();
-        scratch_slot() = nullptr;
-        if (sc && sc->device != dev) {
-            delete sc;
-            sc = nullptr;
-        }
+        sc = scratch_checkout(dev);
         if (!sc) {
             sc = new BuildScratch();
             sc->device = dev;
@@ -251,14 +250,13 @@ struct ScratchLease {   // takes the cached scratch (or a new one) for one build
     ScratchLease &operator=(const ScratchLease &) = delete;
     ~ScratchLease()
     {
-        if (drained && !scratch_slot() && sc->capacity() <= kScratchKeep) {
+        if (drained && sc->capacity() <= kScratchKeep) {
             sc->misc.rewind();
             sc->level[0].rewind();
             sc->level[1].rewind();
-            scratch_slot() = sc;
-        } else {
-            delete sc;      // hipFree waits for whatever is still running
+            if (scratch_checkin(sc)) return;
         }
+        delete sc;      // hipFree waits for whatever is still running
     }
 };
 

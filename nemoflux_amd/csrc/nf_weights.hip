@@ -33,6 +33,7 @@
 #include <cstring>  // rocprim's texture iterator needs host memset declared first
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <mutex>
 #include <vector>
 
 #include "nf_common.h"
@@ -293,7 +294,10 @@ __global__ __launch_bounds__(kBlock) void k_clip_pairs(const double *__restrict_
             // a zero-length piece (a repeated vertex) crosses nothing; the walk never lets one through, a one-cell grid has no walk
         } else if (quad_is_nonconvex(v)) {   // not a cell the weights are defined on: refuse if the line really crosses it
             // (skip policy: the cell contributes nothing and the segment's coverage says so)
-            if (!skip_unsupported && segment_overlaps_quad(v, g.qx, g.qy, g.dx, g.dy)) flag_cell(err, c, 1, g.s);
+            if (segment_overlaps_quad(v, g.qx, g.qy, g.dx, g.dy)) {
+                if (skip_unsupported) atomicAdd(err + 1, 1ull);     // counted: the caller's warning says how many were dropped
+                else flag_cell(err, c, 1, g.s);
+            }
         } else {
             hit = clip_cell(v, g.qx, g.qy, g.dx, g.dy, ta, tb);
         }
@@ -506,6 +510,7 @@ void WeightSet::release()
     if (seg_start) (void)hipFree(seg_start);
     coverage.clear();
     over_seg = -1;
+    dropped = 0;
     cell = nullptr;
     w4 = nullptr;
     seg = nullptr;
@@ -529,16 +534,39 @@ int weights_to_host(const WeightSet &ws, int64_t *cell_edge, double *weight, int
     return NF_OK;
 }
 
-BuildScratch *&scratch_slot()
+namespace {
+std::mutex g_pool_mtx;
+std::vector<BuildScratch *> g_pool;      // idle scratches; never freed at process exit: the HIP runtime may be gone by then
+}  // namespace
+
+BuildScratch *scratch_checkout(int device)
 {
-    static thread_local BuildScratch *slot = nullptr;
-    return slot;
+    std::lock_guard<std::mutex> lock(g_pool_mtx);
+    for (size_t k = g_pool.size(); k-- > 0;)
+        if (g_pool[k]->device == device) {
+            BuildScratch *sc = g_pool[k];
+            g_pool.erase(g_pool.begin() + (long)k);
+            return sc;
+        }
+    return nullptr;
+}
+
+bool scratch_checkin(BuildScratch *sc)
+{
+    std::lock_guard<std::mutex> lock(g_pool_mtx);
+    if (g_pool.size() >= kScratchPool) return false;
+    g_pool.push_back(sc);
+    return true;
 }
 
 void weights_trim_scratch()
 {
-    delete scratch_slot();
-    scratch_slot() = nullptr;
+    std::vector<BuildScratch *> idle;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mtx);
+        idle.swap(g_pool);
+    }
+    for (BuildScratch *sc : idle) delete sc;     // scratches checked out by a running build are not in the pool: untouched
 }
 
 void LocatorBoxes::release()
@@ -636,9 +664,10 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
     double *d_segs = nullptr;
     int *d_cc = nullptr;
     unsigned long long *d_err = nullptr;
-    NF_HIP(misc.take(&d_err, 1));
+    NF_HIP(misc.take(&d_err, 2));      // [0]: the error word (~0 = none); [1]: crossings of unsupported cells dropped ('skip')
     NF_HIP(hipMemsetAsync(d_err, 0xff, sizeof(unsigned long long), s));
-    unsigned long long err_word = ~0ull;
+    NF_HIP(hipMemsetAsync(d_err + 1, 0, sizeof(unsigned long long), s));
+    unsigned long long err_word = ~0ull, err_pair[2] = {~0ull, 0ull};
     auto refuse = [&](unsigned long long w) {
         char buf[256];
         const long cell = (long)(w >> 32);
@@ -692,12 +721,14 @@ int build_weights(const double *xy, long ncell, const double *segs_host, const i
                            (const long *)nullptr, none, d_err, skip_unsupported);
         NF_TRY(wk.scan_waves(cw, &nrec));
     }
-    NF_HIP(hipMemcpyAsync(&err_word, d_err, sizeof err_word, hipMemcpyDeviceToHost, s));
+    NF_HIP(hipMemcpyAsync(err_pair, d_err, sizeof err_pair, hipMemcpyDeviceToHost, s));
     NF_HIP(hipStreamSynchronize(s));
+    err_word = err_pair[0];
     if (err_word != ~0ull) {
         lease.drained = true;      // nothing of this build is running any more: the scratch may serve the next one
         return refuse(err_word);
     }
+    out->dropped = (long)err_pair[1];
     NF_REQUIRE(nrec < (1l << 31), NF_ERR_ARG, "weights: more than 2^31 (segment, cell) records; split the transect set");
 
     NF_HIP(hipMalloc((void **)&out->seg_start, sizeof(int) * (size_t)(nseg + 1)));

@@ -148,6 +148,10 @@ class Field(object):
             raise RuntimeError(f'ERROR: uo / vo carry {len(markers)} different _FillValue / missing_value markers '
                                f'({markers}); the engine masks at most two')
         kw.setdefault('timeObj', TimeObj.fromVariables(uvars))   # field.py:38: TimeObj(self.ncU)
+        # The reference's constructor never raises over a target line that meets a distorted polar cell (field.py:44-49: mint's
+        # computeWeights has no error path), so the drop-in signature leaves such cells out and warns (coverage + the number
+        # of crossings dropped); Field.fromArrays -- the batch constructor of bench.py / fluxplot-style drivers -- refuses.
+        kw.setdefault('unsupportedCells', 'skip')
         self._setup(t['bounds_lon'], t['bounds_lat'], t['deptht_bounds'], uo, vo, lonLatZPoints, sverdrup,
                     fill_value=markers[0] if markers else numpy.nan,
                     missing_value=markers[1] if len(markers) > 1 else numpy.nan, **kw)
@@ -277,8 +281,18 @@ class Field(object):
         # coverage > 1 (overlapping cells: a stretch of the line would be counted twice) was refused by build_weights above
         # unless overlappingCells='warn'; coverage < 1 means part of the line lies in no cell: mint only warns there [recall],
         # and so does this
+        n = ctypes.c_size_t()
+        check(lib.nf_field_num_dropped_crossings(ctypes.byref(self._h), ctypes.byref(n)))
+        self.droppedCrossings = n.value
+        if self.droppedCrossings:
+            import warnings
+            warnings.warn(f'{self.droppedCrossings} crossing(s) of cells the weights are not defined on (not convex in the lon-lat '
+                          f'plane / a corner at a geographic pole) were left out of the transects (unsupportedCells=\'skip\'); '
+                          f'the coverage warnings below name the segments', RuntimeWarning, stacklevel=3)
         for i, cov in enumerate(self.getCoverage()):
-            over = numpy.nonzero(cov > 1.0 + 1.e-8)[0] if overlappingCells == 'warn' else numpy.zeros(0, int)
+            xyz = self._polylines[i]
+            over = numpy.array([q for q in range(cov.size) if overlappingCells == 'warn' and
+                                _lib.over_covered(cov[q], xyz[q], xyz[q + 1])], dtype=int)
             if over.size:
                 import warnings
                 warnings.warn(f'transect {i}: {over.size} of {cov.size} target segments are covered more than once by the cells '

@@ -102,9 +102,18 @@ class PolylineIntegral(object):
         self.numSegments = xyz.shape[0] - 1
         check(lib.mnt_polylineintegral_computeWeights(ctypes.byref(self.obj), xyz.shape[0], _lib.dptr(xyz),
                                                       1 if counterclock else 0))
+        dropped = self.getNumberOfDroppedCrossings()
+        if dropped:     # policy 'skip' (the default: mint's computeWeights has no error path, field.py:44-49) left cells out
+            import warnings
+            cov = self.getCoverage()
+            low = numpy.nonzero(cov < 1.0 - 1.e-8)[0]
+            warnings.warn(f'{dropped} crossing(s) of cells the weights are not defined on (not convex in the lon-lat plane / a '
+                          f'corner at a geographic pole) were left out: {low.size} of {cov.size} target segments are covered '
+                          f'only in part (down to {cov.min():.6g}); setUnsupportedCells(\'refuse\') raises instead',
+                          RuntimeWarning, stacklevel=2)
         if getattr(self, '_overlap_warn', False):
             cov = self.getCoverage()
-            over = numpy.nonzero(cov > 1.0 + 1.e-8)[0]
+            over = numpy.array([q for q in range(cov.size) if _lib.over_covered(cov[q], xyz[q], xyz[q + 1])], dtype=int)
             if over.size:
                 import warnings
                 warnings.warn(f'{over.size} of {cov.size} target segments are covered more than once by the cells of the grid '
@@ -128,10 +137,11 @@ class PolylineIntegral(object):
         return res.value
 
     # ---- extensions beyond mint
-    def setUnsupportedCells(self, policy='refuse'):
+    def setUnsupportedCells(self, policy='skip'):
         """What computeWeights does when the line overlaps a cell the weights are not defined on (not convex in the lon-lat
-        plane / a corner at a geographic pole): 'refuse' (default) raises, 'skip' drops the cell -- getCoverage() then
-        reports < 1 for the segments concerned."""
+        plane / a corner at a geographic pole): 'skip' (the default of this mint-shaped class since round 6: mint's
+        computeWeights never raises there, field.py:44-49) drops the cell, warns (RuntimeWarning with the number of
+        crossings dropped) and getCoverage() reports < 1 for the segments concerned; 'refuse' raises, naming the cell."""
         if policy not in ('refuse', 'skip'):
             raise RuntimeError("ERROR: policy must be 'refuse' or 'skip'")
         check(lib.mnt_polylineintegral_setUnsupportedCells(ctypes.byref(self.obj), 1 if policy == 'skip' else 0))
@@ -144,6 +154,12 @@ class PolylineIntegral(object):
             raise RuntimeError("ERROR: policy must be 'refuse' or 'warn'")
         self._overlap_warn = policy == 'warn'
         check(lib.mnt_polylineintegral_setOverlappingCells(ctypes.byref(self.obj), 1 if policy == 'warn' else 0))
+
+    def getNumberOfDroppedCrossings(self):
+        """(cell, target-segment image) crossings of unsupported cells that the last computeWeights left out (policy 'skip')."""
+        n = ctypes.c_size_t()
+        check(lib.mnt_polylineintegral_getNumberOfDroppedCrossings(ctypes.byref(self.obj), ctypes.byref(n)))
+        return n.value
 
     def getCoverage(self):
         """Fraction of every target segment that lies inside cells of the grid (1 = inside, each point counted once)."""

@@ -274,3 +274,15 @@ def test_host_gather_helper():
         assert numpy.array_equal(dst, want), (n, threads)
     assert lib.nf_host_gather(None, None, None, 0, 1) == 0
     assert lib.nf_host_gather(None, None, None, 5, 1) == 1 and lib.nf_host_gather(sa.ctypes.data, da.ctypes.data, lens.ctypes.data, n, 0) == 1
+
+
+def test_python_overlap_predicate_is_the_engines():
+    """nemoflux_amd._lib.over_covered = over_covered of csrc/nf_common.h (and of the oracle): coverage > 1 + 1e-8 AND the
+    excess as a length > 1e-9 max(1, |coordinates|) degrees.  The Python warnings of policy 'warn' use it (round-5 advisor)."""
+    from nemoflux_amd._lib import over_covered
+    assert not over_covered(1.0 + 5e-9, (0., 0.), (10., 0.))                 # below the coverage tolerance
+    assert over_covered(1.5, (0., 0.), (10., 0.))                            # half of a 10-degree segment counted twice
+    assert not over_covered(1.00003, (170., 40.), (170. + 2e-9, 40.))        # 3e-5 of a 2e-9-degree segment: rounding noise
+    assert over_covered(2.0, (170., 40.), (170. + 2e-6, 40.))                # a whole tiny segment twice: 2e-6 > 1e-9 * 170
+    assert not over_covered(2.0, (170., 40.), (170. + 1e-8, 40.))            # 1e-8 of line < 1e-9 * 170 degrees
+    assert not over_covered(float('nan'), (0., 0.), (1., 0.))

@@ -98,6 +98,7 @@ def run(ncases=500, seed=1, verbose=True):
             pli = mint.PolylineIntegral()
             pli.setGrid(grid)
             pli.buildLocator(numCellsPerBucket=128, periodX=periodX, enableFolding=False)
+            pli.setUnsupportedCells('refuse')          # like the oracle's default: both must refuse the same cell
             try:
                 ow = oracle.polyline_weights(pts, xyz, periodX=periodX)
             except oracle.UnsupportedCell as e:
