@@ -22,6 +22,12 @@
  *   - all entry points are synchronous at return unless the name ends in _async.
  *   - there is NO CPU fallback: every compute entry point fails with NF_ERR_NO_DEVICE when no
  *     gfx950 device is usable.
+ *   - threads: the reference drives mint from one thread (fluxviz.py:20-23,351) and so may a client.  What holds beyond
+ *     that: the error text is per thread; one OBJECT (a PolylineIntegral, a VectorInterp, a field, an inflater) is used by
+ *     one thread at a time; different objects may be driven from different host threads even when they share a Grid_t --
+ *     the grid's locator cache is built, walked and released under the grid's own lock; the weight-build scratch is a
+ *     process-wide pool under a lock.  Giving a Grid_t new points (mnt_grid_build) while another thread still integrates
+ *     with objects made on it is the caller's race, as with mint.  nf_tuning_set is NOT thread-safe (see there).
  */
 #ifndef NEMOFLUX_AMD_H
 #define NEMOFLUX_AMD_H

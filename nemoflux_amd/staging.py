@@ -38,7 +38,11 @@ class StepStager(object):
         self.decoder = None
         self._early_upload = os.environ.get('NF_EARLY_UPLOAD', '1') != '0'
         self._bg_threads = int(os.environ.get('NF_GATHER_THREADS_BG', 8))
-        self._direct_upload = os.environ.get('NF_DIRECT_UPLOAD', '1') != '0'
+        # early upload: gather into pinned memory, then ONE copy (default) -- or, NF_DIRECT_UPLOAD=1, one hipMemcpyAsync per
+        # chunk straight from the mapped file (pageable source, no staging copy).  Both were measured again in round 6
+        # (profiles/r06_group_pipeline.txt): 20.4 against 21.2 ms per C3 step at G = 6, 24.2 against 24.7 at G = 13, and the
+        # per-chunk form is erratic under a running decode (62 to 309 ms for groups of the same size); round 3 had it 20.9 : 21.8
+        self._direct_upload = os.environ.get('NF_DIRECT_UPLOAD', '0') != '0'
         self.comp_bytes = [None, None]            # staging size per step of a variable on the device path
         self.group = 1
         if gpu_decode and os.environ.get('NF_GPU_INFLATE', '1') != '0':
@@ -63,6 +67,10 @@ class StepStager(object):
                 waves = max(1, int(os.environ.get('NF_INFLATE_WAVES', 2)))
                 g = max(1, waves * ChunkDecoder.capacity() // max(per_step, 1))
                 g = min(g, nt, max(1, int(max_group_bytes // (2 * self.step_bytes))))
+                # ... but a pass needs groups to overlap: the first group's host and device halves run under nothing, so a
+                # short series is cut into at least four groups (24 steps of the C3 image: 2 groups of 13 -> 24.7 ms per step,
+                # 4 groups of 6 -> 20.4, although a launch of 900 chunks decodes at 16.2 ms per step against 13.5 for 1 950)
+                g = min(g, max(1, -(-nt // 4)))
                 self.group = int(os.environ.get('NF_INFLATE_GROUP', g))
         self.on_device = self.decoder is not None
         self._slots = [None, None]                # per slot: dict of buffers

@@ -77,25 +77,27 @@ def test_c3_levels_inflate_bit_identical_to_zlib(c3):
     slab.free()
 
 
-@pytest.mark.parametrize('prefetch, group', [(True, None), (False, None), (True, 1)])
+@pytest.mark.parametrize('prefetch, group', [(True, None), (False, None), (True, 1), (True, 'all'), (False, 'all')])
 def test_c3_file_backed_field_against_the_oracle(c3, prefetch, group, oracle, monkeypatch):
     """(b) the file-backed Field on that image (device inflate, groups of time steps, the pipelined gather when prefetch is
     on; with groups of ONE step the staging thread also uploads the next step's compressed bytes while the GPU decodes
     this one) against the CPU ORACLE on the decoded values: every step's full (ncell, 4) field bit for bit, the transect
     totals to rounding -- in file order, out of order, and through computeAll."""
-    if group is not None:
-        monkeypatch.setenv('NF_INFLATE_GROUP', str(group))
     import contextlib
     import io as _io
     from nemoflux_amd.field import Field
     dg, u, v, lu, lv = c3
     nt = u.shape[0]
+    if group == 'all':          # every step of the series in ONE launch of the decoder
+        group = nt
+    if group is not None:
+        monkeypatch.setenv('NF_INFLATE_GROUP', str(group))
     tr = [transect_xyz("(-100,-80),(100,-80),(0,80)"), transect_xyz("(-170,10),(-20,-55),(135,62),(-170,10)")]
     blon, blat = dg.bounds_lon.cpu().numpy(), dg.bounds_lat.cpu().numpy()
     with contextlib.redirect_stdout(_io.StringIO()):
         ff = Field.fromArrays(blon, blat, dg.deptht_bounds, lu, lv, tr, fill_value=1.e20, prefetch=prefetch)
     st = ff._stager
-    assert st.on_device and st.comp_bytes[0] is not None and st.comp_bytes[1] is not None and st.group == (group or nt)
+    assert st.on_device and st.comp_bytes[0] is not None and st.comp_bytes[1] is not None and st.group == (group or -(-nt // 4))      # default: at least four groups per series
     pts = oracle.assemble_points(blon, blat)
     th = dg.zbot - dg.ztop
     ows = [oracle.polyline_weights(pts, xyz) for xyz in tr]
