@@ -574,7 +574,9 @@ def ingest_record(streams=256):
              'bound': 'decoder' if dev_step >= up_step else 'host link',
              'device_half_over_upload': round(dev_step / up_step, 2), 'bit_identical': g_ok,
              'note': 'the pipelined pass uploads the next group under the decode of this one: a file-backed step costs about the '
-                     'larger of the two (tools/filebacked_timing.py measures the whole pass: profiles/r06_filebacked_timing.txt)'}
+                     'larger of the two.  Here the 900 chunks are copies of ONE level and finish together; the distinct levels of a '
+                     'real file do not (16.2 ms per step for the device half, 20.2 ms per step for the whole pipelined pass of 24 '
+                     'steps incl. its first group: tools/filebacked_timing.py, profiles/r06_filebacked_timing.txt)'}
     return {'bound': group['bound'], 'group': group,
             'workload': f'{streams} copies of one {nx}x{ny} float32 level, HDF5 shuffle + zlib level 4 ({f.nbytes} bytes from '
                         f'{len(comp)}): one wavefront per stream, all resident at once',
