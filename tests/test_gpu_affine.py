@@ -289,3 +289,69 @@ def test_affine_psi_dateline_wrapped_periodic(kind):
     fids, _ = fld.vinterp.getCells()
     _check_vectors(fld.vectorValues, fids, cond, f'{kind} Field arrows')
     print(f'{kind}: level 1 worst |err| {worst:.3g}; Field total {err:.3g} segment {err_seg:.3g}; tolerance {tol:.3g}')
+
+
+def _nodal_case(nx, ny, seed):
+    """Random stream function on the LOGICAL nodes of a rotated global grid -- single-valued on the sphere: periodic across the
+    seam, one value along each pole row (all its nodes are one physical point) -- as cell-by-cell edge differences, plus the
+    planar (lon, lat) of every node as the cells store it (corner 0 of its cell; last row / column from corners 3 / 1)."""
+    blon, blat = _rotated_bounds(nx, ny)
+    rng = numpy.random.default_rng(seed)
+    psi = rng.standard_normal((ny + 1, nx + 1))
+    psi[:, -1] = psi[:, 0]
+    psi[0, :] = psi[0, 0]
+    psi[-1, :] = psi[-1, 0]
+    p0, p1, p2, p3 = psi[:-1, :-1], psi[:-1, 1:], psi[1:, 1:], psi[1:, :-1]
+    data = numpy.ascontiguousarray(numpy.stack([p1 - p0, p2 - p1, p2 - p3, p3 - p0], axis=-1).reshape(-1, 4))
+    return blon, blat, psi, data, rng
+
+
+@pytest.mark.parametrize('nx,ny', [(72, 36), (360, 180)])
+def test_random_nodal_psi_between_nodes_of_rotated_grids(nx, ny):
+    """The second oracle-free closed form on curvilinear cells: ANY nodal psi is reproduced by the bilinear interpolants, so for
+    edge data = nodal differences the flux across a polyline that starts and ends on grid NODES is psi(end) - psi(start),
+    whatever its interior vertices (README.md:45,58) -- arbitrary conforming edge data, not only an affine field.  On the
+    un-rotated grid this was tested since round 1; on the rotated grid only closed loops (-> 0) were, because the nodes
+    were thought of in logical coordinates: but every node's planar (lon, lat) is a corner of a cell.  periodX = 360 (psi is
+    periodic and the cells sit on their own branches); Level 1 and Field."""
+    from nemoflux_amd import mint
+    from nemoflux_amd.field import _geometry_only
+    blon, blat, psi, data, rng = _nodal_case(nx, ny, 2026 + nx)
+    geo = _geometry_only(blon, blat)
+    pts = geo['points']
+    cell = pts.reshape(ny, nx, 4, 3)
+    lines, want = [], []
+    while len(lines) < 100:
+        ja, jb = rng.integers(ny // 12 + 1, ny - ny // 12, 2)       # clear of the rotated poles' own rows
+        ia, ib = rng.integers(0, nx, 2)
+        a, b = cell[ja, ia, 0, :2], cell[jb, ib, 0, :2]              # node (j, i) = corner 0 of cell (j, i)
+        if max(abs(a[1]), abs(b[1])) > 84.:
+            continue
+        m = int(rng.integers(0, 4))
+        xyz = numpy.zeros((m + 2, 3))
+        xyz[0, :2], xyz[-1, :2] = a, b
+        xyz[1:-1, 0], xyz[1:-1, 1] = rng.uniform(-175., 175., m), rng.uniform(-84., 84., m)
+        lines.append(xyz)
+        want.append(psi[jb, ib] - psi[ja, ia])
+    want = numpy.array(want)
+    # a line crosses up to ~(nx + ny) cells, each adding a rounding error of ~1e-13 |psi differences| (|psi| ~ 1): measured
+    # 3.5e-13 on 72 x 36 and 8.6e-12 on 360 x 180
+    tol = 1e-13 * (nx + ny)
+    grid = mint.Grid()
+    grid.setPoints(pts)
+    worst = 0.
+    for k, xyz in enumerate(lines):
+        pli = mint.PolylineIntegral()
+        pli.setGrid(grid)
+        pli.buildLocator(numCellsPerBucket=128, periodX=360., enableFolding=False)
+        pli.computeWeights(xyz, counterclock=False)
+        assert numpy.all(numpy.abs(pli.getCoverage() - 1.) <= 1e-9), (k, pli.getCoverage())
+        got = pli.getIntegral(data)
+        worst = max(worst, abs(got - want[k]))
+        assert abs(got - want[k]) <= tol, (k, got, want[k])
+    U, V = _field_uv(data, geo['arcLengths'], ny, nx)
+    fld = _quiet_field(blon, blat, numpy.array([[0., 1.]]), U, V, lines, periodX=360., unsupportedCells='skip')
+    tot, _ = fld.computeAll()
+    ferr = numpy.abs(tot[0] - want).max()
+    print(f'rotated {nx} x {ny}, random nodal psi, 100 node-to-node lines: level 1 worst |err| {worst:.3g}, Field {ferr:.3g}')
+    assert ferr <= tol

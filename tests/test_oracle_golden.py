@@ -776,3 +776,36 @@ def test_oracle_affine_psi_open_polylines_and_face_vectors(kind, oracle):
     vec, ids = oracle.vector_interp(pts, tg, data, periodX=0.)
     assert (ids >= 0).all()
     assert numpy.abs(vec - [b, -a, 0.]).max() <= 1e-10 * (abs(a) + abs(b))
+
+
+def test_oracle_random_nodal_psi_between_nodes_of_a_rotated_grid(oracle):
+    """CPU twin of tests/test_gpu_affine.py::test_random_nodal_psi_between_nodes_of_rotated_grids: on the ROTATED grid too the
+    flux between two grid nodes is psi(end) - psi(start) for any interior vertices -- the nodes' planar coordinates are corners
+    of cells.  psi single-valued on the sphere (periodic seam, one value per pole row); periodX = 360."""
+    nx, ny = 72, 36
+    o = oracle.DataGen(nx, ny, 1, 1)
+    o.rotatePole((20., 30.))
+    pts = oracle.assemble_points(o.bounds_lon, o.bounds_lat)
+    rng = numpy.random.default_rng(5)
+    psi = rng.standard_normal((ny + 1, nx + 1))
+    psi[:, -1] = psi[:, 0]
+    psi[0, :] = psi[0, 0]
+    psi[-1, :] = psi[-1, 0]
+    p0, p1, p2, p3 = psi[:-1, :-1], psi[:-1, 1:], psi[1:, 1:], psi[1:, :-1]
+    data = numpy.stack([p1 - p0, p2 - p1, p2 - p3, p3 - p0], axis=-1).reshape(-1, 4)
+    cell = pts.reshape(ny, nx, 4, 3)
+    done = 0
+    while done < 40:
+        ja, jb = rng.integers(4, ny - 3, 2)
+        ia, ib = rng.integers(0, nx, 2)
+        a, b = cell[ja, ia, 0, :2], cell[jb, ib, 0, :2]
+        if max(abs(a[1]), abs(b[1])) > 80.:
+            continue
+        m = int(rng.integers(0, 4))
+        xyz = numpy.zeros((m + 2, 3))
+        xyz[0, :2], xyz[-1, :2] = a, b
+        xyz[1:-1, 0], xyz[1:-1, 1] = rng.uniform(-175., 175., m), rng.uniform(-80., 80., m)
+        w = oracle.polyline_weights(pts, xyz, periodX=360., skip_unsupported=True)
+        assert numpy.all(numpy.abs(w.coverage - 1.) <= 1e-9), w.coverage
+        assert abs(oracle.get_integral(w, data) - (psi[jb, ib] - psi[ja, ia])) <= 1e-11
+        done += 1
