@@ -7,6 +7,7 @@ Test infrastructure (uses oracle/): never imported by the product."""
 import os
 import sys
 import time
+import warnings
 
 import numpy
 
@@ -108,6 +109,25 @@ def run(ncases=500, seed=1, verbose=True):
                     assert f'cell {e.cell}' in str(ge), (case, kind, str(ge), e.cell)
                     stats['refused'] += 1
                     kinds[('refused', kind)] = kinds.get(('refused', kind), 0) + 1
+                    # round 6: the same line under the drop-in's default policy ('skip'): the unsupported cells drop out of both
+                    # sides alike -- same entries, same coverage -- and the device counts what it dropped
+                    try:
+                        osk = oracle.polyline_weights(pts, xyz, periodX=periodX, skip_unsupported=True)
+                    except (oracle.OverCovered, oracle.UnsupportedCell):
+                        continue        # what is left of the line is over-covered / Newton fails elsewhere: other campaigns
+                    pli.setUnsupportedCells('skip')
+                    with warnings.catch_warnings():
+                        warnings.simplefilter('ignore')
+                        pli.computeWeights(xyz, counterclock=False)
+                    assert pli.getNumberOfDroppedCrossings() >= 1, (case, kind)
+                    assert numpy.allclose(pli.getCoverage(), osk.coverage, rtol=0, atol=1e-10), (case, kind)
+                    ce, w, sg = pli.getWeights()
+                    gd = {}
+                    for a, b, c in zip(sg.tolist(), ce.tolist(), w.tolist()):
+                        gd[(a, b)] = gd.get((a, b), 0.0) + c
+                    od = osk.as_dict()
+                    assert set(gd) == set(od) and (not od or max(abs(gd[k] - od[k]) for k in od) <= 1e-12), (case, kind)
+                    stats['skipped_ok'] = stats.get('skipped_ok', 0) + 1
                     continue
                 raise AssertionError(f'case {case} ({kind}): oracle refuses cell {e.cell}, the GPU does not')
             except oracle.OverCovered as e:
