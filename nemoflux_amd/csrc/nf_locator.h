@@ -212,7 +212,7 @@ struct Arena {
     template <typename T> hipError_t take(T **out, size_t count) { return take((void **)out, sizeof(T) * count); }
 };
 
-// The arenas of a build, kept between builds of the same host thread while they are small (a viewer makes one
+// The arenas of a build, kept between builds (in a process-wide pool, below) while they are small (a viewer makes one
 // PolylineIntegral per transect: without this every one of them paid ten hipMalloc / hipFree pairs, more than its kernels).
 struct BuildScratch {
     Arena misc, level[2];
