@@ -310,3 +310,27 @@ def affine_expected(xyz, a, b):
     d = numpy.diff(xyz[:, :2], axis=0)
     seg = a * d[:, 0] + b * d[:, 1]
     return seg, float(a * (xyz[-1, 0] - xyz[0, 0]) + b * (xyz[-1, 1] - xyz[0, 1]))
+
+
+def curl_of_bilinear_case(points, psi_cells, rng, n, ok):
+    """Oracle-free expectation for mint.VectorInterp on curvilinear cells with NON-constant data (round 6): n target points
+    made FORWARD from chosen (cell, xi, eta) -- p = F(xi, eta), no inverse map involved -- in cells where `ok`, and the vector
+    the lowest-order face interpolation of edge data = nodal differences of psi must give there: the curl of the cell's
+    bilinear psi_h, (d psi_h / d lat, -d psi_h / d lon, 0), from grad psi_h = DF^-T grad_ref psi_hat (the gradient form; the
+    engine and the oracle evaluate the Piola form (psi_eta r_xi - psi_xi r_eta) / J).
+    points (ncell,4,3); psi_cells (ncell,4): psi at the four corners of every cell.  Returns cells, xi, eta, targets (n,3), v."""
+    cells = rng.choice(numpy.nonzero(ok)[0], n)
+    xi, eta = rng.uniform(0.05, 0.95, n), rng.uniform(0.05, 0.95, n)
+    P = points[cells][:, :, :2]
+    N = numpy.stack([(1 - xi) * (1 - eta), xi * (1 - eta), xi * eta, (1 - xi) * eta], axis=1)
+    dNx = numpy.stack([-(1 - eta), (1 - eta), eta, -eta], axis=1)
+    dNe = numpy.stack([-(1 - xi), -xi, xi, (1 - xi)], axis=1)
+    targets = numpy.zeros((n, 3))
+    targets[:, :2] = (N[:, :, None] * P).sum(axis=1)
+    rxi, reta = (dNx[:, :, None] * P).sum(axis=1), (dNe[:, :, None] * P).sum(axis=1)
+    ps = psi_cells[cells]
+    pxi, peta = (dNx * ps).sum(axis=1), (dNe * ps).sum(axis=1)
+    J = rxi[:, 0] * reta[:, 1] - rxi[:, 1] * reta[:, 0]
+    gx = (reta[:, 1] * pxi - rxi[:, 1] * peta) / J
+    gy = (-reta[:, 0] * pxi + rxi[:, 0] * peta) / J
+    return cells, xi, eta, targets, numpy.stack([gy, -gx, numpy.zeros(n)], axis=1)

@@ -355,3 +355,51 @@ def test_random_nodal_psi_between_nodes_of_rotated_grids(nx, ny):
     ferr = numpy.abs(tot[0] - want).max()
     print(f'rotated {nx} x {ny}, random nodal psi, 100 node-to-node lines: level 1 worst |err| {worst:.3g}, Field {ferr:.3g}')
     assert ferr <= tol
+
+
+@pytest.mark.parametrize('kind', ['c2_rotated', 'orca025_real', 'orca12_rotated'])
+def test_face_vectors_are_the_curl_of_the_bilinear_psi(kind):
+    """Oracle-free, NON-constant data: for edge data = nodal differences of any nodal psi the face-vector interpolation must
+    return the curl of the cell's bilinear psi_h at the target point.  The points are made FORWARD from chosen (cell, xi, eta),
+    so findPoints has to return exactly that cell and those parametric coordinates (an inverse-bilinear check that shares no
+    text with the device's Newton), and getFaceVectors the closed form of conftest.curl_of_bilinear_case (gradient form
+    against the engine's Piola form).  field.py:90-95,119-120."""
+    from conftest import curl_of_bilinear_case
+    from nemoflux_amd import mint
+    from nemoflux_amd.field import _geometry_only
+    blon, blat, _ = _case(kind)
+    ny, nx = blon.shape[:2]
+    pts = _geometry_only(blon, blat)['points']
+    rng = numpy.random.default_rng(31)
+    rotated = kind != 'orca025_real'
+    if rotated:       # nodal psi on the logical mesh, single-valued on the sphere
+        psi = rng.standard_normal((ny + 1, nx + 1))
+        psi[:, -1] = psi[:, 0]
+        psi[0, :], psi[-1, :] = psi[0, 0], psi[-1, 0]
+        pc = numpy.stack([psi[:-1, :-1], psi[:-1, 1:], psi[1:, 1:], psi[1:, :-1]], axis=-1).reshape(-1, 4)
+    else:             # the real geometry is conforming too, but nothing here needs that: psi per cell corner
+        pc = rng.standard_normal((ny * nx, 4))
+    data = numpy.ascontiguousarray(numpy.stack([pc[:, 1] - pc[:, 0], pc[:, 2] - pc[:, 1], pc[:, 2] - pc[:, 3],
+                                                pc[:, 3] - pc[:, 0]], axis=1))
+    ok = numpy.ptp(pts[:, :, 0], axis=1) < 90.          # not the cells that reach around a geographic pole
+    if rotated:
+        ok.reshape(ny, nx)[0, :] = ok.reshape(ny, nx)[-1, :] = False      # the degenerate triangles at the rotated poles
+    cells, xi, eta, targets, want = curl_of_bilinear_case(pts, pc, rng, NPOINTS, ok)
+    grid = mint.Grid()
+    grid.setPoints(pts)
+    grid.setRowLength(nx)
+    vi = mint.VectorInterp()
+    vi.setGrid(grid)
+    vi.buildLocator(numCellsPerBucket=128, periodX=360. if rotated else 0., enableFolding=False)
+    assert vi.findPoints(targets, tol2=1.e-12) == 0
+    ids, pcoords = vi.getCells()
+    assert numpy.array_equal(ids, cells)
+    perr = max(numpy.abs(pcoords[:, 0] - xi).max(), numpy.abs(pcoords[:, 1] - eta).max())
+    vec = vi.getFaceVectors(data)
+    amp, _ = _cell_condition(pts)
+    err = numpy.abs(vec - want).max(axis=1)
+    bound = 64 * numpy.finfo(float).eps * amp[cells] * numpy.abs(want).max(axis=1).clip(min=numpy.abs(data[cells]).max(axis=1))
+    print(f'{kind}: {NPOINTS} points made forward from (cell, xi, eta): cells identical, max |pcoord error| {perr:.3g}, '
+          f'vectors max |err| {err.max():.3g} (max |v| {numpy.abs(want).max():.3g}), max err / bound {(err / bound).max():.3g}')
+    assert perr <= 1e-9
+    assert numpy.all(err <= bound)

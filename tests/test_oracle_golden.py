@@ -809,3 +809,33 @@ def test_oracle_random_nodal_psi_between_nodes_of_a_rotated_grid(oracle):
         assert numpy.all(numpy.abs(w.coverage - 1.) <= 1e-9), w.coverage
         assert abs(oracle.get_integral(w, data) - (psi[jb, ib] - psi[ja, ia])) <= 1e-11
         done += 1
+
+
+def test_oracle_face_vectors_are_the_curl_of_the_bilinear_psi(oracle):
+    """CPU twin of tests/test_gpu_affine.py::test_face_vectors_are_the_curl_of_the_bilinear_psi (rotated 72 x 36 grid, periodX =
+    360, and the real ORCA025 geometry): points made forward from (cell, xi, eta) are located in that cell and the interpolated
+    vector is the curl of the cell's bilinear psi_h -- non-constant data, no shared helper on the expectation's side."""
+    from conftest import curl_of_bilinear_case
+    rng = numpy.random.default_rng(3)
+    nx, ny = 72, 36
+    d = oracle.DataGen(nx, ny, 1, 1)
+    d.rotatePole((20., 30.))
+    g = load_golden('sa_T_bounds')
+    for pts, periodX, rot in ((oracle.assemble_points(d.bounds_lon, d.bounds_lat), 360., True),
+                              (oracle.assemble_points(g['bounds_lon'], g['bounds_lat']), 0., False)):
+        ncell = pts.shape[0]
+        if rot:
+            psi = rng.standard_normal((ny + 1, nx + 1))
+            psi[:, -1] = psi[:, 0]
+            psi[0, :], psi[-1, :] = psi[0, 0], psi[-1, 0]
+            pc = numpy.stack([psi[:-1, :-1], psi[:-1, 1:], psi[1:, 1:], psi[1:, :-1]], axis=-1).reshape(-1, 4)
+        else:
+            pc = rng.standard_normal((ncell, 4))
+        data = numpy.stack([pc[:, 1] - pc[:, 0], pc[:, 2] - pc[:, 1], pc[:, 2] - pc[:, 3], pc[:, 3] - pc[:, 0]], axis=1)
+        ok = numpy.ptp(pts[:, :, 0], axis=1) < 90.
+        if rot:
+            ok.reshape(ny, nx)[0, :] = ok.reshape(ny, nx)[-1, :] = False
+        cells, xi, eta, tg, want = curl_of_bilinear_case(pts, pc, rng, 3000, ok)
+        vec, ids = oracle.vector_interp(pts, tg, data, periodX=periodX)
+        assert numpy.array_equal(ids, cells)
+        assert numpy.abs(vec - want).max() <= 1e-10 * numpy.abs(want).max()
