@@ -398,7 +398,11 @@ def test_face_vectors_are_the_curl_of_the_bilinear_psi(kind):
     vec = vi.getFaceVectors(data)
     amp, _ = _cell_condition(pts)
     err = numpy.abs(vec - want).max(axis=1)
-    bound = 64 * numpy.finfo(float).eps * amp[cells] * numpy.abs(want).max(axis=1).clip(min=numpy.abs(data[cells]).max(axis=1))
+    # rounding of the corner coordinates (as in _check_vectors) + what the error of the located (xi, eta) -- measured just above,
+    # asserted <= 1e-9 below; 1.3e-10 in the slender cells next to the rotated poles of the ORCA12-size grid -- does to a
+    # vector field whose relative variation across a cell is O(1): 4 x that error x |v|
+    size = numpy.abs(want).max(axis=1).clip(min=numpy.abs(data[cells]).max(axis=1))
+    bound = (64 * numpy.finfo(float).eps * amp[cells] + 4 * perr) * size
     print(f'{kind}: {NPOINTS} points made forward from (cell, xi, eta): cells identical, max |pcoord error| {perr:.3g}, '
           f'vectors max |err| {err.max():.3g} (max |v| {numpy.abs(want).max():.3g}), max err / bound {(err / bound).max():.3g}')
     assert perr <= 1e-9
